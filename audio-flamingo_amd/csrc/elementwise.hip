@@ -1,0 +1,632 @@
+// HBM-bound glue kernels of the AF3 training path (gfx950): transposes, activations, RoPE, conv im2col,
+// pooling, embedding gather/scatter, bias gradients, AdamW.  All loads/stores are 8- or 16-byte per lane,
+// coalesced across the 64-lane wave; grids are capped at ~2048 blocks and grid-stride (guide G11/G13).
+#include "common.h"
+#include "../../include/afk.h"
+
+namespace {
+
+inline int ew_grid(int64_t n_items, int per_block) {
+    int64_t g = afk_cdiv(n_items, per_block);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ batched 2-D transpose (bf16)
+// out[b1][b2][c][r] = in[b1][b2][r][c], r < R, c < C; columns R..Rpad-1 of out are zero-filled so that the
+// transposed operand can be fed to the NT GEMM with K padded to a multiple of 64.
+// 64x64 tile through LDS: 16-byte row reads, 2-byte conflict-free column writes to LDS, 16-byte row writes out.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int R, int C,
+                                                        int Rpad, int64_t ld_in, int64_t ld_out, int nb2,
+                                                        int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out) {
+    __shared__ bf16 tile[64][66];  // tile[c][r], +2 pad: column writes hit distinct banks
+    const int b = blockIdx.z, b1 = b / nb2, b2 = b - b1 * nb2;
+    in += b1 * bs1_in + b2 * bs2_in;
+    out += b1 * bs1_out + b2 * bs2_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    // load: 64 rows x 8 chunks of 8 bf16 = 512 chunks, 2 per thread
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = t + 256 * k;
+        const int r = idx >> 3, ch = idx & 7;
+        const int gr = r0 + r, gc = c0 + ch * 8;
+        bf16x8 v;
+        if (gr < R && gc + 7 < C) {
+            v = *(const bf16x8*)(in + (int64_t)gr * ld_in + gc);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (gr < R && gc + e < C) ? in[(int64_t)gr * ld_in + gc + e] : (bf16)0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][r] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int idx = t + 256 * k;
+        const int c = idx >> 3, ch = idx & 7;
+        const int gc = c0 + c, gr = r0 + ch * 8;
+        if (gc < C && gr < Rpad) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[c][ch * 8 + e];
+            if (gr + 7 < Rpad) {
+                *(bf16x8*)(out + (int64_t)gc * ld_out + gr) = v;
+            } else {
+                for (int e = 0; e < 8 && gr + e < Rpad; ++e) out[(int64_t)gc * ld_out + gr + e] = v[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ activations
+// dx = dy * gelu'(pre)      (exact-erf GELU; oracle F.gelu, activations.py:70-89)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre,
+                                                       bf16* __restrict__ dx, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 d = *(const bf16x8*)(dy + 8 * i);
+        const bf16x8 p = *(const bf16x8*)(pre + 8 * i);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)d[e] * gelu_grad_f((float)p[e]));
+        *(bf16x8*)(dx + 8 * i) = o;
+    }
+}
+
+// y = gelu(x)  (standalone; conv stem uses the GEMM epilogue instead)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 p = *(const bf16x8*)(x + 8 * i);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)gelu_f((float)p[e]);
+        *(bf16x8*)(y + 8 * i) = o;
+    }
+}
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// h = bf16(bf16(silu(g)) * u)   gu = [rows, 2I] (gate | up), h = [rows, I]   (Qwen2MLP.forward, modeling_qwen2.py:46-48)
+__global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ h, int64_t rows,
+                                                           int I) {
+    const int vpr = I >> 3;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        const bf16x8 g = *(const bf16x8*)(gu + r * 2 * I + c);
+        const bf16x8 u = *(const bf16x8*)(gu + r * 2 * I + I + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gf = (float)g[e];
+            o[e] = (bf16)(rbf(gf * sigmoid_f(gf)) * (float)u[e]);
+        }
+        *(bf16x8*)(h + r * I + c) = o;
+    }
+}
+
+// dgu[:, :I] = dh*u*silu'(g) ; dgu[:, I:] = dh*silu(g)
+__global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dh,
+                                                           bf16* __restrict__ dgu, int64_t rows, int I) {
+    const int vpr = I >> 3;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        const bf16x8 g = *(const bf16x8*)(gu + r * 2 * I + c);
+        const bf16x8 u = *(const bf16x8*)(gu + r * 2 * I + I + c);
+        const bf16x8 d = *(const bf16x8*)(dh + r * I + c);
+        bf16x8 og, ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gf = (float)g[e], uf = (float)u[e], df = (float)d[e];
+            const float s = sigmoid_f(gf);
+            const float silu = gf * s;
+            og[e] = (bf16)(df * uf * (s * (1.f + gf * (1.f - s))));
+            ou[e] = (bf16)(df * silu);
+        }
+        *(bf16x8*)(dgu + r * 2 * I + c) = og;
+        *(bf16x8*)(dgu + r * 2 * I + I + c) = ou;
+    }
+}
+
+// ------------------------------------------------------------------ RoPE (rotate-half), in place on the q|k columns
+// apply_rotary_pos_emb (modeling_qwen2.py:112-135): x*cos + rotate_half(x)*sin with cos/sin rounded to bf16
+// (:102) and every product/sum a bf16 tensor op.  buf = [rows, ld]; heads 0..nheads-1 of width D start at
+// column 0 (q heads then k heads, contiguous).  pos[row] gives the position id (null -> row % S).
+// sign=+1 forward, -1 backward (the transpose of a rotation is the rotation by -theta).
+__global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ buf, const bf16* __restrict__ cos_t,
+                                                   const bf16* __restrict__ sin_t, const int* __restrict__ pos, int64_t rows,
+                                                   int S, int ld, int nheads, int D, float sign) {
+    const int half = D >> 1, vph = half >> 2;  // bf16x4 vectors per half-head
+    const int64_t total = rows * nheads * vph;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vph);
+        const int64_t t = i / vph;
+        const int h = (int)(t % nheads);
+        const int64_t r = t / nheads;
+        const int p = pos ? pos[r] : (int)(r % S);
+        bf16* x1p = buf + r * ld + h * D + 4 * v;
+        bf16* x2p = x1p + half;
+        const bf16x4 x1 = *(const bf16x4*)x1p, x2 = *(const bf16x4*)x2p;
+        const bf16x4 c1 = *(const bf16x4*)(cos_t + (int64_t)p * D + 4 * v);
+        const bf16x4 s1 = *(const bf16x4*)(sin_t + (int64_t)p * D + 4 * v);
+        const bf16x4 c2 = *(const bf16x4*)(cos_t + (int64_t)p * D + half + 4 * v);
+        const bf16x4 s2 = *(const bf16x4*)(sin_t + (int64_t)p * D + half + 4 * v);
+        bf16x4 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = (float)x1[e], b = (float)x2[e];
+            o1[e] = (bf16)(rbf(a * (float)c1[e]) + rbf(-sign * b * (float)s1[e]));
+            o2[e] = (bf16)(rbf(b * (float)c2[e]) + rbf(sign * a * (float)s2[e]));
+        }
+        *(bf16x4*)x1p = o1;
+        *(bf16x4*)x2p = o2;
+    }
+}
+
+// ------------------------------------------------------------------ misc elementwise
+__global__ __launch_bounds__(256) void add_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, bf16* __restrict__ o,
+                                                  int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 x = *(const bf16x8*)(a + 8 * i), y = *(const bf16x8*)(b + 8 * i);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)x[e] + (float)y[e]);
+        *(bf16x8*)(o + 8 * i) = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ a, bf16* __restrict__ o, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = (bf16)a[i];
+}
+
+// out[r] (+)= sum_c in[r][c]  - bias gradient from the transposed grad (one wave per row, coalesced)
+__global__ __launch_bounds__(256) void rowsum_kernel(const bf16* __restrict__ in, int64_t ld, int C, bf16* __restrict__ out,
+                                                     int rows, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* p = in + (int64_t)row * ld;
+    float s = 0.f;
+    const int nv = C >> 3;
+    for (int v = lane; v < nv; v += 64) {
+        const bf16x8 t = *(const bf16x8*)(p + 8 * v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)t[e];
+    }
+    for (int c = nv * 8 + lane; c < C; c += 64) s += (float)p[c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = (bf16)(accumulate ? s + (float)out[row] : s);
+}
+
+// ------------------------------------------------------------------ conv stem as GEMM: im2col / col2im
+// conv1 (Conv1d(128->1280,k3,p1), modeling_audioflamingo3.py:328,380): x = [W, C, T] (f32 or bf16 log-mel,
+// channel-major as the feature extractor emits it) -> col[(w,t)][kk*C + c] = x[w][c][t+kk-1] (0 outside).
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_cmajor_kernel(const T* __restrict__ x, bf16* __restrict__ col, int W, int C,
+                                                            int Tn) {
+    __shared__ float tile[64][65];  // [c][t], t covers 62 outputs + halo
+    const int w = blockIdx.z, c0 = blockIdx.y * 64, t0 = blockIdx.x * 62;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int c = idx >> 6, tt = idx & 63;
+        const int t = t0 - 1 + tt, gc = c0 + c;
+        float v = 0.f;
+        if (t >= 0 && t < Tn && gc < C) v = (float)x[((int64_t)w * C + gc) * Tn + t];
+        tile[c][tt] = v;
+    }
+    __syncthreads();
+    // outputs: 62 time steps x 3 taps x 64 channels
+    for (int idx = tid; idx < 62 * 3 * 64; idx += 256) {
+        const int c = idx & 63;
+        const int kk = (idx >> 6) % 3;
+        const int tt = idx / 192;
+        const int t = t0 + tt, gc = c0 + c;
+        if (t < Tn && gc < C) col[((int64_t)w * Tn + t) * (3 * C) + kk * C + gc] = (bf16)tile[c][tt + kk];
+    }
+}
+
+// conv2 (Conv1d(1280->1280,k3,s2,p1), :329,381): h = [W, Tin, C] time-major (conv1 GEMM output) ->
+// col[(w,t')][kk*C + c] = h[w][2t'+kk-1][c]; pure 16-byte row copies.
+__global__ __launch_bounds__(256) void im2col_tmajor_s2_kernel(const bf16* __restrict__ h, bf16* __restrict__ col, int W,
+                                                               int Tin, int Tout, int C) {
+    const int vpr = C >> 3;
+    const int64_t total = (int64_t)W * Tout * 3 * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        int64_t t = i / vpr;
+        const int kk = (int)(t % 3);
+        t /= 3;
+        const int to = (int)(t % Tout);
+        const int w = (int)(t / Tout);
+        const int ti = 2 * to + kk - 1;
+        bf16x8 val;
+        if (ti >= 0 && ti < Tin) {
+            val = *(const bf16x8*)(h + ((int64_t)w * Tin + ti) * C + 8 * v);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) val[e] = (bf16)0.f;
+        }
+        *(bf16x8*)(col + ((int64_t)w * Tout + to) * (3 * C) + kk * C + 8 * v) = val;
+    }
+}
+
+// col2im for conv2 dgrad (gather form, no atomics): dh[w][j][c] = sum over (t',kk) with 2t'+kk-1 == j of dcol[(w,t')][kk*C+c]
+__global__ __launch_bounds__(256) void col2im_tmajor_s2_kernel(const bf16* __restrict__ dcol, bf16* __restrict__ dh, int W,
+                                                               int Tin, int Tout, int C) {
+    const int vpr = C >> 3;
+    const int64_t total = (int64_t)W * Tin * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t t = i / vpr;
+        const int j = (int)(t % Tin);
+        const int w = (int)(t / Tin);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+            const int num = j + 1 - kk;
+            if (num >= 0 && (num & 1) == 0) {
+                const int to = num >> 1;
+                if (to < Tout) {
+                    const bf16x8 d = *(const bf16x8*)(dcol + ((int64_t)w * Tout + to) * (3 * C) + kk * C + 8 * v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+                }
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+        *(bf16x8*)(dh + ((int64_t)w * Tin + j) * C + 8 * v) = o;
+    }
+}
+
+// conv weight [Co][Ci][3] <-> GEMM operand [Co][3][Ci]   (dir=0: w->wperm, dir=1: wperm(+accumulate) -> w layout)
+__global__ __launch_bounds__(256) void conv_w_permute_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int Co, int Ci,
+                                                             int dir, int accumulate) {
+    const int64_t total = (int64_t)Co * Ci * 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int kk = (int)(i % 3);
+        const int64_t t = i / 3;
+        const int ci = (int)(t % Ci);
+        const int64_t co = t / Ci;
+        const int64_t iw = (co * Ci + ci) * 3 + kk, ip = (co * 3 + kk) * Ci + ci;
+        if (dir == 0) out[ip] = in[iw];
+        else out[iw] = (bf16)(accumulate ? (float)out[iw] + (float)in[ip] : (float)in[ip]);
+    }
+}
+
+// ------------------------------------------------------------------ AvgPool1d(2,2) over time (rows)  (:337,401-402)
+// y[w][t][c] = bf16(0.5*(x[w][2t][c] + x[w][2t+1][c]));  bwd: dx[2t] = dx[2t+1] = bf16(0.5*dy[t])
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t out_rows,
+                                                           int C) {
+    const int vpr = C >> 3;
+    const int64_t total = out_rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const bf16x8 a = *(const bf16x8*)(x + (2 * r) * C + 8 * v), b = *(const bf16x8*)(x + (2 * r + 1) * C + 8 * v);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(0.5f * ((float)a[e] + (float)b[e]));
+        *(bf16x8*)(y + r * C + 8 * v) = o;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int64_t out_rows,
+                                                           int C) {
+    const int vpr = C >> 3;
+    const int64_t total = out_rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const bf16x8 d = *(const bf16x8*)(dy + r * C + 8 * v);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(0.5f * (float)d[e]);
+        *(bf16x8*)(dx + (2 * r) * C + 8 * v) = o;
+        *(bf16x8*)(dx + (2 * r + 1) * C + 8 * v) = o;
+    }
+}
+
+// ------------------------------------------------------------------ embedding gather + <sound> scatter (:532-545)
+// src[i] = rank of position i among placeholders (row-major order) if ids[i]==audio_id else -1; count -> *n_audio.
+// Single block exclusive scan (the id matrix is B*S <= a few 10^4 entries).
+__global__ __launch_bounds__(1024) void placeholder_scan_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t audio_id,
+                                                                int* __restrict__ src, int* __restrict__ n_audio) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const int m = (i < n && ids[i] == audio_id) ? 1 : 0;
+        int incl = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        const int c = carry;
+        if (i < n) src[i] = m ? (c + woff + incl - 1) : -1;
+        __syncthreads();
+        if (tid == 1023) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) *n_audio = carry;
+}
+
+// out[i] = src[i] >= 0 ? audio[src[i]] : embed[ids[i]]
+__global__ __launch_bounds__(256) void embed_scatter_fwd_kernel(const int64_t* __restrict__ ids, const int* __restrict__ src,
+                                                                const bf16* __restrict__ embed, const bf16* __restrict__ audio,
+                                                                bf16* __restrict__ out, int64_t n, int H) {
+    const int vpr = H >> 3;
+    const int64_t total = n * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const int s = src ? src[r] : -1;
+        const bf16* p = (s >= 0) ? audio + (int64_t)s * H : embed + ids[r] * H;
+        *(bf16x8*)(out + r * H + 8 * v) = *(const bf16x8*)(p + 8 * v);
+    }
+}
+
+__device__ __forceinline__ void atomic_add_bf16x2(bf16* addr, float a, float b) {
+    unsigned int* w = (unsigned int*)addr;
+    unsigned int old = *w, assumed;
+    do {
+        assumed = old;
+        bf16x2 cur = *(bf16x2*)&assumed;
+        bf16x2 nv;
+        nv[0] = (bf16)((float)cur[0] + a);
+        nv[1] = (bf16)((float)cur[1] + b);
+        old = atomicCAS(w, assumed, *(unsigned int*)&nv);
+    } while (old != assumed);
+}
+
+// backward: text rows scatter-add into d_embed (token ids may repeat -> CAS adds on bf16 pairs);
+// placeholder rows are gathered into d_audio[src].
+__global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const int64_t* __restrict__ ids, const int* __restrict__ src,
+                                                                const bf16* __restrict__ dout, bf16* __restrict__ d_embed,
+                                                                bf16* __restrict__ d_audio, int64_t n, int H) {
+    const int vpr = H >> 3;
+    const int64_t total = n * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const int s = src ? src[r] : -1;
+        const bf16x8 d = *(const bf16x8*)(dout + r * H + 8 * v);
+        if (s >= 0) {
+            if (d_audio) *(bf16x8*)(d_audio + (int64_t)s * H + 8 * v) = d;
+        } else if (d_embed) {
+            bf16* p = d_embed + ids[r] * H + 8 * v;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) atomic_add_bf16x2(p + e, (float)d[e], (float)d[e + 1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ AdamW (bf16 param + fp32 master/m/v)
+// torch.optim.AdamW semantics: p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  grad_scale multiplies g (DP averaging / loss scaling).
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                    const bf16* __restrict__ g, bf16* __restrict__ p, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float grad_scale) {
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        f32x4 w = *(const f32x4*)(master + 4 * i), mm = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
+        const bf16x4 gg = *(const bf16x4*)(g + 4 * i);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = (float)gg[e] * grad_scale;
+            w[e] *= 1.f - lr * wd;
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            w[e] -= (lr / bc1) * (mm[e] / denom);
+            o[e] = (bf16)w[e];
+        }
+        *(f32x4*)(master + 4 * i) = w;
+        *(f32x4*)(m + 4 * i) = mm;
+        *(f32x4*)(v + 4 * i) = vv;
+        *(bf16x4*)(p + 4 * i) = o;
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        const float gr = (float)g[i] * grad_scale;
+        float w = master[i] * (1.f - lr * wd);
+        const float mm = b1 * m[i] + (1.f - b1) * gr;
+        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+        w -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        master[i] = w;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] = (bf16)w;
+    }
+}
+
+}  // namespace
+
+// ==================================================================== C ABI
+#define ST ((hipStream_t)stream)
+
+extern "C" int afk_transpose_bf16(const void* in, void* out, int R, int C, int Rpad, int64_t ld_in, int64_t ld_out, int nb1,
+                                  int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, void* stream) {
+    AFK_REQUIRE(in && out && R > 0 && C > 0 && Rpad >= R && nb1 > 0 && nb2 > 0, "afk_transpose_bf16: bad args");
+    AFK_REQUIRE(ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
+                    bs1_in % 8 == 0 && bs2_in % 8 == 0 && bs1_out % 8 == 0 && bs2_out % 8 == 0,
+                "afk_transpose_bf16: 16-byte alignment required");
+    AFK_REQUIRE((int64_t)nb1 * nb2 <= 65535, "afk_transpose_bf16: batch too large");
+    dim3 grid((unsigned)afk_cdiv(C, 64), (unsigned)afk_cdiv(Rpad, 64), (unsigned)(nb1 * nb2));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ST, (const bf16*)in, (bf16*)out, R, C, Rpad, ld_in, ld_out, nb2,
+                       bs1_in, bs2_in, bs1_out, bs2_out);
+    AFK_LAUNCH_CHECK("afk_transpose_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+    AFK_REQUIRE(x && y && n % 8 == 0, "afk_gelu_fwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n / 8);
+    AFK_LAUNCH_CHECK("afk_gelu_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, void* stream) {
+    AFK_REQUIRE(dy && pre && dx && n % 8 == 0, "afk_gelu_bwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)dy, (const bf16*)pre,
+                       (bf16*)dx, n / 8);
+    AFK_LAUNCH_CHECK("afk_gelu_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_silu_mul_fwd(const void* gu, void* h, int64_t rows, int I, void* stream) {
+    AFK_REQUIRE(gu && h && I % 8 == 0 && rows > 0, "afk_silu_mul_fwd: bad args");
+    hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid(rows * (I / 8), 256)), dim3(256), 0, ST, (const bf16*)gu, (bf16*)h,
+                       rows, I);
+    AFK_LAUNCH_CHECK("afk_silu_mul_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_silu_mul_bwd(const void* gu, const void* dh, void* dgu, int64_t rows, int I, void* stream) {
+    AFK_REQUIRE(gu && dh && dgu && I % 8 == 0 && rows > 0, "afk_silu_mul_bwd: bad args");
+    hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid(rows * (I / 8), 256)), dim3(256), 0, ST, (const bf16*)gu,
+                       (const bf16*)dh, (bf16*)dgu, rows, I);
+    AFK_LAUNCH_CHECK("afk_silu_mul_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_rope_inplace(void* buf, const void* cos_t, const void* sin_t, const int* pos, int64_t rows, int S, int ld,
+                                int nheads, int D, int backward, void* stream) {
+    AFK_REQUIRE(buf && cos_t && sin_t && rows > 0 && D % 8 == 0 && ld % 4 == 0, "afk_rope_inplace: bad args");
+    hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(rows * nheads * (D / 8), 256)), dim3(256), 0, ST, (bf16*)buf,
+                       (const bf16*)cos_t, (const bf16*)sin_t, pos, rows, S, ld, nheads, D, backward ? -1.f : 1.f);
+    AFK_LAUNCH_CHECK("afk_rope_inplace");
+    return AFK_OK;
+}
+
+extern "C" int afk_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    AFK_REQUIRE(a && b && out && n % 8 == 0, "afk_add_bf16: n must be a multiple of 8");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)a, (const bf16*)b, (bf16*)out,
+                       n / 8);
+    AFK_LAUNCH_CHECK("afk_add_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream) {
+    AFK_REQUIRE(in && out && n > 0, "afk_cast_f32_bf16: bad args");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, ST, in, (bf16*)out, n);
+    AFK_LAUNCH_CHECK("afk_cast_f32_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int accumulate, void* stream) {
+    AFK_REQUIRE(in && out && rows > 0 && C > 0 && ld % 8 == 0, "afk_rowsum_bf16: bad args");
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)afk_cdiv(rows, 4)), dim3(256), 0, ST, (const bf16*)in, ld, C, (bf16*)out,
+                       rows, accumulate);
+    AFK_LAUNCH_CHECK("afk_rowsum_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_im2col_conv1(const void* x, int x_is_f32, void* col, int W, int C, int T, void* stream) {
+    AFK_REQUIRE(x && col && W > 0 && C > 0 && T > 0, "afk_im2col_conv1: bad args");
+    dim3 grid((unsigned)afk_cdiv(T, 62), (unsigned)afk_cdiv(C, 64), (unsigned)W);
+    if (x_is_f32)
+        hipLaunchKernelGGL(im2col_cmajor_kernel<float>, grid, dim3(256), 0, ST, (const float*)x, (bf16*)col, W, C, T);
+    else
+        hipLaunchKernelGGL(im2col_cmajor_kernel<bf16>, grid, dim3(256), 0, ST, (const bf16*)x, (bf16*)col, W, C, T);
+    AFK_LAUNCH_CHECK("afk_im2col_conv1");
+    return AFK_OK;
+}
+
+extern "C" int afk_im2col_conv2(const void* h, void* col, int W, int Tin, int Tout, int C, void* stream) {
+    AFK_REQUIRE(h && col && C % 8 == 0, "afk_im2col_conv2: bad args");
+    hipLaunchKernelGGL(im2col_tmajor_s2_kernel, dim3(ew_grid((int64_t)W * Tout * 3 * (C / 8), 256)), dim3(256), 0, ST,
+                       (const bf16*)h, (bf16*)col, W, Tin, Tout, C);
+    AFK_LAUNCH_CHECK("afk_im2col_conv2");
+    return AFK_OK;
+}
+
+extern "C" int afk_col2im_conv2(const void* dcol, void* dh, int W, int Tin, int Tout, int C, void* stream) {
+    AFK_REQUIRE(dcol && dh && C % 8 == 0, "afk_col2im_conv2: bad args");
+    hipLaunchKernelGGL(col2im_tmajor_s2_kernel, dim3(ew_grid((int64_t)W * Tin * (C / 8), 256)), dim3(256), 0, ST,
+                       (const bf16*)dcol, (bf16*)dh, W, Tin, Tout, C);
+    AFK_LAUNCH_CHECK("afk_col2im_conv2");
+    return AFK_OK;
+}
+
+extern "C" int afk_conv_weight_permute(const void* in, void* out, int Co, int Ci, int dir, int accumulate, void* stream) {
+    AFK_REQUIRE(in && out && Co > 0 && Ci > 0, "afk_conv_weight_permute: bad args");
+    hipLaunchKernelGGL(conv_w_permute_kernel, dim3(ew_grid((int64_t)Co * Ci * 3, 256)), dim3(256), 0, ST, (const bf16*)in,
+                       (bf16*)out, Co, Ci, dir, accumulate);
+    AFK_LAUNCH_CHECK("afk_conv_weight_permute");
+    return AFK_OK;
+}
+
+extern "C" int afk_avgpool2_fwd(const void* x, void* y, int64_t out_rows, int C, void* stream) {
+    AFK_REQUIRE(x && y && C % 8 == 0 && out_rows > 0, "afk_avgpool2_fwd: bad args");
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(ew_grid(out_rows * (C / 8), 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y,
+                       out_rows, C);
+    AFK_LAUNCH_CHECK("afk_avgpool2_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_avgpool2_bwd(const void* dy, void* dx, int64_t out_rows, int C, void* stream) {
+    AFK_REQUIRE(dy && dx && C % 8 == 0 && out_rows > 0, "afk_avgpool2_bwd: bad args");
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(ew_grid(out_rows * (C / 8), 256)), dim3(256), 0, ST, (const bf16*)dy, (bf16*)dx,
+                       out_rows, C);
+    AFK_LAUNCH_CHECK("afk_avgpool2_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_placeholder_scan(const int64_t* ids, int64_t n, int64_t audio_id, int* src, int* n_audio, void* stream) {
+    AFK_REQUIRE(ids && src && n_audio && n > 0, "afk_placeholder_scan: bad args");
+    hipLaunchKernelGGL(placeholder_scan_kernel, dim3(1), dim3(1024), 0, ST, ids, n, audio_id, src, n_audio);
+    AFK_LAUNCH_CHECK("afk_placeholder_scan");
+    return AFK_OK;
+}
+
+extern "C" int afk_embed_scatter_fwd(const int64_t* ids, const int* src, const void* embed, const void* audio, void* out,
+                                     int64_t n, int H, void* stream) {
+    AFK_REQUIRE(ids && embed && out && n > 0 && H % 8 == 0, "afk_embed_scatter_fwd: bad args");
+    AFK_REQUIRE(!src || audio, "afk_embed_scatter_fwd: src without audio rows");
+    hipLaunchKernelGGL(embed_scatter_fwd_kernel, dim3(ew_grid(n * (H / 8), 256)), dim3(256), 0, ST, ids, src,
+                       (const bf16*)embed, (const bf16*)audio, (bf16*)out, n, H);
+    AFK_LAUNCH_CHECK("afk_embed_scatter_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_embed_scatter_bwd(const int64_t* ids, const int* src, const void* dout, void* d_embed, void* d_audio,
+                                     int64_t n, int H, void* stream) {
+    AFK_REQUIRE(ids && dout && n > 0 && H % 8 == 0, "afk_embed_scatter_bwd: bad args");
+    hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(ew_grid(n * (H / 8), 256)), dim3(256), 0, ST, ids, src,
+                       (const bf16*)dout, (bf16*)d_embed, (bf16*)d_audio, n, H);
+    AFK_LAUNCH_CHECK("afk_embed_scatter_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    AFK_REQUIRE(master && m && v && grad && param && n > 0 && step >= 1, "afk_adamw_step: bad args");
+    AFK_REQUIRE(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
+                    ((uintptr_t)grad % 8 == 0) && ((uintptr_t)param % 8 == 0),
+                "afk_adamw_step: misaligned buffer");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(afk_cdiv(n, 4), 256)), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
+                       (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    AFK_LAUNCH_CHECK("afk_adamw_step");
+    return AFK_OK;
+}

@@ -1,0 +1,323 @@
+// bf16 NT GEMM for gfx950:  C[M,N] = epilogue( A[M,K] . B[N,K]^T )   (fp32 accumulate on MFMA)
+//
+// This one kernel carries every dense contraction on the Audio Flamingo 3 training path
+// (oracle call sites: nn.Linear in modeling_audioflamingo3.py:109-115,209-210,427-433,576 and
+// modeling_qwen2.py:40-42,189-192; conv stem :328-329 via im2col).  nn.Linear stores W as [N,K]
+// row-major, so the forward is NT with both operands K-contiguous - exactly the MFMA fragment order.
+// The backward contractions are brought to the same NT form by the host (W^T shadow copies and
+// transposed activations, see ops.py), so one tuned kernel serves fwd, dgrad and wgrad.
+//
+// Structure (v1): 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles,
+// global->LDS by direct LDS-DMA (global_load_lds_dwordx4), two LDS stages (64 KiB => 2 blocks/CU),
+// one barrier per K-step.  LDS rows are 128 B (64 bf16); the 16-B chunk c of row r is stored at
+// chunk position c ^ ((r>>1)&7): the LDS-DMA destination is lane-linear, so the permutation is applied
+// to the per-lane SOURCE address and again on the ds_read_b128 side (guide rule 21).  With the
+// 32x32x16 fragment (lane -> row l&31, chunk 2s+(l>>5)) every ds_read_b128 lane group then covers all
+// 16 slots of the 256-B bank row exactly once.
+// Operands are fed swapped (mfma(Bfrag, Afrag)) so that each lane ends up with 4 consecutive N for one
+// M row: 8-byte bf16 stores, and bias / residual loads of the same shape.
+// Workgroup ids are remapped XCD-contiguously and walk the tile space in 8-row groups so that the
+// 64 tiles resident on one XCD share 8 A panels and 8 B panels through that XCD's L2.
+#include "common.h"
+#include "../../include/afk.h"
+#include <vector>
+#include <mutex>
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROWB = BK * 2;                   // 128 bytes per LDS row
+constexpr int STAGE_BYTES = (BM + BN) * ROWB;  // 32 KiB
+constexpr int NSTAGE = 2;
+
+struct GemmArgs {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    void* C2;  // optional second output: pre-activation (bf16) when AFK_GEMM_GELU is set
+    const bf16* bias;
+    const bf16* R;
+    int64_t lda, ldb, ldc, ldr;
+    int M, N, K;
+    int ntm, ntn;
+    int flags;
+    int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
+    float alpha;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- workgroup -> tile: XCD-contiguous (bijective) then grouped along M
+    int tm, tn;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        constexpr int GM = 8;
+        const int per_group = GM * p.ntn;
+        const int g = swz / per_group, rem = swz - g * per_group;
+        const int first_m = g * GM;
+        const int gsz = min(p.ntm - first_m, GM);
+        tm = first_m + rem % gsz;
+        tn = rem / gsz;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- per-lane LDS-DMA source pointers: unit u covers LDS rows [8u, 8u+8) of the tile, 1 KiB
+    const bf16* a_src[4];
+    const bf16* b_src[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int unit = wave + 4 * u;
+        const int rl = unit * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
+        const int ra = min(m0 + rl, p.M - 1);
+        const int rb = min(n0 + rl, p.N - 1);
+        a_src[u] = p.A + (int64_t)ra * p.lda + chunk * 8;
+        b_src[u] = p.B + (int64_t)rb * p.ldb + chunk * 8;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + BM * ROWB;
+        const int koff = kt * BK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int unit = wave + 4 * u;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(a_src[u] + koff), (lds_void*)(sa + unit * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int unit = wave + 4 * u;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(b_src[u] + koff), (lds_void*)(sb + unit * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes) inside a tile image; swizzle term is lane-constant
+    const int swz_l = (lane >> 1) & 7;
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = ((2 * s + hi) ^ swz_l) << 4;
+        a_off[s] = (wm * 64 + l31) * ROWB + c;
+        b_off[s] = (wn * 64 + l31) * ROWB + c;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nkt = p.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + BM * ROWB;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(sa + a_off[s] + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(sb + b_off[s] + j * 32 * ROWB);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue. lane holds m = ..+l31 and n = ..+8q+4hi+{0..3} for q = 0..3 (regs 4q..4q+3)
+    const int flags = p.flags;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + l31;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (flags & AFK_GEMM_BIAS) {
+                    const bf16x4 bv = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+                }
+                if (flags & AFK_GEMM_GELU) {
+                    // oracle applies GELU to the bf16-rounded Linear output
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+                    if (p.C2) {
+                        bf16x4 pre;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pre[e] = (bf16)v[e];
+                        *(bf16x4*)((bf16*)p.C2 + (int64_t)m * p.ldc + n) = pre;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+                }
+                if (flags & AFK_GEMM_RESIDUAL) {
+                    const int rm = p.res_mod > 0 ? m % p.res_mod : m;
+                    const bf16x4 rv = *(const bf16x4*)(p.R + (int64_t)rm * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + (float)rv[e];
+                }
+                if (flags & AFK_GEMM_OUT_F32) {
+                    float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                    f32x4 o;
+                    if (flags & AFK_GEMM_ACCUM) {
+                        o = *(const f32x4*)cp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += v[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = v[e];
+                    }
+                    *(f32x4*)cp = o;
+                } else {
+                    bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
+                    if (flags & AFK_GEMM_ACCUM) {
+                        const bf16x4 old = *(const bf16x4*)cp;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                    *(bf16x4*)cp = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ profiling (HIP events per launch)
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<hipEvent_t> pool;  // pairs
+    size_t used = 0;
+    double flops = 0.0;
+    int64_t launches = 0;
+};
+ProfState g_prof;
+
+hipEvent_t prof_next_event() {
+    if (g_prof.used == g_prof.pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_prof.pool.push_back(e);
+    }
+    return g_prof.pool[g_prof.used++];
+}
+
+}  // namespace
+
+extern "C" int afk_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on = on != 0;
+    return AFK_OK;
+}
+
+extern "C" int afk_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.used = 0;
+    g_prof.flops = 0.0;
+    g_prof.launches = 0;
+    return AFK_OK;
+}
+
+extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        if (hipEventSynchronize(g_prof.pool[i + 1]) != hipSuccess)
+            return afk_set_error(AFK_ERR_LAUNCH, "afk_prof_collect: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.pool[i], g_prof.pool[i + 1]) != hipSuccess)
+            return afk_set_error(AFK_ERR_LAUNCH, "afk_prof_collect: elapsed failed");
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = g_prof.flops;
+    if (launches) *launches = g_prof.launches;
+    return AFK_OK;
+}
+
+extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                                int res_mod, void* preact_out, float alpha, int flags, void* stream) {
+    AFK_REQUIRE(A && B && C, "afk_gemm_nt_bf16: null operand");
+    AFK_REQUIRE(M > 0 && N > 0 && K > 0, "afk_gemm_nt_bf16: bad shape %d %d %d", M, N, K);
+    AFK_REQUIRE(K % BK == 0, "afk_gemm_nt_bf16: K=%d must be a multiple of %d (pad the operand)", K, BK);
+    AFK_REQUIRE(N % 4 == 0, "afk_gemm_nt_bf16: N=%d must be a multiple of 4", N);
+    AFK_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "afk_gemm_nt_bf16: leading dims must keep 16-B (A,B) / 8-B (C) alignment");
+    AFK_REQUIRE(!(flags & AFK_GEMM_BIAS) || bias, "afk_gemm_nt_bf16: BIAS flag without bias");
+    AFK_REQUIRE(!(flags & AFK_GEMM_RESIDUAL) || (residual && ldr % 4 == 0), "afk_gemm_nt_bf16: RESIDUAL flag without residual");
+    AFK_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0), "afk_gemm_nt_bf16: misaligned pointer");
+    GemmArgs p;
+    p.A = (const bf16*)A;
+    p.B = (const bf16*)B;
+    p.C = C;
+    p.C2 = preact_out;
+    p.bias = (const bf16*)bias;
+    p.R = (const bf16*)residual;
+    p.lda = lda;
+    p.ldb = ldb;
+    p.ldc = ldc;
+    p.ldr = ldr;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.ntm = (int)afk_cdiv(M, BM);
+    p.ntn = (int)afk_cdiv(N, BN);
+    p.flags = flags;
+    p.res_mod = res_mod;
+    p.alpha = alpha;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_nt_bf16_k128, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nwg = (int64_t)p.ntm * p.ntn;
+    AFK_REQUIRE(nwg < (1ll << 31), "afk_gemm_nt_bf16: grid too large");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        prof = g_prof.on;
+        if (prof) {
+            e0 = prof_next_event();
+            e1 = prof_next_event();
+            g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
+            g_prof.launches += 1;
+        }
+    }
+    if (prof) hipEventRecord(e0, st);
+    hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg), dim3(256), NSTAGE * STAGE_BYTES, st, p);
+    if (prof) hipEventRecord(e1, st);
+    AFK_LAUNCH_CHECK("afk_gemm_nt_bf16");
+    return AFK_OK;
+}

@@ -1,0 +1,285 @@
+// LayerNorm / RMSNorm forward + backward for gfx950 (HBM-bound row kernels).
+//
+// One 64-lane wave owns one row; the row lives in registers as VPL bf16x4 vectors per lane (8-byte
+// coalesced loads, 512 B per wave-instruction), statistics in fp32 with wave shuffles only - no LDS, no
+// barriers - 4 rows per 256-thread block, grid-stride over rows.  Algorithmic traffic: read x + write y
+// (fwd), read x,dy + write dx (bwd) - SURVEY.md §8(d).
+//
+// Oracle semantics reproduced exactly:
+//   LayerNorm  (nn.LayerNorm, modeling_audioflamingo3.py:207,212,335; eps 1e-5): fp32 statistics,
+//              y = bf16((x-mean)*rstd*w + b).
+//   RMSNorm    (Qwen2RMSNorm.forward, modeling_qwen2.py:247-252; eps 1e-6): x32 = float(x);
+//              xh = bf16(x32 * rsqrt(mean(x32^2)+eps));  y = bf16(w * xh)   (cast BEFORE the weight multiply).
+// Weight/bias gradients are reduced in two stages: each block keeps fp32 partial column sums for the rows it
+// visited and writes one partial row to a workspace [nblocks, 2, D]; afk_colsum_partials folds them.
+#include "common.h"
+#include "../../include/afk.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;
+
+template <int VPL, bool RMS>
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                       const bf16* __restrict__ b, bf16* __restrict__ y,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nvec = D >> 2;
+    const float invD = 1.f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+        const bf16* xr = x + row * D;
+        float v[VPL][4];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
+                const bf16x4 t = *(const bf16x4*)(xr + 4 * vi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[i][e] = (float)t[e];
+                    s += v[i][e];
+                    ss += v[i][e] * v[i][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+            }
+        }
+        float mean = 0.f, rstd;
+        if (RMS) {
+            ss = wave_sum(ss);
+            rstd = rsqrtf(ss * invD + eps);
+        } else {
+            s = wave_sum(s);
+            mean = s * invD;
+            // two-pass variance on the register copy (matches ATen's numerically careful path)
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) {
+                const int vi = lane + 64 * i;
+                if (vi < nvec) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[i][e] - mean;
+                        q += d * d;
+                    }
+                }
+            }
+            q = wave_sum(q);
+            rstd = rsqrtf(q * invD + eps);
+        }
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            rstd_out[row] = rstd;
+        }
+        bf16* yr = y + row * D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
+                const bf16x4 wv4 = *(const bf16x4*)(w + 4 * vi);
+                bf16x4 o;
+                if (RMS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((float)wv4[e] * rbf(v[i][e] * rstd));
+                } else {
+                    const bf16x4 bv4 = *(const bf16x4*)(b + 4 * vi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd * (float)wv4[e] + (float)bv4[e]);
+                }
+                *(bf16x4*)(yr + 4 * vi) = o;
+            }
+        }
+    }
+}
+
+// backward.  dx for one row; per-block fp32 partial sums of dw (and db) over the rows this block visits.
+//   LN : xh=(x-mean)*rstd; g=dy*w;  dx = rstd*(g - mean(g) - xh*mean(g*xh));  dw+=dy*xh; db+=dy
+//   RMS: xh=x*rstd;        g=dy*w;  dx = rstd*(g - xh*mean(g*xh));            dw+=dy*bf16(xh)
+template <int VPL, bool RMS>
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                       const bf16* __restrict__ dy, const float* __restrict__ mean_in,
+                                                       const float* __restrict__ rstd_in, bf16* __restrict__ dx,
+                                                       const bf16* __restrict__ dx_add, float* __restrict__ partials,
+                                                       int64_t rows, int D) {
+    __shared__ float red[2][VPL * 256];  // cross-wave fold of the column partials (LDS atomics)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nvec = D >> 2;
+    const float invD = 1.f / (float)D;
+    float pw[VPL][4], pb[VPL][4];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pw[i][e] = pb[i][e] = 0.f;
+    for (int c = threadIdx.x; c < VPL * 256; c += 256) red[0][c] = red[1][c] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+        const bf16* xr = x + row * D;
+        const bf16* dyr = dy + row * D;
+        const float mean = RMS ? 0.f : mean_in[row];
+        const float rstd = rstd_in[row];
+        float xh[VPL][4], g[VPL][4];
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
+                const bf16x4 xt = *(const bf16x4*)(xr + 4 * vi);
+                const bf16x4 dt = *(const bf16x4*)(dyr + 4 * vi);
+                const bf16x4 wt = *(const bf16x4*)(w + 4 * vi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = (float)dt[e];
+                    xh[i][e] = ((float)xt[e] - mean) * rstd;
+                    g[i][e] = d * (float)wt[e];
+                    sg += g[i][e];
+                    sgx += g[i][e] * xh[i][e];
+                    pw[i][e] += d * (RMS ? rbf(xh[i][e]) : xh[i][e]);
+                    if (!RMS) pb[i][e] += d;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xh[i][e] = g[i][e] = 0.f;
+            }
+        }
+        sgx = wave_sum(sgx) * invD;
+        sg = RMS ? 0.f : wave_sum(sg) * invD;
+        bf16* dxr = dx + row * D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
+                bf16x4 o;
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = rstd * (g[i][e] - sg - xh[i][e] * sgx);
+                if (dx_add) {  // fused residual-gradient merge: dx = bf16(norm-branch) + skip-branch
+                    const bf16x4 a = *(const bf16x4*)(dx_add + row * D + 4 * vi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = rbf(r[e]) + (float)a[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)r[e];
+                *(bf16x4*)(dxr + 4 * vi) = o;
+            }
+        }
+    }
+    // fold the 4 waves' partials (LDS float atomics) and write this block's partial row:
+    // partials[block][0][D] = dw, [1][D] = db
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&red[0][(lane + 64 * i) * 4 + e], pw[i][e]);
+            if (!RMS) atomicAdd(&red[1][(lane + 64 * i) * 4 + e], pb[i][e]);
+        }
+    __syncthreads();
+    float* outp = partials + (int64_t)blockIdx.x * 2 * D;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        outp[c] = red[0][c];
+        outp[D + c] = red[1][c];
+    }
+}
+
+// out[c] (+)= sum_p partials[p][which][c]   -> bf16 grads
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, int nparts, int D,
+                                                            int stride, int offset, bf16* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= D) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partials[(int64_t)p * stride + offset + c];
+    if (accumulate) s += (float)out[c];
+    out[c] = (bf16)s;
+}
+
+int norm_grid(int64_t rows) {
+    int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+template <bool RMS>
+int launch_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows, int D,
+               float eps, hipStream_t st) {
+    const int g = norm_grid(rows);
+#define AFK_NF(V)                                                                                                    \
+    hipLaunchKernelGGL((norm_fwd_kernel<V, RMS>), dim3(g), dim3(256), 0, st, (const bf16*)x, (const bf16*)w,       \
+                       (const bf16*)b, (bf16*)y, mean, rstd, rows, D, eps)
+    if (D <= 512) AFK_NF(2);
+    else if (D <= 1280) AFK_NF(5);
+    else if (D <= 3584) AFK_NF(14);
+    else AFK_NF(32);
+#undef AFK_NF
+    return AFK_OK;
+}
+
+template <bool RMS>
+int launch_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
+               const void* dx_add, float* partials, int nblocks, int64_t rows, int D, hipStream_t st) {
+#define AFK_NB(V)                                                                                                    \
+    hipLaunchKernelGGL((norm_bwd_kernel<V, RMS>), dim3(nblocks), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, \
+                       (const bf16*)dy, mean, rstd, (bf16*)dx, (const bf16*)dx_add, partials, rows, D)
+    if (D <= 512) AFK_NB(2);
+    else if (D <= 1280) AFK_NB(5);
+    else AFK_NB(14);
+#undef AFK_NB
+    return AFK_OK;
+}
+
+}  // namespace
+
+extern "C" int afk_norm_bwd_blocks(int64_t rows) {
+    int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
+    if (g > 512) g = 512;
+    return (int)g;
+}
+
+extern "C" int afk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                                 int64_t rows, int D, float eps, void* stream) {
+    AFK_REQUIRE(x && w && b && y && mean && rstd, "afk_layernorm_fwd: null pointer");
+    AFK_REQUIRE(D % 4 == 0 && D <= 8192 && rows > 0, "afk_layernorm_fwd: unsupported D=%d", D);
+    launch_fwd<false>(x, w, b, y, mean, rstd, rows, D, eps, (hipStream_t)stream);
+    AFK_LAUNCH_CHECK("afk_layernorm_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int D, float eps,
+                               void* stream) {
+    AFK_REQUIRE(x && w && y && rstd, "afk_rmsnorm_fwd: null pointer");
+    AFK_REQUIRE(D % 4 == 0 && D <= 8192 && rows > 0, "afk_rmsnorm_fwd: unsupported D=%d", D);
+    launch_fwd<true>(x, w, nullptr, y, nullptr, rstd, rows, D, eps, (hipStream_t)stream);
+    AFK_LAUNCH_CHECK("afk_rmsnorm_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_layernorm_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd,
+                                 void* dx, const void* dx_add, void* dw, void* db, int accumulate, float* workspace,
+                                 int64_t rows, int D, void* stream) {
+    AFK_REQUIRE(x && w && dy && mean && rstd && dx && dw && db && workspace, "afk_layernorm_bwd: null pointer");
+    AFK_REQUIRE(D % 4 == 0 && D <= 3584 && rows > 0, "afk_layernorm_bwd: unsupported D=%d", D);
+    const int nb = afk_norm_bwd_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    launch_bwd<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
+                       (bf16*)dw, accumulate);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, D,
+                       (bf16*)db, accumulate);
+    AFK_LAUNCH_CHECK("afk_layernorm_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx,
+                               const void* dx_add, void* dw, int accumulate, float* workspace, int64_t rows, int D,
+                               void* stream) {
+    AFK_REQUIRE(x && w && dy && rstd && dx && dw && workspace, "afk_rmsnorm_bwd: null pointer");
+    AFK_REQUIRE(D % 4 == 0 && D <= 3584 && rows > 0, "afk_rmsnorm_bwd: unsupported D=%d", D);
+    const int nb = afk_norm_bwd_blocks(rows);
+    hipStream_t st = (hipStream_t)stream;
+    launch_bwd<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
+                       (bf16*)dw, accumulate);
+    AFK_LAUNCH_CHECK("afk_rmsnorm_bwd");
+    return AFK_OK;
+}

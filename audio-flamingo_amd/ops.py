@@ -1,0 +1,353 @@
+"""Tensor-level wrappers over the C ABI (include/afk.h).
+
+PyTorch is used only as plumbing here: device memory (caching allocator), the current HIP stream, tensor
+metadata.  Every function enqueues hand-written gfx950 kernels on ``torch.cuda.current_stream()``.
+No function has a CPU / eager fallback: inputs must live on a HIP device (AfkError otherwise).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import AfkError
+
+BF16 = torch.bfloat16
+
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ACCUM = 1, 2, 4, 8, 16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise AfkError(f"{name}: expected a HIP device tensor, got {t.device} (no CPU fallback in this package)")
+    if dtype is not None and t.dtype != dtype:
+        raise AfkError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None, out_f32=False,
+            accumulate=False, alpha=1.0, M=None, N=None, K=None):
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b: 2-D bf16 with unit inner stride (row stride free)."""
+    _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    assert K <= a.shape[1] and K <= b.shape[1]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= N
+    flags = 0
+    if bias is not None:
+        flags |= GEMM_BIAS
+        _chk(bias, BF16, "gemm bias")
+    if gelu:
+        flags |= GEMM_GELU
+    if residual is not None:
+        flags |= GEMM_RESIDUAL
+        _chk(residual, BF16, "gemm residual")
+        assert residual.stride(-1) == 1
+    if out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    if accumulate:
+        flags |= GEMM_ACCUM
+    if preact_out is not None:
+        assert preact_out.stride(0) == out.stride(0) and preact_out.dtype == BF16
+    _lib.call("afk_gemm_nt_bf16", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+              M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
+              _p(preact_out), float(alpha), flags, _stream())
+    return out
+
+
+def transpose(x, out=None, *, rpad=None):
+    """x [R, C] (row stride free) -> out [C, Rpad] with zero-filled tail columns."""
+    _chk(x, BF16, "transpose x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    R, C = x.shape
+    rpad = pad64(R) if rpad is None else rpad
+    if out is None:
+        out = torch.empty((C, rpad), device=x.device, dtype=BF16)
+    _lib.call("afk_transpose_bf16", x.data_ptr(), out.data_ptr(), R, C, rpad, x.stride(0), out.stride(0), 1, 1, 0, 0, 0, 0,
+              _stream())
+    return out
+
+
+def transpose_heads(x, B, S, H, D, ld, spad, out=None):
+    """x addressed [b][s][h][d] = base + (b*S+s)*ld + h*D + d  ->  out [B, H, D, spad] (zero padded)."""
+    _chk(x, BF16, "transpose_heads x")
+    if out is None:
+        out = torch.empty((B, H, D, spad), device=x.device, dtype=BF16)
+    _lib.call("afk_transpose_bf16", x.data_ptr(), out.data_ptr(), S, D, spad, ld, spad, B, H, S * ld, D, H * D * spad,
+              D * spad, _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def layernorm_fwd(x, w, b, eps=1e-5):
+    _chk(x, BF16, "layernorm x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.call("afk_layernorm_fwd", x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              rows, D, float(eps), _stream())
+    return y, mean, rstd
+
+
+def _norm_ws(rows, D, device):
+    nb = _lib.load().afk_norm_bwd_blocks(rows)
+    return torch.empty(nb * 2 * D, device=device, dtype=torch.float32)
+
+
+def layernorm_bwd(x, w, dy, mean, rstd, dw, db, *, dx_add=None, accumulate=False):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    ws = _norm_ws(rows, D, x.device)
+    _lib.call("afk_layernorm_bwd", x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+              _p(dx_add), dw.data_ptr(), db.data_ptr(), int(accumulate), ws.data_ptr(), rows, D, _stream())
+    return dx
+
+
+def rmsnorm_fwd(x, w, eps=1e-6):
+    _chk(x, BF16, "rmsnorm x")
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _lib.call("afk_rmsnorm_fwd", x.data_ptr(), w.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, D, float(eps), _stream())
+    return y, rstd
+
+
+def rmsnorm_bwd(x, w, dy, rstd, dw, *, dx_add=None, accumulate=False):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty_like(x)
+    ws = _norm_ws(rows, D, x.device)
+    _lib.call("afk_rmsnorm_bwd", x.data_ptr(), w.data_ptr(), dy.data_ptr(), rstd.data_ptr(), dx.data_ptr(), _p(dx_add),
+              dw.data_ptr(), int(accumulate), ws.data_ptr(), rows, D, _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+def gelu_fwd(x):
+    y = torch.empty_like(_chk(x, BF16))
+    _lib.call("afk_gelu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+    return y
+
+
+def gelu_bwd(dy, pre):
+    dx = torch.empty_like(_chk(dy, BF16))
+    _lib.call("afk_gelu_bwd", dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), dy.numel(), _stream())
+    return dx
+
+
+def silu_mul_fwd(gu):
+    rows, I2 = _chk(gu, BF16).shape
+    h = torch.empty((rows, I2 // 2), device=gu.device, dtype=BF16)
+    _lib.call("afk_silu_mul_fwd", gu.data_ptr(), h.data_ptr(), rows, I2 // 2, _stream())
+    return h
+
+
+def silu_mul_bwd(gu, dh):
+    rows, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    _lib.call("afk_silu_mul_bwd", gu.data_ptr(), dh.data_ptr(), dgu.data_ptr(), rows, I2 // 2, _stream())
+    return dgu
+
+
+def rope_(buf, cos, sin, *, S, nheads, D, pos=None, backward=False):
+    """in-place rotate-half RoPE on the first nheads*D columns of buf [rows, ld]."""
+    _chk(buf, BF16, "rope buf")
+    rows, ld = buf.shape[0], buf.stride(0)
+    _lib.call("afk_rope_inplace", buf.data_ptr(), cos.data_ptr(), sin.data_ptr(), _p(pos), rows, S, ld, nheads, D,
+              int(backward), _stream())
+    return buf
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _lib.call("afk_add_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+def cast_f32_bf16(x):
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _lib.call("afk_cast_f32_bf16", _chk(x, torch.float32).data_ptr(), out.data_ptr(), x.numel(), _stream())
+    return out
+
+
+def rowsum(xt, C, out, *, accumulate=False):
+    """out[r] (+)= sum_{c<C} xt[r][c]"""
+    _lib.call("afk_rowsum_bf16", xt.data_ptr(), xt.stride(0), C, out.data_ptr(), xt.shape[0], int(accumulate), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- conv stem helpers
+def im2col_conv1(x):
+    """x [W, C, T] (f32 or bf16, channel-major) -> col [W*T, 3*C] bf16"""
+    W, C, T = x.shape
+    assert x.is_contiguous() and x.is_cuda
+    col = torch.empty((W * T, 3 * C), device=x.device, dtype=BF16)
+    _lib.call("afk_im2col_conv1", x.data_ptr(), int(x.dtype == torch.float32), col.data_ptr(), W, C, T, _stream())
+    return col
+
+
+def im2col_conv2(h, W, Tin, C):
+    Tout = (Tin - 1) // 2 + 1
+    col = torch.empty((W * Tout, 3 * C), device=h.device, dtype=BF16)
+    _lib.call("afk_im2col_conv2", h.data_ptr(), col.data_ptr(), W, Tin, Tout, C, _stream())
+    return col
+
+
+def col2im_conv2(dcol, W, Tin, C):
+    Tout = (Tin - 1) // 2 + 1
+    dh = torch.empty((W * Tin, C), device=dcol.device, dtype=BF16)
+    _lib.call("afk_col2im_conv2", dcol.data_ptr(), dh.data_ptr(), W, Tin, Tout, C, _stream())
+    return dh
+
+
+def conv_weight_to_gemm(w, out=None):
+    """[Co, Ci, 3] -> [Co, 3*Ci] (tap-major)"""
+    Co, Ci, _ = w.shape
+    out = torch.empty((Co, 3 * Ci), device=w.device, dtype=BF16) if out is None else out
+    _lib.call("afk_conv_weight_permute", w.data_ptr(), out.data_ptr(), Co, Ci, 0, 0, _stream())
+    return out
+
+
+def conv_weight_grad_from_gemm(dwp, dw, *, accumulate=False):
+    Co, Ci, _ = dw.shape
+    _lib.call("afk_conv_weight_permute", dwp.data_ptr(), dw.data_ptr(), Co, Ci, 1, int(accumulate), _stream())
+    return dw
+
+
+def avgpool2_fwd(x, out_rows, C):
+    y = torch.empty((out_rows, C), device=x.device, dtype=BF16)
+    _lib.call("afk_avgpool2_fwd", x.data_ptr(), y.data_ptr(), out_rows, C, _stream())
+    return y
+
+
+def avgpool2_bwd(dy, out_rows, C):
+    dx = torch.empty((out_rows * 2, C), device=dy.device, dtype=BF16)
+    _lib.call("afk_avgpool2_bwd", dy.data_ptr(), dx.data_ptr(), out_rows, C, _stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------- embedding
+def placeholder_scan(ids, audio_id):
+    ids = _chk(ids.contiguous(), torch.int64, "input_ids")
+    n = ids.numel()
+    src = torch.empty(n, device=ids.device, dtype=torch.int32)
+    cnt = torch.empty(1, device=ids.device, dtype=torch.int32)
+    _lib.call("afk_placeholder_scan", ids.data_ptr(), n, int(audio_id), src.data_ptr(), cnt.data_ptr(), _stream())
+    return src, cnt
+
+
+def embed_scatter_fwd(ids, src, embed, audio):
+    n, H = ids.numel(), embed.shape[1]
+    out = torch.empty((n, H), device=embed.device, dtype=BF16)
+    _lib.call("afk_embed_scatter_fwd", ids.data_ptr(), _p(src), embed.data_ptr(), _p(audio), out.data_ptr(), n, H, _stream())
+    return out
+
+
+def embed_scatter_bwd(ids, src, dout, d_embed, d_audio):
+    n, H = ids.numel(), dout.shape[-1]
+    _lib.call("afk_embed_scatter_bwd", ids.data_ptr(), _p(src), dout.data_ptr(), _p(d_embed), _p(d_audio), n, H, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
+    """qkv [B*S, (Hq+2Hkv)*D] fused projection output (q | k | v).  -> o [B*S, Hq*D], lse [B,Hq,S]"""
+    _chk(qkv, BF16, "qkv")
+    ld = qkv.stride(0)
+    spad = pad64(S)
+    q = qkv
+    k = qkv[:, Hq * D:]
+    v = qkv[:, (Hq + Hkv) * D:]
+    vt = transpose_heads(v, B, S, Hkv, D, ld, spad)
+    o = torch.empty((B * S, Hq * D), device=qkv.device, dtype=BF16)
+    lse = torch.empty((B, Hq, S), device=qkv.device, dtype=torch.float32)
+    _lib.call("afk_attn_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, vt.data_ptr(), o.data_ptr(),
+              S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+    return o, lse
+
+
+def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
+    """-> dqkv [B*S, (Hq+2Hkv)*D]"""
+    ld = qkv.stride(0)
+    spad = pad64(S)
+    q = qkv
+    k = qkv[:, Hq * D:]
+    v = qkv[:, (Hq + Hkv) * D:]
+    dev = qkv.device
+    delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)
+    ldo = Hq * D
+    _lib.call("afk_attn_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, D,
+              _stream())
+    qt = transpose_heads(q, B, S, Hq, D, ld, spad)
+    kt = transpose_heads(k, B, S, Hkv, D, ld, spad)
+    dot = transpose_heads(do, B, S, Hq, D, ldo, spad)
+    dqkv = torch.empty_like(qkv)
+    ldd = dqkv.stride(0)
+    dq = dqkv
+    dk = dqkv[:, Hq * D:]
+    dv = dqkv[:, (Hq + Hkv) * D:]
+    _lib.call("afk_attn_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+              do.data_ptr(), S * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+              dq.data_ptr(), S * ldd, D, ldd, dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len),
+              B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------- loss
+def count_valid(labels):
+    out = torch.empty(1, device=labels.device, dtype=torch.float32)
+    _lib.call("afk_count_valid", labels.data_ptr(), labels.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def ce_fwd_bwd_(logits, shift_labels, row_loss, denom, *, upstream=1.0, write_grad=True):
+    rows, V = logits.shape
+    _lib.call("afk_ce_fwd_bwd", logits.data_ptr(), logits.stride(0), rows, V, shift_labels.data_ptr(), row_loss.data_ptr(),
+              denom.data_ptr(), float(upstream), int(write_grad), _stream())
+
+
+def loss_reduce(row_loss, denom, loss, *, accumulate=False):
+    _lib.call("afk_loss_reduce", row_loss.data_ptr(), row_loss.numel(), denom.data_ptr(), loss.data_ptr(), int(accumulate),
+              _stream())
+    return loss
+
+
+# ---------------------------------------------------------------------------------------------- optimizer
+def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _lib.call("afk_adamw_step", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), param.numel(),
+              float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- profiling
+def prof_enable(on: bool):
+    _lib.call("afk_prof_enable", int(on))
+
+
+def prof_reset():
+    _lib.call("afk_prof_reset")
+
+
+def prof_collect():
+    import ctypes
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+    _lib.call("afk_prof_collect", ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n))
+    return ms.value, fl.value, n.value

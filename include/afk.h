@@ -1,0 +1,138 @@
+/* afk — Audio Flamingo kernels for MI355X (gfx950).  C ABI of libafk.so.
+ *
+ * This is the drop-in boundary of the repo.  The reference has no FFI of its own: the
+ * hot path it runs is PyTorch ATen ops called from the modules of
+ *   TF = transformers 5.15 (models/audioflamingo3/modeling_audioflamingo3.py, models/qwen2/modeling_qwen2.py,
+ *        models/whisper/feature_extraction_whisper.py, loss/loss_utils.py)
+ * so every entry point below names the oracle expression (file:line) it replaces.  A host binds these with
+ * ctypes / cffi / pybind; audio_flamingo_amd/_lib.py is the ctypes binding used here.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named host_*.
+ *   - bf16 tensors are row-major, "ld*" are leading dimensions in ELEMENTS.
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no host sync, no
+ *     allocation).  Calls are re-entrant and may be issued from any thread (autograd's backward thread too).
+ *   - return 0 on success, negative on error; afk_last_error() returns the message for the calling thread.
+ */
+#ifndef AFK_H
+#define AFK_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int afk_version(void);
+const char* afk_last_error(void);
+
+/* ---- profiling: HIP events around every afk_gemm_nt_bf16 launch (bench.py roofline leg) ------------- */
+int afk_prof_enable(int on);
+int afk_prof_reset(void);
+int afk_prof_collect(double* host_total_ms, double* host_total_flops, int64_t* host_launches);
+
+/* ---- dense contraction ------------------------------------------------------------------------------
+ * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T)  bf16 in, fp32 MFMA accumulate, bf16 (or f32) out.
+ * Replaces F.linear at modeling_audioflamingo3.py:109-115 (q/k/v/out_proj), :209-210 (fc1/fc2),
+ * :427-433 (projector), :576 (lm_head); modeling_qwen2.py:40-42 (gate/up/down), :189-192 (q/k/v/o);
+ * and nn.Conv1d :328-329 after im2col.  Backward dgrad/wgrad use the same entry with transposed operands.
+ * K must be a multiple of 64 and N of 4; M and N edges are handled in-kernel.
+ * residual row index is m, or m % res_mod when res_mod > 0 (broadcast table: embed_positions add, :385).
+ * epilogue order: +bias[n] -> (round bf16, write preact_out, GELU-erf) -> (round bf16, +residual[m,n]) -> (+C if ACCUM)
+ */
+#define AFK_GEMM_BIAS 1
+#define AFK_GEMM_GELU 2
+#define AFK_GEMM_RESIDUAL 4
+#define AFK_GEMM_OUT_F32 8
+#define AFK_GEMM_ACCUM 16
+int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                     int res_mod, void* preact_out, float alpha, int flags, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------------
+ * LayerNorm: nn.LayerNorm(eps=1e-5) at modeling_audioflamingo3.py:207,212 (per layer) and :335,403 (final).
+ * RMSNorm:   Qwen2RMSNorm.forward, modeling_qwen2.py:247-252 (eps 1e-6, cast to bf16 BEFORE the weight multiply).
+ * bwd: dx = norm-branch grad (+ dx_add if non-null: fused residual-gradient merge); dw/db (bf16) are
+ * overwritten or accumulated; workspace = afk_norm_bwd_blocks(rows) * 2 * D floats. */
+int afk_norm_bwd_blocks(int64_t rows);
+int afk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
+                      int64_t rows, int D, float eps, void* stream);
+int afk_layernorm_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd,
+                      void* dx, const void* dx_add, void* dw, void* db, int accumulate, float* workspace,
+                      int64_t rows, int D, void* stream);
+int afk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int D, float eps, void* stream);
+int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, const void* dx_add,
+                    void* dw, int accumulate, float* workspace, int64_t rows, int D, void* stream);
+
+/* ---- layout + elementwise glue ------------------------------------------------------------------------
+ * transpose: out[b1][b2][c][r] = in[b1][b2][r][c]; columns R..Rpad-1 of out are zero (K padding for wgrad GEMMs,
+ *            and the [B,H,D,Spad] operand copies of the attention kernels). */
+int afk_transpose_bf16(const void* in, void* out, int R, int C, int Rpad, int64_t ld_in, int64_t ld_out, int nb1,
+                       int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, void* stream);
+/* exact-erf GELU (transformers/activations.py:70-89) */
+int afk_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int afk_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, void* stream);
+/* SwiGLU: Qwen2MLP.forward modeling_qwen2.py:46-48; gu = [rows, 2I] (gate | up) */
+int afk_silu_mul_fwd(const void* gu, void* h, int64_t rows, int I, void* stream);
+int afk_silu_mul_bwd(const void* gu, const void* dh, void* dgu, int64_t rows, int I, void* stream);
+/* rotate-half RoPE in place on the first nheads*D columns of buf[rows, ld]: apply_rotary_pos_emb modeling_qwen2.py:112-135 */
+int afk_rope_inplace(void* buf, const void* cos_t, const void* sin_t, const int* pos, int64_t rows, int S, int ld,
+                     int nheads, int D, int backward, void* stream);
+int afk_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int afk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+/* out[r] (+)= sum_c in[r][c] : bias gradient from the transposed output-gradient */
+int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int accumulate, void* stream);
+
+/* ---- conv stem as GEMM (modeling_audioflamingo3.py:328-329,380-382) ------------------------------------ */
+int afk_im2col_conv1(const void* x, int x_is_f32, void* col, int W, int C, int T, void* stream);
+int afk_im2col_conv2(const void* h, void* col, int W, int Tin, int Tout, int C, void* stream);
+int afk_col2im_conv2(const void* dcol, void* dh, int W, int Tin, int Tout, int C, void* stream);
+int afk_conv_weight_permute(const void* in, void* out, int Co, int Ci, int dir, int accumulate, void* stream);
+/* AvgPool1d(2,2) over time, :337,401-402 */
+int afk_avgpool2_fwd(const void* x, void* y, int64_t out_rows, int C, void* stream);
+int afk_avgpool2_bwd(const void* dy, void* dx, int64_t out_rows, int C, void* stream);
+
+/* ---- embedding gather + <sound> placeholder scatter (:490-512, :532-545) ------------------------------- */
+int afk_placeholder_scan(const int64_t* ids, int64_t n, int64_t audio_id, int* src, int* n_audio, void* stream);
+int afk_embed_scatter_fwd(const int64_t* ids, const int* src, const void* embed, const void* audio, void* out,
+                          int64_t n, int H, void* stream);
+int afk_embed_scatter_bwd(const int64_t* ids, const int* src, const void* dout, void* d_embed, void* d_audio,
+                          int64_t n, int H, void* stream);
+
+/* ---- attention (encoder :117-189 bidirectional 20x64; decoder modeling_qwen2.py:195-234 causal GQA 28:4x128) --
+ * tensors are addressed base + b*bs + h*hs + s*rs + d (element strides) so q/k/v can live inside the fused
+ * projection output; Vt/Kt/Qt/dOt are [B, H, D, Spad] transposed copies (afk_transpose_bf16, zero padded).
+ * LSE/delta are [B, Hq, S] fp32.  kv_len[b] (or NULL) = number of valid keys (encoder key padding). */
+int afk_attn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                 int64_t k_rs, const void* Vt, void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, float* LSE,
+                 const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale, int causal, void* stream);
+int afk_attn_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, const void* dO, int64_t do_bs,
+                   int64_t do_hs, int64_t do_rs, float* delta, int B, int H, int S, int D, void* stream);
+int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                 int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO,
+                 int64_t do_bs, int64_t do_hs, int64_t do_rs, const void* Qt, const void* Kt, const void* dOt,
+                 const float* LSE, const float* delta, void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs,
+                 void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV, int64_t dv_bs, int64_t dv_hs,
+                 int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale,
+                 int causal, void* stream);
+
+/* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
+ * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;
+ * denom = device scalar (number of valid labels, or num_items_in_batch). */
+int afk_ce_fwd_bwd(void* logits, int64_t ld, int64_t rows, int V, const int64_t* shift_labels, float* row_loss,
+                   const float* denom, float upstream, int write_grad, void* stream);
+int afk_count_valid(const int64_t* labels, int64_t n, float* out, void* stream);
+int afk_loss_reduce(const float* row_loss, int64_t n, const float* denom, float* loss, int accumulate, void* stream);
+
+/* ---- log-mel frontend: WhisperFeatureExtractor._torch_extract_fbank_features, feature_extraction_whisper.py:135-168
+ * wav [W, nsamp] fp32 -> out [W, nmel, nsamp/160] (fp32 or bf16).  cosb/sinb = hann-folded DFT basis
+ * [400, nbins_pad]; melT = [201, nmel]; raw_ws = W*nmel*T floats, wmax_ws = W ints. */
+int afk_logmel(const float* wav, int W, int64_t nsamp, const float* cosb, const float* sinb, int nbins_pad,
+               const float* melT, int nmel, float* raw_ws, int* wmax_ws, void* out, int out_is_bf16, void* stream);
+
+/* ---- optimizer: AdamW on a flat parameter arena (bf16 param + fp32 master/m/v, 28 B/param) ------------- */
+int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,412 @@
+"""Op-level parity of every HIP kernel against a plain PyTorch fp32 expression of the oracle op it replaces
+(the oracle line is cited in include/afk.h).  All calls go through the C ABI (ops.py -> ctypes -> libafk.so)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _ops():
+    from audio_flamingo_amd import ops
+
+    return ops
+
+
+def _cmp(name, got, ref, atol, rtol):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[:8].tolist()
+        worst = err.argmax().item()
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} out of tol (atol={atol}, rtol={rtol}); max_err={err.max().item():.4g} "
+            f"at flat {worst} got={got.flatten()[worst].item():.5g} ref={ref.flatten()[worst].item():.5g}; first bad idx={idx}; "
+            f"ref_absmax={ref.abs().max().item():.4g}"
+        )
+
+
+def _rand(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1000, 1280, 1280), (129, 132, 64)])
+def test_gemm_plain(dev, M, N, K):
+    ops = _ops()
+    a = _rand((M, K), dev, seed=1).to(BF)
+    b = _rand((N, K), dev, seed=2).to(BF)  # asymmetric operands: catches row/col swaps
+    c = ops.gemm_nt(a, b)
+    ref = a.float() @ b.float().t()
+    _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
+
+
+def test_gemm_identity_layout(dev):
+    """A = I pattern with asymmetric B: output must equal B^T rows exactly (detects transposed C writes)."""
+    ops = _ops()
+    M = N = 128
+    K = 128
+    a = torch.eye(M, K, device=dev).to(BF)
+    b = (torch.arange(N * K, device=dev).reshape(N, K) % 251).float().to(BF)
+    c = ops.gemm_nt(a, b)
+    ref = b.float().t()[:M, :N]
+    _cmp("gemm identity", c, ref, atol=0, rtol=0)
+
+
+def test_gemm_epilogues(dev):
+    ops = _ops()
+    M, N, K = 384, 512, 256
+    a = _rand((M, K), dev, 0.5, 3).to(BF)
+    b = _rand((N, K), dev, 0.1, 4).to(BF)
+    bias = _rand((N,), dev, 1.0, 5).to(BF)
+    res = _rand((M, N), dev, 1.0, 6).to(BF)
+    lin = (a.float() @ b.float().t() + bias.float()).to(BF).float()
+    # bias + gelu (+preact)
+    pre = torch.empty((M, N), device=dev, dtype=BF)
+    c = ops.gemm_nt(a, b, bias=bias, gelu=True, preact_out=pre)
+    _cmp("preact", pre, lin, atol=2e-2, rtol=1e-2)
+    _cmp("bias+gelu", c, torch.nn.functional.gelu(lin), atol=2e-2, rtol=1e-2)
+    # bias + residual
+    c = ops.gemm_nt(a, b, bias=bias, residual=res)
+    _cmp("bias+res", c, lin + res.float(), atol=3e-2, rtol=1e-2)
+    # residual table broadcast (row m % 96)
+    tab = _rand((96, N), dev, 1.0, 7).to(BF)
+    c = ops.gemm_nt(a, b, residual=tab, res_mod=96)
+    ref = (a.float() @ b.float().t()).to(BF).float() + tab.float().repeat(M // 96, 1)
+    _cmp("res_mod", c, ref, atol=3e-2, rtol=1e-2)
+    # f32 out + accumulate
+    c32 = torch.ones((M, N), device=dev, dtype=torch.float32)
+    ops.gemm_nt(a, b, out=c32, accumulate=True)
+    _cmp("f32 accum", c32, a.float() @ b.float().t() + 1.0, atol=1e-2, rtol=1e-3)
+    # bf16 accumulate with strided operands (views into wider buffers)
+    wide_a = _rand((M, K + 64), dev, 0.5, 8).to(BF)
+    cb = res.clone()
+    ops.gemm_nt(wide_a[:, 64:], b, out=cb, accumulate=True)
+    _cmp("bf16 accum strided", cb, wide_a[:, 64:].float() @ b.float().t() + res.float(), atol=4e-2, rtol=1e-2)
+
+
+def test_transpose(dev):
+    ops = _ops()
+    for R, C in [(64, 64), (100, 72), (1500, 128), (8, 200)]:
+        x = _rand((R, C), dev, seed=R).to(BF)
+        t = ops.transpose(x)
+        rp = (R + 63) // 64 * 64
+        assert t.shape == (C, rp)
+        assert torch.equal(t[:, :R], x.t()), f"transpose {R}x{C} mismatch"
+        assert (t[:, R:] == 0).all(), "transpose pad not zero"
+    # heads
+    B, S, H, D = 2, 100, 3, 64
+    ld = H * D + 32
+    buf = _rand((B * S, ld), dev, seed=9).to(BF)
+    t = ops.transpose_heads(buf, B, S, H, D, ld, 128)
+    ref = buf[:, : H * D].reshape(B, S, H, D).permute(0, 2, 3, 1)
+    assert torch.equal(t[..., :S], ref) and (t[..., S:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("rows,D", [(37, 128), (1000, 1280), (64, 3584)])
+def test_layernorm(dev, rows, D):
+    ops = _ops()
+    x = _rand((rows, D), dev, 2.0, 1).to(BF)
+    w = (1 + 0.1 * _rand((D,), dev, seed=2)).to(BF)
+    b = (0.1 * _rand((D,), dev, seed=3)).to(BF)
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-5)
+    xr = x.float().requires_grad_(True)
+    wr, br = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5)
+    _cmp("ln fwd", y, ref, atol=2e-2, rtol=1e-2)
+    dy = _rand((rows, D), dev, 1.0, 4).to(BF)
+    ref.backward(dy.float())
+    dw = torch.empty(D, device=dev, dtype=BF)
+    db = torch.empty(D, device=dev, dtype=BF)
+    dx = ops.layernorm_bwd(x, w, dy, mean, rstd, dw, db)
+    _cmp("ln dx", dx, xr.grad, atol=3e-2, rtol=2e-2)
+    _cmp("ln dw", dw, wr.grad, atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
+    _cmp("ln db", db, br.grad, atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
+    # fused residual merge + accumulate
+    skip = _rand((rows, D), dev, 1.0, 5).to(BF)
+    dw2, db2 = dw.clone(), db.clone()
+    dx2 = ops.layernorm_bwd(x, w, dy, mean, rstd, dw2, db2, dx_add=skip, accumulate=True)
+    _cmp("ln dx+skip", dx2, xr.grad + skip.float(), atol=4e-2, rtol=2e-2)
+    _cmp("ln dw acc", dw2, 2 * wr.grad, atol=0.05 * math.sqrt(rows) + 0.1, rtol=3e-2)
+
+
+@pytest.mark.parametrize("rows,D", [(37, 96), (512, 3584)])
+def test_rmsnorm(dev, rows, D):
+    ops = _ops()
+    x = _rand((rows, D), dev, 2.0, 1).to(BF)
+    w = (1 + 0.1 * _rand((D,), dev, seed=2)).to(BF)
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+
+    def oracle(xf, wf):  # Qwen2RMSNorm.forward restated
+        var = xf.pow(2).mean(-1, keepdim=True)
+        return wf * (xf * torch.rsqrt(var + 1e-6))
+
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    ref = oracle(xr, wr)
+    _cmp("rms fwd", y, ref, atol=2e-2, rtol=1e-2)
+    dy = _rand((rows, D), dev, 1.0, 4).to(BF)
+    ref.backward(dy.float())
+    dw = torch.empty(D, device=dev, dtype=BF)
+    dx = ops.rmsnorm_bwd(x, w, dy, rstd, dw)
+    _cmp("rms dx", dx, xr.grad, atol=3e-2, rtol=2e-2)
+    _cmp("rms dw", dw, wr.grad, atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_gelu_silu_rope_misc(dev):
+    ops = _ops()
+    x = _rand((64, 512), dev, 2.0, 1).to(BF)
+    _cmp("gelu fwd", ops.gelu_fwd(x), torch.nn.functional.gelu(x.float()), 1e-2, 1e-2)
+    dy = _rand((64, 512), dev, 1.0, 2).to(BF)
+    xr = x.float().requires_grad_(True)
+    torch.nn.functional.gelu(xr).backward(dy.float())
+    _cmp("gelu bwd", ops.gelu_bwd(dy, x), xr.grad, 1e-2, 1e-2)
+    # swiglu
+    I = 256
+    gu = _rand((40, 2 * I), dev, 1.5, 3).to(BF)
+    gr = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(gr[:, :I]) * gr[:, I:]
+    h = ops.silu_mul_fwd(gu)
+    _cmp("silu_mul fwd", h, ref, 2e-2, 1e-2)
+    dh = _rand((40, I), dev, 1.0, 4).to(BF)
+    ref.backward(dh.float())
+    _cmp("silu_mul bwd", ops.silu_mul_bwd(gu, dh), gr.grad, 2e-2, 2e-2)
+    # rope: oracle apply_rotary_pos_emb
+    B, S, Hq, Hkv, D = 2, 24, 4, 2, 64
+    ld = (Hq + 2 * Hkv) * D
+    buf = _rand((B * S, ld), dev, 1.0, 5).to(BF)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device=dev).float() / D))
+    fr = torch.arange(S, device=dev).float()[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF), emb.sin().to(BF)
+
+    def rot(t):
+        return torch.cat([-t[..., D // 2:], t[..., : D // 2]], -1)
+
+    qk = buf[:, : (Hq + Hkv) * D].float().reshape(B, S, Hq + Hkv, D)
+    ref = qk * cos.float()[None, :, None] + rot(qk) * sin.float()[None, :, None]
+    out = buf.clone()
+    ops.rope_(out, cos, sin, S=S, nheads=Hq + Hkv, D=D)
+    _cmp("rope fwd", out[:, : (Hq + Hkv) * D].reshape(B, S, Hq + Hkv, D), ref, 2e-2, 1e-2)
+    assert torch.equal(out[:, (Hq + Hkv) * D:], buf[:, (Hq + Hkv) * D:]), "rope touched v columns"
+    # backward = transpose of the rotation: <rope(x), y> == <x, rope_bwd(y)>
+    y = _rand((B * S, ld), dev, 1.0, 6).to(BF)
+    yb = y.clone()
+    ops.rope_(yb, cos, sin, S=S, nheads=Hq + Hkv, D=D, backward=True)
+    n = (Hq + Hkv) * D
+    lhs = (out[:, :n].float() * y[:, :n].float()).sum()
+    rhs = (buf[:, :n].float() * yb[:, :n].float()).sum()
+    assert abs(lhs - rhs) < 2e-2 * abs(lhs) + 1.0, f"rope adjoint {lhs} vs {rhs}"
+    # add / cast / rowsum
+    a, b = _rand((33, 64), dev, seed=7).to(BF), _rand((33, 64), dev, seed=8).to(BF)
+    _cmp("add", ops.add(a, b), a.float() + b.float(), 1e-2, 1e-2)
+    f = _rand((1000,), dev, seed=9)
+    assert torch.equal(ops.cast_f32_bf16(f), f.to(BF))
+    xt = _rand((50, 192), dev, seed=10).to(BF)
+    out = torch.zeros(50, device=dev, dtype=BF)
+    ops.rowsum(xt, 150, out)
+    _cmp("rowsum", out, xt[:, :150].float().sum(1), 0.1, 1e-2)
+
+
+def test_conv_stem_helpers(dev):
+    ops = _ops()
+    W, C, T, Co = 2, 16, 100, 32
+    x = _rand((W, C, T), dev, 1.0, 1)
+    w1 = _rand((Co, C, 3), dev, 0.2, 2).to(BF)
+    for xin in (x, x.to(BF)):
+        col = ops.im2col_conv1(xin.contiguous())
+        wp = ops.conv_weight_to_gemm(w1)
+        y = ops.gemm_nt(torch.nn.functional.pad(col, (0, 64 - col.shape[1] % 64)) if col.shape[1] % 64 else col,
+                        torch.nn.functional.pad(wp, (0, 64 - wp.shape[1] % 64)) if wp.shape[1] % 64 else wp)
+        ref = torch.nn.functional.conv1d(xin.to(BF).float(), w1.float(), padding=1)  # [W, Co, T]
+        _cmp("conv1 via im2col", y.reshape(W, T, Co).permute(0, 2, 1), ref, 3e-2, 2e-2)
+    # conv2 (stride 2) from time-major input
+    Ci = 64
+    h = _rand((W * T, Ci), dev, 1.0, 3).to(BF)
+    w2 = _rand((Co, Ci, 3), dev, 0.1, 4).to(BF)
+    col = ops.im2col_conv2(h, W, T, Ci)
+    y = ops.gemm_nt(col, ops.conv_weight_to_gemm(w2))
+    ref = torch.nn.functional.conv1d(h.float().reshape(W, T, Ci).permute(0, 2, 1), w2.float(), stride=2, padding=1)
+    _cmp("conv2 via im2col", y.reshape(W, T // 2, Co).permute(0, 2, 1), ref, 5e-2, 2e-2)
+    # col2im is the adjoint of im2col
+    dcol = _rand(tuple(col.shape), dev, 1.0, 5).to(BF)
+    dh = ops.col2im_conv2(dcol, W, T, Ci)
+    lhs = (col.float() * dcol.float()).sum()
+    rhs = (h.float() * dh.float()).sum()
+    assert abs(lhs - rhs) < 2e-2 * abs(lhs) + 2.0, f"col2im adjoint {lhs} vs {rhs}"
+    # weight grad permute round trip
+    dwp = _rand((Co, 3 * Ci), dev, 1.0, 6).to(BF)
+    dw = torch.zeros((Co, Ci, 3), device=dev, dtype=BF)
+    ops.conv_weight_grad_from_gemm(dwp, dw)
+    assert torch.equal(dw, dwp.reshape(Co, 3, Ci).permute(0, 2, 1))
+    # avgpool
+    xp = _rand((40, 64), dev, 1.0, 7).to(BF)
+    _cmp("pool fwd", ops.avgpool2_fwd(xp, 20, 64), xp.float().reshape(20, 2, 64).mean(1), 1e-2, 1e-2)
+    dyp = _rand((20, 64), dev, 1.0, 8).to(BF)
+    _cmp("pool bwd", ops.avgpool2_bwd(dyp, 20, 64), (0.5 * dyp.float()).repeat_interleave(2, 0), 1e-2, 1e-2)
+
+
+def test_embed_scatter(dev):
+    ops = _ops()
+    V, H, B, S, AID = 50, 64, 3, 700, 49
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, V - 1, (B, S), generator=g)
+    ids[0, 5:300] = AID
+    ids[2, 600:700] = AID
+    ids = ids.to(dev)
+    n_audio = int((ids == AID).sum())
+    embed = _rand((V, H), dev, 1.0, 1).to(BF)
+    audio = _rand((n_audio, H), dev, 1.0, 2).to(BF)
+    src, cnt = ops.placeholder_scan(ids, AID)
+    assert int(cnt.item()) == n_audio
+    out = ops.embed_scatter_fwd(ids.reshape(-1), src, embed, audio)
+    ref = embed[ids.reshape(-1)].clone()
+    ref[(ids == AID).reshape(-1)] = audio  # masked_scatter row-major order
+    assert torch.equal(out, ref), "embed scatter mismatch"
+    dout = _rand((B * S, H), dev, 1.0, 3).to(BF)
+    d_embed = torch.zeros((V, H), device=dev, dtype=torch.bfloat16)
+    d_audio = torch.empty((n_audio, H), device=dev, dtype=BF)
+    ops.embed_scatter_bwd(ids.reshape(-1), src, dout, d_embed, d_audio)
+    mask = (ids == AID).reshape(-1)
+    assert torch.equal(d_audio, dout[mask])
+    ref_de = torch.zeros((V, H), device=dev)
+    ref_de.index_add_(0, ids.reshape(-1)[~mask], dout[~mask].float())
+    _cmp("d_embed", d_embed, ref_de, atol=0.25, rtol=3e-2)  # bf16 running sums over ~40 duplicates
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, S, Hq, Hkv, D, scale, causal, kv_len):
+    q = qkv[:, : Hq * D].float().reshape(B, S, Hq, D).transpose(1, 2)
+    k = qkv[:, Hq * D: (Hq + Hkv) * D].float().reshape(B, S, Hkv, D).transpose(1, 2)
+    v = qkv[:, (Hq + Hkv) * D:].float().reshape(B, S, Hkv, D).transpose(1, 2)
+    g = Hq // Hkv
+    k, v = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
+    s = (q @ k.transpose(-1, -2)) * scale
+    mask = torch.zeros(B, 1, S, S, dtype=torch.bool, device=qkv.device)
+    if causal:
+        mask |= torch.triu(torch.ones(S, S, dtype=torch.bool, device=qkv.device), 1)
+    if kv_len is not None:
+        mask |= (torch.arange(S, device=qkv.device)[None, :] >= kv_len[:, None].long())[:, None, None, :]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * S, Hq * D)
+    return o
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,causal,pad", [
+    (2, 96, 4, 4, 64, False, False),
+    (2, 150, 4, 4, 64, False, True),
+    (2, 200, 4, 2, 128, True, False),
+    (1, 77, 6, 2, 32, True, False),
+    (1, 1500, 2, 2, 64, False, False),
+])
+def test_attention(dev, B, S, Hq, Hkv, D, causal, pad):
+    ops = _ops()
+    ld = (Hq + 2 * Hkv) * D
+    qkv = _rand((B * S, ld), dev, 1.0, 1).to(BF)
+    scale = D ** -0.5
+    kv_len = None
+    if pad:
+        kv_len = torch.tensor([S, S - 37], device=dev, dtype=torch.int32)[:B]
+    o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=causal, kv_len=kv_len)
+    qr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qr, B, S, Hq, Hkv, D, scale, causal, kv_len)
+    _cmp("attn fwd", o, ref, atol=2e-2, rtol=2e-2)
+    do = _rand((B * S, Hq * D), dev, 1.0, 2).to(BF)
+    ref.backward(do.float())
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=causal, kv_len=kv_len)
+    nq, nk = Hq * D, Hkv * D
+    _cmp("attn dq", dqkv[:, :nq], qr.grad[:, :nq], atol=3e-2, rtol=3e-2)
+    _cmp("attn dk", dqkv[:, nq: nq + nk], qr.grad[:, nq: nq + nk], atol=4e-2, rtol=3e-2)
+    _cmp("attn dv", dqkv[:, nq + nk:], qr.grad[:, nq + nk:], atol=4e-2, rtol=3e-2)
+
+
+def test_attention_online_softmax_spike(dev):
+    """force a late running-max jump (guide rule 26): one key row aligned with one query row at a late tile"""
+    ops = _ops()
+    B, S, H, D = 1, 160, 1, 64
+    qkv = _rand((B * S, 3 * D), dev, 0.3, 3).to(BF)
+    qkv[10, :D] = 4.0
+    qkv[140, D: 2 * D] = 4.0
+    o, _ = ops.attn_fwd(qkv, B, S, H, H, D, scale=D ** -0.5, causal=False)
+    _cmp("attn spike", o, _attn_ref(qkv, B, S, H, H, D, D ** -0.5, False, None), 2e-2, 2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ CE
+def test_cross_entropy(dev):
+    ops = _ops()
+    rows, V = 70, 1000 + 64
+    logits = _rand((rows, V), dev, 3.0, 1).to(BF)
+    g = torch.Generator().manual_seed(1)
+    labels = torch.randint(0, V, (rows,), generator=g)
+    labels[::5] = -100
+    labels = labels.to(dev)
+    lr = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-100)
+    ref.backward()
+    denom = ops.count_valid(labels)
+    assert denom.item() == (labels >= 0).sum().item()
+    row_loss = torch.empty(rows, device=dev, dtype=torch.float32)
+    work = logits.clone()
+    ops.ce_fwd_bwd_(work, labels, row_loss, denom)
+    loss = torch.zeros(1, device=dev)
+    ops.loss_reduce(row_loss, denom, loss)
+    assert abs(loss.item() - ref.item()) < 2e-4 * abs(ref.item()) + 1e-5, f"CE loss {loss.item()} vs {ref.item()}"
+    _cmp("dlogits", work, lr.grad, atol=2e-4, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ AdamW
+def test_adamw(dev):
+    ops = _ops()
+    n = 4099
+    p = torch.nn.Parameter(_rand((n,), dev, 1.0, 1))
+    opt = torch.optim.AdamW([p], lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    master = p.detach().clone()
+    m, v = torch.zeros_like(master), torch.zeros_like(master)
+    pb = master.to(BF)
+    for step in range(1, 4):
+        g = _rand((n,), dev, 1.0, 10 + step).to(BF)
+        p.grad = g.float()
+        opt.step()
+        ops.adamw_step(master, m, v, g, pb, lr=1e-2, beta1=0.9, beta2=0.95, eps=1e-8, weight_decay=0.1, step=step)
+    _cmp("adamw master", master, p.detach(), atol=1e-5, rtol=1e-4)
+    assert torch.equal(pb, master.to(BF))
+
+
+# ------------------------------------------------------------------------------------------------ log-mel
+def test_logmel(dev):
+    """vs the oracle expression (feature_extraction_whisper.py:135-168) evaluated with torch.stft in fp32 on the CPU"""
+    import numpy as np
+    from audio_flamingo_amd.frontend import LogMelFrontend, mel_filter_bank
+
+    rng = np.random.default_rng(0)
+    n = 480000
+    wav = np.zeros((2, n), np.float32)
+    wav[0] = rng.standard_normal(n).astype(np.float32) * 0.1
+    t = np.arange(80000) / 16000.0
+    wav[1, :80000] = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.01 * rng.standard_normal(80000)).astype(np.float32)  # 5 s clip, zero padded
+    w = torch.from_numpy(wav)
+    window = torch.hann_window(400)
+    stft = torch.stft(w, 400, 160, window=window, return_complex=True)
+    mag = stft[..., :-1].abs() ** 2
+    mel = torch.from_numpy(mel_filter_bank(128).astype(np.float32))
+    spec = torch.clamp(mel.T @ mag, min=1e-10).log10()
+    mx = spec.amax(dim=(1, 2), keepdim=True)
+    ref = (torch.maximum(spec, mx - 8.0) + 4.0) / 4.0
+    fe = LogMelFrontend(dev)
+    out = fe(w.to(dev))
+    assert out.shape == (2, 128, 3000)
+    err = (out.cpu() - ref).abs()
+    # the oracle documents 1e-5 agreement between its own two paths; log10 of near-floor bins amplifies fp32 noise,
+    # so the bar is 1e-4 absolute on the (x+4)/4 scale with a 1e-5 median
+    assert err.max().item() < 2e-4, f"logmel max err {err.max().item()} at {err.argmax().item()}"
+    assert err.median().item() < 1e-5, f"logmel median err {err.median().item()}"
+    outb = fe(w.to(dev), out_dtype=torch.bfloat16)
+    assert torch.equal(outb, out.to(torch.bfloat16))
