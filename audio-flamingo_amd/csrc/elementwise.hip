@@ -180,6 +180,25 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16* __restrict__ a, co
     }
 }
 
+// y = (accumulate ? y : 0) + (*scale) * x     (scale is a DEVICE scalar: no host sync to apply an upstream loss gradient)
+__global__ __launch_bounds__(256) void scale_add_kernel(const bf16* x, bf16* y, int64_t nvec, const float* __restrict__ scale,
+                                                        int accumulate) {
+    const float a = *scale;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 xv = *(const bf16x8*)(x + 8 * i);
+        bf16x8 o;
+        if (accumulate) {
+            const bf16x8 yv = *(const bf16x8*)(y + 8 * i);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)yv[e] + a * (float)xv[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(a * (float)xv[e]);
+        }
+        *(bf16x8*)(y + 8 * i) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ a, bf16* __restrict__ o, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) o[i] = (bf16)a[i];
 }
@@ -522,6 +541,14 @@ extern "C" int afk_add_bf16(const void* a, const void* b, void* out, int64_t n, 
     hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)a, (const bf16*)b, (bf16*)out,
                        n / 8);
     AFK_LAUNCH_CHECK("afk_add_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_scale_add_bf16(const void* x, void* y, int64_t n, const float* scale_dev, int accumulate, void* stream) {
+    AFK_REQUIRE(x && y && scale_dev && n % 8 == 0, "afk_scale_add_bf16: n must be a multiple of 8");
+    hipLaunchKernelGGL(scale_add_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n / 8, scale_dev,
+                       accumulate);
+    AFK_LAUNCH_CHECK("afk_scale_add_bf16");
     return AFK_OK;
 }
 

@@ -1,0 +1,386 @@
+"""Layer-level autograd Functions with hand-written backward passes.
+
+Each Function is one stage of the oracle's forward expressed as a sequence of afk kernels, and
+its backward is the matching hand-derived sequence: autograd only stitches the stages together.  Weight
+gradients never travel through autograd: the wgrad GEMMs write (or accumulate) directly into the gradient arena
+(arena.py) and the Functions return ``None`` for their parameter inputs.  The single ``anchor`` tensor each
+Function takes is a parameter view that only serves to make the output require grad.
+
+Backward GEMM forms (all on the one NT kernel, csrc/gemm.hip):
+    dgrad  dX[M,K] = dY[M,N] . Wt[K,N]^T          Wt = arena shadow (W^T, refreshed after every optimizer step)
+    wgrad  dW[N,K] = dYt[N,M] . Xt[K,M]^T          dYt, Xt = afk_transpose_bf16 (M zero-padded to a multiple of 64)
+    bias   db[N]   = rowsum(dYt)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .arena import Arena, Block
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def _wgrad(arena: Arena, blk: Block, dyt, xt, Mvalid, *, bias_blk=None, bias_slices=None, dyt_rows=None):
+    """blk.grad[N,K] (+)= dyt[N,Mp] . xt[K,Mp]^T ; bias grad(s) from rowsum(dyt)."""
+    gw = blk.grad.reshape(blk.shape[0], -1)
+    ops.gemm_nt(dyt, xt, out=gw, accumulate=not blk.fresh)
+    arena.grad_written(blk)
+    if bias_blk is not None:
+        acc = not bias_blk.fresh
+        if bias_slices is None:
+            ops.rowsum(dyt, Mvalid, bias_blk.grad, accumulate=acc)
+        else:
+            for (s, e) in bias_slices:
+                ops.rowsum(dyt[s:e], Mvalid, bias_blk.grad[s:e], accumulate=acc)
+        arena.grad_written(bias_blk)
+
+
+def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True):
+    """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena."""
+    M = dy.shape[0]
+    blk = arena[wkey]
+    dyt = ops.transpose(dy)  # [N, Mp]
+    xt = ops.transpose(x)    # [K, Mp]
+    _wgrad(arena, blk, dyt, xt, M, bias_blk=arena[bkey] if bkey else None, bias_slices=bias_slices)
+    del dyt, xt
+    if not need_dx:
+        return None
+    wt = arena.shadow(wkey)  # [K, pad64(N)]
+    return ops.gemm_nt(dy, wt, K=dy.shape[1])
+
+
+# ---------------------------------------------------------------------------------------------- conv stem (a2)
+class ConvStemFn(torch.autograd.Function):
+    """gelu(conv1) -> gelu(conv2, stride 2) -> permute -> + embed_positions   (modeling_audioflamingo3.py:380-385)"""
+
+    @staticmethod
+    def forward(ctx, feats, anchor, arena, keys, pos, W, T, C):
+        k1w, k1b, k2w, k2b = keys
+        E = arena[k1w].shape[0]
+        col1 = ops.im2col_conv1(feats)  # [W*T, 3C]
+        w1 = arena.shadow(k1w)  # [E, 3C] tap-major
+        M1 = W * T
+        pre1 = torch.empty((M1, E), device=feats.device, dtype=torch.bfloat16)
+        h1 = ops.gemm_nt(col1, w1, bias=arena[k1b].data, gelu=True, preact_out=pre1)
+        T2 = (T - 1) // 2 + 1
+        col2 = ops.im2col_conv2(h1, W, T, E)
+        del h1
+        w2 = arena.shadow(k2w)
+        pre2 = torch.empty((W * T2, E), device=feats.device, dtype=torch.bfloat16)
+        x0 = ops.gemm_nt(col2, w2, bias=arena[k2b].data, gelu=True, preact_out=pre2, residual=pos, res_mod=T2)
+        ctx.save_for_backward(col1, pre1, pre2)
+        ctx.meta = (arena, keys, W, T, T2, E)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        col1, pre1, pre2 = ctx.saved_tensors
+        arena, (k1w, k1b, k2w, k2b), W, T, T2, E = ctx.meta
+        dx0 = dx0.contiguous()
+        dpre2 = ops.gelu_bwd(dx0, pre2)
+        h1 = ops.gelu_fwd(pre1)
+        col2 = ops.im2col_conv2(h1, W, T, E)
+        del h1
+        dyt = ops.transpose(dpre2)
+        xt = ops.transpose(col2)
+        del col2
+        b2 = arena[k2w]
+        dwp = ops.gemm_nt(dyt, xt)  # [E, 3E] tap-major
+        ops.conv_weight_grad_from_gemm(dwp, b2.grad, accumulate=not b2.fresh)
+        arena.grad_written(b2)
+        bb = arena[k2b]
+        ops.rowsum(dyt, W * T2, bb.grad, accumulate=not bb.fresh)
+        arena.grad_written(bb)
+        del dyt, xt, dwp
+        dcol2 = ops.gemm_nt(dpre2, arena.shadow_aux(k2w), K=E)  # [W*T2, 3E]
+        dh1 = ops.col2im_conv2(dcol2, W, T, E)
+        del dcol2
+        dpre1 = ops.gelu_bwd(dh1, pre1)
+        del dh1
+        dyt = ops.transpose(dpre1)
+        xt = ops.transpose(col1)
+        b1 = arena[k1w]
+        dwp = ops.gemm_nt(dyt, xt)
+        ops.conv_weight_grad_from_gemm(dwp, b1.grad, accumulate=not b1.fresh)
+        arena.grad_written(b1)
+        bb = arena[k1b]
+        ops.rowsum(dyt, W * T, bb.grad, accumulate=not bb.fresh)
+        arena.grad_written(bb)
+        return None, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- encoder layer (a5, a6)
+class EncoderLayerFn(torch.autograd.Function):
+    """pre-LN attention block + pre-LN GELU MLP   (AudioFlamingo3EncoderLayer.forward, :211-245)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, pfx, W, S, H, kv_len):
+        E = x.shape[1]
+        D = E // H
+        A = lambda k: arena[pfx + k]
+        h, mean1, rstd1 = ops.layernorm_fwd(x, A("self_attn_layer_norm.weight").data, A("self_attn_layer_norm.bias").data)
+        qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
+        # q*scaling before the dot product (:142) == scaling the scores by the same power of two
+        o, lse = ops.attn_fwd(qkv, W, S, H, H, D, scale=D ** -0.5, causal=False, kv_len=kv_len)
+        x2 = ops.gemm_nt(o, A("self_attn.out_proj.weight").data, bias=A("self_attn.out_proj.bias").data, residual=x)
+        h2, mean2, rstd2 = ops.layernorm_fwd(x2, A("final_layer_norm.weight").data, A("final_layer_norm.bias").data)
+        pre = torch.empty((x.shape[0], A("fc1.weight").shape[0]), device=x.device, dtype=torch.bfloat16)
+        f = ops.gemm_nt(h2, A("fc1.weight").data, bias=A("fc1.bias").data, gelu=True, preact_out=pre)
+        x3 = ops.gemm_nt(f, A("fc2.weight").data, bias=A("fc2.bias").data, residual=x2)
+        ctx.save_for_backward(x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len)
+        ctx.meta = (arena, pfx, W, S, H, D)
+        return x3
+
+    @staticmethod
+    def backward(ctx, dx3):
+        x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len = ctx.saved_tensors
+        arena, pfx, W, S, H, D = ctx.meta
+        E = x.shape[1]
+        A = lambda k: arena[pfx + k]
+        dx3 = dx3.contiguous()
+        f = ops.gelu_fwd(pre)
+        df = linear_bwd(arena, dx3, f, pfx + "fc2.weight", bkey=pfx + "fc2.bias")
+        del f
+        dpre = ops.gelu_bwd(df, pre)
+        del df
+        dh2 = linear_bwd(arena, dpre, h2, pfx + "fc1.weight", bkey=pfx + "fc1.bias")
+        del dpre
+        lw, lb = A("final_layer_norm.weight"), A("final_layer_norm.bias")
+        dx2 = ops.layernorm_bwd(x2, lw.data, dh2, mean2, rstd2, lw.grad, lb.grad, dx_add=dx3, accumulate=not lw.fresh)
+        arena.grad_written(lw), arena.grad_written(lb)
+        del dh2
+        do = linear_bwd(arena, dx2, o, pfx + "self_attn.out_proj.weight", bkey=pfx + "self_attn.out_proj.bias")
+        dqkv = ops.attn_bwd(qkv, o, do, lse, W, S, H, H, D, scale=D ** -0.5, causal=False, kv_len=kv_len)
+        del do
+        # k_proj has no bias (:112): only the q and v thirds of the fused bias receive a gradient
+        dh = linear_bwd(arena, dqkv, h, pfx + "self_attn.qkv.weight", bkey=pfx + "self_attn.qkv.bias",
+                        bias_slices=[(0, E), (2 * E, 3 * E)])
+        del dqkv
+        lw, lb = A("self_attn_layer_norm.weight"), A("self_attn_layer_norm.bias")
+        dx = ops.layernorm_bwd(x, lw.data, dh, mean1, rstd1, lw.grad, lb.grad, dx_add=dx2, accumulate=not lw.fresh)
+        arena.grad_written(lw), arena.grad_written(lb)
+        return dx, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- avg-pool + LN (a7)
+class PoolNormFn(torch.autograd.Function):
+    """AvgPool1d(2,2) over time then LayerNorm (:401-403)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, wkey, bkey, out_rows):
+        E = x.shape[1]
+        pooled = ops.avgpool2_fwd(x, out_rows, E)
+        y, mean, rstd = ops.layernorm_fwd(pooled, arena[wkey].data, arena[bkey].data)
+        ctx.save_for_backward(pooled, mean, rstd)
+        ctx.meta = (arena, wkey, bkey, out_rows, E)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pooled, mean, rstd = ctx.saved_tensors
+        arena, wkey, bkey, out_rows, E = ctx.meta
+        lw, lb = arena[wkey], arena[bkey]
+        dp = ops.layernorm_bwd(pooled, lw.data, dy.contiguous(), mean, rstd, lw.grad, lb.grad, accumulate=not lw.fresh)
+        arena.grad_written(lw), arena.grad_written(lb)
+        return ops.avgpool2_bwd(dp, out_rows, E), None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- projector (a8)
+class ProjectorFn(torch.autograd.Function):
+    """Linear -> GELU -> Linear (AudioFlamingo3MultiModalProjector.forward, :435-439)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, pfx):
+        A = lambda k: arena[pfx + k]
+        pre = torch.empty((x.shape[0], A("linear_1.weight").shape[0]), device=x.device, dtype=torch.bfloat16)
+        a = ops.gemm_nt(x, A("linear_1.weight").data, bias=A("linear_1.bias").data, gelu=True, preact_out=pre)
+        y = ops.gemm_nt(a, A("linear_2.weight").data, bias=A("linear_2.bias").data)
+        ctx.save_for_backward(x, pre)
+        ctx.meta = (arena, pfx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre = ctx.saved_tensors
+        arena, pfx = ctx.meta
+        dy = dy.contiguous()
+        a = ops.gelu_fwd(pre)
+        da = linear_bwd(arena, dy, a, pfx + "linear_2.weight", bkey=pfx + "linear_2.bias")
+        dpre = ops.gelu_bwd(da, pre)
+        dx = linear_bwd(arena, dpre, x, pfx + "linear_1.weight", bkey=pfx + "linear_1.bias")
+        return dx, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- embedding scatter (a10)
+class EmbedScatterFn(torch.autograd.Function):
+    """embed_tokens(input_ids) with <sound> rows overwritten by audio rows in row-major order (:532-545)"""
+
+    @staticmethod
+    def forward(ctx, audio, anchor, arena, ekey, ids, src):
+        out = ops.embed_scatter_fwd(ids, src, arena[ekey].data, audio)
+        ctx.save_for_backward(ids, src)
+        ctx.meta = (arena, ekey, None if audio is None else audio.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, src = ctx.saved_tensors
+        arena, ekey, ashape = ctx.meta
+        blk = arena[ekey]
+        if blk.fresh:
+            blk.grad.zero_()  # sparse row updates need a cleared destination
+        d_audio = None
+        if ashape is not None:
+            # rows of padded windows that no placeholder references keep a zero gradient
+            d_audio = torch.zeros(ashape, device=dout.device, dtype=torch.bfloat16)
+        ops.embed_scatter_bwd(ids, src, dout.contiguous(), blk.grad, d_audio)
+        arena.grad_written(blk)
+        return d_audio, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- decoder layer (a13-a16)
+class DecoderLayerFn(torch.autograd.Function):
+    """RMSNorm -> GQA causal attention (RoPE) -> +res ; RMSNorm -> SwiGLU -> +res  (Qwen2DecoderLayer.forward, :269-298)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len):
+        A = lambda k: arena[pfx + k]
+        h, rstd1 = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
+        qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
+        ops.rope_(qkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos)
+        o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+        x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
+        h2, rstd2 = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
+        gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
+        a = ops.silu_mul_fwd(gu)
+        x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
+        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len)
+        ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)
+        return x3
+
+    @staticmethod
+    def backward(ctx, dx3):
+        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len = ctx.saved_tensors
+        arena, pfx, B, S, Hq, Hkv, D = ctx.meta
+        A = lambda k: arena[pfx + k]
+        dx3 = dx3.contiguous()
+        a = ops.silu_mul_fwd(gu)
+        da = linear_bwd(arena, dx3, a, pfx + "mlp.down_proj.weight")
+        del a
+        dgu = ops.silu_mul_bwd(gu, da)
+        del da
+        dh2 = linear_bwd(arena, dgu, h2, pfx + "mlp.gate_up.weight")
+        del dgu
+        nw = A("post_attention_layernorm.weight")
+        dx2 = ops.rmsnorm_bwd(x2, nw.data, dh2, rstd2, nw.grad, dx_add=dx3, accumulate=not nw.fresh)
+        arena.grad_written(nw)
+        del dh2
+        do = linear_bwd(arena, dx2, o, pfx + "self_attn.o_proj.weight")
+        dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+        del do
+        ops.rope_(dqkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos, backward=True)
+        dh = linear_bwd(arena, dqkv, h, pfx + "self_attn.qkv.weight", bkey=pfx + "self_attn.qkv.bias")
+        del dqkv
+        nw = A("input_layernorm.weight")
+        dx = ops.rmsnorm_bwd(x, nw.data, dh, rstd1, nw.grad, dx_add=dx2, accumulate=not nw.fresh)
+        arena.grad_written(nw)
+        return (dx,) + (None,) * 13
+
+
+class RMSNormFn(torch.autograd.Function):
+    """final Qwen2RMSNorm (modeling_qwen2.py:398)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, wkey, eps):
+        y, rstd = ops.rmsnorm_fwd(x, arena[wkey].data, eps)
+        ctx.save_for_backward(x, rstd)
+        ctx.meta = (arena, wkey)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, rstd = ctx.saved_tensors
+        arena, wkey = ctx.meta
+        nw = arena[wkey]
+        dx = ops.rmsnorm_bwd(x, nw.data, dy.contiguous(), rstd, nw.grad, accumulate=not nw.fresh)
+        arena.grad_written(nw)
+        return dx, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- lm_head (+ fused loss) (a17, a18)
+class LMHeadFn(torch.autograd.Function):
+    """logits = hidden @ lm_head.weight^T   (materialised; used for generate() and parity checks)"""
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, wkey):
+        y = ops.gemm_nt(x, arena[wkey].data)
+        ctx.save_for_backward(x)
+        ctx.meta = (arena, wkey)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        arena, wkey = ctx.meta
+        return linear_bwd(arena, dy.contiguous(), x, wkey), None, None, None
+
+
+class LMHeadLossFn(torch.autograd.Function):
+    """lm_head + shifted cross-entropy without materialising [B*S, V] (lm_head :625-627 + ForCausalLMLoss, loss_utils.py:51-72).
+
+    Row chunks: logits chunk (bf16, as the oracle's lm_head output) -> afk_ce_fwd_bwd turns it into dlogits in place
+    -> dgrad / wgrad GEMMs consume it -> the chunk buffer is reused.  Gradients are produced here for an upstream
+    gradient of 1 and rescaled by the device-side grad_output in backward (no host sync).
+    """
+
+    CHUNK = 2048
+
+    @staticmethod
+    def forward(ctx, x, anchor, arena, wkey, shift_labels, denom):
+        M, H = x.shape
+        blk = arena[wkey]
+        V = blk.shape[0]
+        dev = x.device
+        need_grad = torch.is_grad_enabled()
+        row_loss = torch.empty(M, device=dev, dtype=torch.float32)
+        dx = torch.empty_like(x) if need_grad else None
+        chunk = min(LMHeadLossFn.CHUNK, M)
+        buf = torch.empty((chunk, V), device=dev, dtype=torch.bfloat16)
+        wt = arena.shadow(wkey) if need_grad else None
+        if need_grad:
+            # unscaled lm_head gradient goes to a private buffer when it must be accumulated into existing grads
+            gw_tmp = blk.grad if blk.fresh else torch.empty_like(blk.grad)
+        first = True
+        for s in range(0, M, chunk):
+            e = min(M, s + chunk)
+            n = e - s
+            logits = buf[:n]
+            ops.gemm_nt(x[s:e], blk.data, out=logits)
+            ops.ce_fwd_bwd_(logits, shift_labels[s:e], row_loss[s:e], denom, upstream=1.0, write_grad=need_grad)
+            if need_grad:
+                ops.gemm_nt(logits, wt, out=dx[s:e], K=V)
+                dlt = ops.transpose(logits)      # [V, pad64(n)]
+                xt = ops.transpose(x[s:e])       # [H, pad64(n)]
+                ops.gemm_nt(dlt, xt, out=gw_tmp, accumulate=not first)
+                del dlt, xt
+                first = False
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        ops.loss_reduce(row_loss, denom, loss)
+        if need_grad:
+            ctx.save_for_backward(dx, gw_tmp)
+            ctx.meta = (arena, wkey, gw_tmp is blk.grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dx, gw_tmp = ctx.saved_tensors
+        arena, wkey, inplace = ctx.meta
+        blk = arena[wkey]
+        g32 = g.reshape(1).float()
+        ops.scale_add_(dx, dx, g32, accumulate=False)
+        if inplace:
+            ops.scale_add_(blk.grad, blk.grad, g32, accumulate=False)
+        else:
+            ops.scale_add_(gw_tmp, blk.grad, g32, accumulate=True)
+        arena.grad_written(blk)
+        return dx, None, None, None, None, None

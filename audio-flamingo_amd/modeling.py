@@ -1,0 +1,354 @@
+"""MI355X-native Audio Flamingo 3 model with the surface of transformers' AudioFlamingo3ForConditionalGeneration.
+
+Mirrors (same constructor config classes, same ``forward`` argument names, same ``state_dict`` keys, ``generate``):
+    transformers/models/audioflamingo3/modeling_audioflamingo3.py:570-642 (ForConditionalGeneration)
+    :448-562 (Model), :302-416 (Encoder), :419-439 (projector); transformers/models/qwen2/modeling_qwen2.py:321-402.
+The arithmetic is entirely the hand-written gfx950 kernels of libafk.so (functional.py); this module only owns
+the parameter layout (arena.py) and the order of the stages.  Parameters named as in the oracle are views into
+fused arena blocks (q|k|v and gate|up are stored contiguously so that each is one GEMM), so
+``load_state_dict`` from an oracle checkpoint and ``state_dict`` round-trip unchanged.
+
+Deviations from the oracle surface (documented, not silent):
+  * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``;
+  * ``generate`` is greedy (do_sample=False) and recomputes the prefix each step (KV-cache decode is a next-round row);
+  * decoder padding must be on the right (``attention_mask`` of the form 1..10..0); left padding raises.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import AfkError
+from .arena import Arena
+from . import functional as F_
+
+
+@dataclass
+class AF3Output:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[object] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+    audio_hidden_states: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        return getattr(self, k) if isinstance(k, str) else tuple(v for v in (self.loss, self.logits) if v is not None)[k]
+
+
+class _Holder(nn.Module):
+    """parameter container that reproduces the oracle's module tree (and therefore its state_dict keys)"""
+
+
+def _attach(root: nn.Module, name: str, param: nn.Parameter):
+    parts = name.split(".")
+    m = root
+    for p in parts[:-1]:
+        if p not in m._modules:
+            m.add_module(p, _Holder())
+        m = m._modules[p]
+    m.register_parameter(parts[-1], param)
+
+
+class AudioFlamingo3ForConditionalGeneration(nn.Module):
+    """Drop-in for the oracle class of the same name (config = transformers.AudioFlamingo3Config or a duck-typed object)."""
+
+    def __init__(self, config, device="cuda", init_seed: Optional[int] = 0):
+        super().__init__()
+        self.config = config
+        ac, tc = config.audio_config, config.text_config
+        self.device_ = torch.device(device)
+        # NOTE: construction on "cpu" is allowed for host-side logic (layout, state_dict, DP bucketing tests);
+        # every compute entry point raises AfkError for non-HIP tensors - there is no CPU arithmetic path.
+        self.E, self.enc_heads, self.enc_ffn = ac.hidden_size, ac.num_attention_heads, ac.intermediate_size
+        self.enc_layers, self.n_mels, self.max_pos = ac.num_hidden_layers, ac.num_mel_bins, ac.max_source_positions
+        self.H, self.I, self.V = tc.hidden_size, tc.intermediate_size, tc.vocab_size
+        self.Hq, self.Hkv = tc.num_attention_heads, tc.num_key_value_heads
+        self.D = getattr(tc, "head_dim", None) or self.H // self.Hq
+        self.dec_layers, self.rms_eps = tc.num_hidden_layers, tc.rms_norm_eps
+        rp = getattr(tc, "rope_parameters", None) or {}
+        self.rope_theta = float(rp.get("rope_theta", getattr(tc, "rope_theta", 10000.0)) if isinstance(rp, dict) else getattr(tc, "rope_theta", 10000.0))
+        self.audio_token_id = config.audio_token_id
+        self.check_placeholders = True
+        for name, v in (("audio hidden", self.E), ("encoder ffn", self.enc_ffn), ("text hidden", self.H), ("intermediate", self.I),
+                        ("vocab", self.V), ("3*n_mels", 3 * self.n_mels)):
+            if v % 64:
+                raise AfkError(f"{name} size {v} must be a multiple of 64 for the MFMA GEMM")
+        if (self.E // self.enc_heads) not in (32, 64, 128) or self.D not in (32, 64, 128):
+            raise AfkError("head_dim must be 32, 64 or 128")
+
+        # ---------------- arena layout (forward order; one bucket per layer)
+        a = Arena(self.device_)
+        self.arena = a
+        E, Fd, H, I, V = self.E, self.enc_ffn, self.H, self.I, self.V
+        at, pj, lm = "model.audio_tower.", "model.multi_modal_projector.", "model.language_model."
+        b = a.new_bucket("stem")
+        a.add(at + "conv1.weight", (E, self.n_mels, 3), b, shadow="conv")
+        a.add(at + "conv1.bias", (E,), b, decay=False)
+        a.add(at + "conv2.weight", (E, E, 3), b, shadow="conv")
+        a.add(at + "conv2.bias", (E,), b, decay=False)
+        for i in range(self.enc_layers):
+            p = f"{at}layers.{i}."
+            b = a.new_bucket(f"enc{i}")
+            a.add(p + "self_attn_layer_norm.weight", (E,), b, decay=False)
+            a.add(p + "self_attn_layer_norm.bias", (E,), b, decay=False)
+            a.add(p + "self_attn.qkv.weight", (3 * E, E), b, shadow="T")
+            a.add(p + "self_attn.qkv.bias", (3 * E,), b, decay=False)
+            a.add(p + "self_attn.out_proj.weight", (E, E), b, shadow="T")
+            a.add(p + "self_attn.out_proj.bias", (E,), b, decay=False)
+            a.add(p + "final_layer_norm.weight", (E,), b, decay=False)
+            a.add(p + "final_layer_norm.bias", (E,), b, decay=False)
+            a.add(p + "fc1.weight", (Fd, E), b, shadow="T")
+            a.add(p + "fc1.bias", (Fd,), b, decay=False)
+            a.add(p + "fc2.weight", (E, Fd), b, shadow="T")
+            a.add(p + "fc2.bias", (E,), b, decay=False)
+        b = a.new_bucket("enc_out")
+        a.add(at + "layer_norm.weight", (E,), b, decay=False)
+        a.add(at + "layer_norm.bias", (E,), b, decay=False)
+        a.add(pj + "linear_1.weight", (H, E), b, shadow="T")
+        a.add(pj + "linear_1.bias", (H,), b, decay=False)
+        a.add(pj + "linear_2.weight", (H, H), b, shadow="T")
+        a.add(pj + "linear_2.bias", (H,), b, decay=False)
+        b = a.new_bucket("embed")
+        a.add(lm + "embed_tokens.weight", (V, H), b)
+        nq, nkv = self.Hq * self.D, self.Hkv * self.D
+        for i in range(self.dec_layers):
+            p = f"{lm}layers.{i}."
+            b = a.new_bucket(f"dec{i}")
+            a.add(p + "input_layernorm.weight", (H,), b, decay=False)
+            a.add(p + "self_attn.qkv.weight", (nq + 2 * nkv, H), b, shadow="T")
+            a.add(p + "self_attn.qkv.bias", (nq + 2 * nkv,), b, decay=False)
+            a.add(p + "self_attn.o_proj.weight", (H, nq), b, shadow="T")
+            a.add(p + "post_attention_layernorm.weight", (H,), b, decay=False)
+            a.add(p + "mlp.gate_up.weight", (2 * I, H), b, shadow="T")
+            a.add(p + "mlp.down_proj.weight", (H, I), b, shadow="T")
+        b = a.new_bucket("head")
+        a.add(lm + "norm.weight", (H,), b, decay=False)
+        a.add("lm_head.weight", (V, H), b, shadow="T")
+        a.finalize()
+
+        # ---------------- oracle-named parameters = views into the arena
+        self._prm = {}
+        def P(name, blk_key, rows=None):
+            blk = a[blk_key]
+            d, g = (blk.data, blk.grad) if rows is None else (blk.data[rows[0]: rows[1]], blk.grad[rows[0]: rows[1]])
+            prm = nn.Parameter(d)
+            prm.grad = g
+            self._prm[name] = prm
+            _attach(self, name, prm)
+
+        for k in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "layer_norm.weight", "layer_norm.bias"):
+            P(at + k, at + k)
+        # frozen sinusoid table (requires_grad False in the oracle, :332) lives outside the arena
+        pos_prm = nn.Parameter(torch.zeros((self.max_pos, E), device=self.device_, dtype=torch.bfloat16), requires_grad=False)
+        _attach(self, at + "embed_positions.weight", pos_prm)
+        self._prm[at + "embed_positions.weight"] = pos_prm
+        for i in range(self.enc_layers):
+            p = f"{at}layers.{i}."
+            P(p + "self_attn.q_proj.weight", p + "self_attn.qkv.weight", (0, E))
+            P(p + "self_attn.k_proj.weight", p + "self_attn.qkv.weight", (E, 2 * E))
+            P(p + "self_attn.v_proj.weight", p + "self_attn.qkv.weight", (2 * E, 3 * E))
+            P(p + "self_attn.q_proj.bias", p + "self_attn.qkv.bias", (0, E))
+            P(p + "self_attn.v_proj.bias", p + "self_attn.qkv.bias", (2 * E, 3 * E))
+            for k in ("self_attn.out_proj.weight", "self_attn.out_proj.bias", "self_attn_layer_norm.weight", "self_attn_layer_norm.bias",
+                      "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias", "final_layer_norm.weight", "final_layer_norm.bias"):
+                P(p + k, p + k)
+        for k in ("linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias"):
+            P(pj + k, pj + k)
+        P(lm + "embed_tokens.weight", lm + "embed_tokens.weight")
+        for i in range(self.dec_layers):
+            p = f"{lm}layers.{i}."
+            for nm, (s, e) in (("q_proj", (0, nq)), ("k_proj", (nq, nq + nkv)), ("v_proj", (nq + nkv, nq + 2 * nkv))):
+                P(p + f"self_attn.{nm}.weight", p + "self_attn.qkv.weight", (s, e))
+                P(p + f"self_attn.{nm}.bias", p + "self_attn.qkv.bias", (s, e))
+            P(p + "self_attn.o_proj.weight", p + "self_attn.o_proj.weight")
+            P(p + "mlp.gate_proj.weight", p + "mlp.gate_up.weight", (0, I))
+            P(p + "mlp.up_proj.weight", p + "mlp.gate_up.weight", (I, 2 * I))
+            P(p + "mlp.down_proj.weight", p + "mlp.down_proj.weight")
+            P(p + "input_layernorm.weight", p + "input_layernorm.weight")
+            P(p + "post_attention_layernorm.weight", p + "post_attention_layernorm.weight")
+        P(lm + "norm.weight", lm + "norm.weight")
+        P("lm_head.weight", "lm_head.weight")
+
+        self._at, self._pj, self._lm = at, pj, lm
+        self._rope_cache = {}
+        if init_seed is not None:
+            self.init_weights(init_seed)
+        self.training = True
+
+    # ------------------------------------------------------------------ init (oracle _init_weights: N(0, initializer_range), norms 1/0, biases 0)
+    @torch.no_grad()
+    def init_weights(self, seed: int = 0):
+        a = self.arena
+        std = float(getattr(self.config.audio_config, "initializer_range", 0.02))
+        a.init_normal_(std, seed)
+        for blk in a.order:
+            if blk.key.endswith("norm.weight"):
+                blk.data.fill_(1.0)
+            elif blk.key.endswith(".bias"):
+                blk.data.zero_()
+        g = torch.Generator(device=self.device_)
+        g.manual_seed(seed + 1)
+        self.embed_positions.data.copy_((torch.randn(self.embed_positions.shape, device=self.device_, generator=g) * std).to(torch.bfloat16))
+        a.step_counter += 1
+
+    def load_state_dict(self, sd, strict=True, assign=False):
+        r = super().load_state_dict({k: v.to(torch.bfloat16) for k, v in sd.items()}, strict=strict)
+        # the k-third of the fused encoder bias is not a parameter (k_proj has no bias): keep it zero
+        E = self.E
+        for i in range(self.enc_layers):
+            self.arena[f"{self._at}layers.{i}.self_attn.qkv.bias"].data[E: 2 * E].zero_()
+        self.arena.step_counter += 1  # invalidate W^T shadows
+        return r
+
+    def trainable_numel(self):
+        return sum(b.numel for b in self.arena.order)
+
+    # ------------------------------------------------------------------ helpers
+    def _rope_tables(self, S: int):
+        """Qwen2RotaryEmbedding.forward (modeling_qwen2.py:91-102): fp32 angles, cos/sin rounded to bf16"""
+        if S not in self._rope_cache:
+            D = self.D
+            inv = 1.0 / (self.rope_theta ** (torch.arange(0, D, 2, device=self.device_, dtype=torch.float32) / D))
+            fr = torch.arange(S, device=self.device_, dtype=torch.float32)[:, None] * inv[None, :]
+            emb = torch.cat([fr, fr], dim=-1)
+            self._rope_cache[S] = (emb.cos().to(torch.bfloat16).contiguous(), emb.sin().to(torch.bfloat16).contiguous())
+        return self._rope_cache[S]
+
+    def _require_hip(self):
+        if self.device_.type != "cuda" or not torch.cuda.is_available():
+            raise AfkError("audio_flamingo_amd: forward needs a HIP device (MI355X); this package has no CPU arithmetic path")
+
+    @property
+    def embed_positions(self):
+        return self._prm[self._at + "embed_positions.weight"]
+
+    def _anchor(self, key):
+        """a real nn.Parameter of the stage: makes the Function's output require grad (its own grad slot stays None)"""
+        return self._prm[key]
+
+    # ------------------------------------------------------------------ audio tower + projector (a2-a9)
+    def get_audio_features(self, input_features, input_features_mask=None):
+        """-> (audio_rows [W*T3, H] (all rows, padded windows included), tokens_per_window int64[W] or None)"""
+        self._require_hip()
+        a, at = self.arena, self._at
+        feats = input_features.contiguous()
+        if not feats.is_cuda:
+            raise AfkError("input_features must be on the HIP device")
+        if feats.dtype not in (torch.float32, torch.bfloat16):
+            feats = feats.float()
+        W, C, T = feats.shape
+        T2 = (T - 1) // 2 + 1
+        if T2 != self.max_pos:
+            raise AfkError(f"input_features must have {2 * self.max_pos} frames (got {T}); embed_positions add requires it (:385)")
+        kv_len, n_tok = None, None
+        if input_features_mask is not None:
+            L0 = input_features_mask.to(self.device_).sum(-1).to(torch.int64)
+            L1 = (L0 - 1) // 2 + 1
+            n_tok = (L1 - 2) // 2 + 1
+            kv_len = L1.to(torch.int32).contiguous()
+        x = F_.ConvStemFn.apply(feats, self._anchor(at + "conv1.weight"), a,
+                                (at + "conv1.weight", at + "conv1.bias", at + "conv2.weight", at + "conv2.bias"),
+                                self.embed_positions.data, W, T, C)
+        for i in range(self.enc_layers):
+            p = f"{at}layers.{i}."
+            x = F_.EncoderLayerFn.apply(x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len)
+        T3 = T2 // 2
+        x = F_.PoolNormFn.apply(x, self._anchor(at + "layer_norm.weight"), a, at + "layer_norm.weight", at + "layer_norm.bias", W * T3)
+        x = F_.ProjectorFn.apply(x, self._anchor(self._pj + "linear_1.weight"), a, self._pj)
+        return x, n_tok
+
+    # ------------------------------------------------------------------ forward (a10-a18)
+    def forward(self, input_ids=None, input_features=None, input_features_mask=None, attention_mask=None, position_ids=None,
+                past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, logits_to_keep=0, return_logits=None,
+                num_items_in_batch=None, **kwargs):
+        if inputs_embeds is not None or past_key_values is not None:
+            raise AfkError("inputs_embeds / past_key_values are not supported by the MI355X training path yet")
+        self._require_hip()
+        a, lm = self.arena, self._lm
+        ids = input_ids.to(self.device_)
+        B, S = ids.shape
+        ids_flat = ids.reshape(-1).contiguous()
+        audio, src = None, None
+        if input_features is not None:
+            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask)
+            src, cnt = ops.placeholder_scan(ids_flat, self.audio_token_id)
+            T3 = audio.shape[0] // input_features.shape[0]
+            if n_tok is not None:
+                # rank r among placeholders -> row (window, t) of the padded audio buffer  (:483-486 boolean index)
+                csum = torch.cumsum(n_tok, 0)
+                r = src.clamp_min(0).to(torch.int64)
+                win = torch.searchsorted(csum, r, right=True).clamp_max(n_tok.numel() - 1)
+                row = win * T3 + (r - (csum - n_tok)[win])
+                src = torch.where(src >= 0, row.to(torch.int32), src).contiguous()
+                expected = csum[-1]
+            else:
+                expected = audio.shape[0]
+            if self.check_placeholders:
+                n = int(cnt.item())
+                e = int(expected)
+                if n != e:
+                    raise ValueError(f"Audio features and audio tokens do not match, tokens: {n}, features: {e}")
+        kv_len = None
+        if attention_mask is not None:
+            am = attention_mask.to(self.device_)
+            if not bool(am.all()):
+                lens = am.sum(-1)
+                if not bool((am.cumsum(-1) == torch.minimum(torch.arange(1, S + 1, device=am.device)[None], lens[:, None])).all()):
+                    raise AfkError("only right-padded attention_mask is supported on the MI355X path")
+                kv_len = lens.to(torch.int32).contiguous()
+        pos = None
+        if position_ids is not None:
+            pos = position_ids.to(self.device_).expand(B, S).reshape(-1).to(torch.int32).contiguous()
+        cos, sin = self._rope_tables(S if pos is None else int(self.config.text_config.max_position_embeddings))
+        x = F_.EmbedScatterFn.apply(audio, self._anchor(lm + "embed_tokens.weight"), a, lm + "embed_tokens.weight", ids_flat, src)
+        audio_hidden = audio
+        for i in range(self.dec_layers):
+            p = f"{lm}layers.{i}."
+            x = F_.DecoderLayerFn.apply(x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
+                                        self.rms_eps, cos, sin, pos, kv_len)
+        x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
+        loss, logits = None, None
+        if labels is not None:
+            lab = labels.to(self.device_)
+            shift = torch.nn.functional.pad(lab, (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
+            if num_items_in_batch is not None:
+                denom = torch.as_tensor(num_items_in_batch, device=self.device_, dtype=torch.float32).reshape(1)
+            else:
+                denom = ops.count_valid(shift)
+            loss = F_.LMHeadLossFn.apply(x, self._anchor("lm_head.weight"), a, "lm_head.weight", shift, denom)
+        if labels is None or return_logits:
+            xs = x
+            if isinstance(logits_to_keep, int) and logits_to_keep > 0:
+                xs = x.reshape(B, S, -1)[:, -logits_to_keep:, :].reshape(-1, x.shape[-1]).contiguous()
+            lg = F_.LMHeadFn.apply(xs, self._anchor("lm_head.weight"), a, "lm_head.weight")
+            logits = lg.reshape(B, -1, self.V)
+        return AF3Output(loss=loss, logits=logits, audio_hidden_states=audio_hidden)
+
+    # ------------------------------------------------------------------ generate (greedy, prefix recompute)
+    @torch.no_grad()
+    def generate(self, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20,
+                 do_sample=False, eos_token_id=None, **kwargs):
+        if do_sample:
+            raise AfkError("only greedy decoding (do_sample=False) is implemented")
+        ids = input_ids.to(self.device_)
+        if ids.shape[0] != 1 and attention_mask is not None and not bool(attention_mask.all()):
+            raise AfkError("batched generate with padding is not supported")
+        audio_cache = None
+        for _ in range(max_new_tokens):
+            out = self.forward(input_ids=ids, input_features=input_features, input_features_mask=input_features_mask,
+                               logits_to_keep=1)
+            nxt = out.logits[:, -1, :].float().argmax(-1, keepdim=True)
+            ids = torch.cat([ids, nxt], dim=1)
+            if eos_token_id is not None and bool((nxt == eos_token_id).all()):
+                break
+        return ids
+
+    # gradient bookkeeping -------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()

@@ -184,6 +184,13 @@ def add(a, b, out=None):
     return out
 
 
+def scale_add_(x, y, scale_dev, *, accumulate=False):
+    """y = (accumulate ? y : 0) + scale_dev[0] * x  (scale on the device)"""
+    _lib.call("afk_scale_add_bf16", x.data_ptr(), y.data_ptr(), x.numel(), _chk(scale_dev, torch.float32).data_ptr(),
+              int(accumulate), _stream())
+    return y
+
+
 def cast_f32_bf16(x):
     out = torch.empty(x.shape, device=x.device, dtype=BF16)
     _lib.call("afk_cast_f32_bf16", _chk(x, torch.float32).data_ptr(), out.data_ptr(), x.numel(), _stream())

@@ -78,6 +78,8 @@ int afk_rope_inplace(void* buf, const void* cos_t, const void* sin_t, const int*
                      int nheads, int D, int backward, void* stream);
 int afk_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 int afk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
+/* y = (accumulate ? y : 0) + (*scale_dev) * x ; applies an upstream loss gradient held on the device without a host sync */
+int afk_scale_add_bf16(const void* x, void* y, int64_t n, const float* scale_dev, int accumulate, void* stream);
 /* out[r] (+)= sum_c in[r][c] : bias gradient from the transposed output-gradient */
 int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int accumulate, void* stream);
 

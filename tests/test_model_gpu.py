@@ -1,0 +1,163 @@
+"""Model-level parity on MI355X: the HIP path (through the C ABI) against the golden vectors produced by the live
+reference implementation and against the CPU oracle restatement on the same seeded inputs.
+
+Tolerances (north_star: "token indices bit-exact, logits within a stated fp tolerance"):
+  * reference = fp32 CPU on bf16-rounded weights; ours = bf16 storage / fp32 accumulate.
+  * loss: |d| <= 1e-2;  logits: max |d| <= 4e-2 (logit scale ~1) ; audio features: rel-L2 <= 2e-2
+  * greedy token ids: equal wherever the reference's top-1/top-2 gap exceeds 2x the logit tolerance; generate() ids equal
+  * gradients: relative L2 error per tensor <= 6e-2 (bf16 gradient storage, eps 2^-8 per element)
+"""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+LOGIT_TOL = 4e-2
+REPORT = {}
+
+
+def _cfg():
+    from transformers import AudioFlamingo3Config
+    from tests.test_host_cpu import TINY
+
+    return AudioFlamingo3Config(**TINY)
+
+
+def _model(dev):
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    m = Mine(_cfg(), device=dev)
+    m.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    return m
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def _dump():
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "model_parity_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)
+
+
+@pytest.mark.parametrize("case", ["A", "B"])
+def test_forward_backward_vs_reference_golden(dev, case):
+    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
+    m = _model(dev)
+    m.zero_grad()
+    att = g["att"].to(dev) if case == "B" else None
+    out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+            attention_mask=att, labels=g["labels"].to(dev), return_logits=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    rep = {"loss": float(out.loss), "loss_ref": float(g["loss"])}
+    sel = g["labels"] != -100
+    lg = out.logits.float().cpu()
+    ref = g["logits_bf16"].float()
+    rep["logits_max_err"] = float((lg[sel] - ref).abs().max())
+    rep["logits_ref_absmax"] = float(ref.abs().max())
+    keep = g["att"].bool()
+    confident = (g["top_gap"] > 2 * LOGIT_TOL) & keep
+    am = lg.argmax(-1)
+    rep["argmax_mismatch_confident"] = int((am[confident] != g["argmax"][confident]).sum())
+    rep["argmax_mismatch_all_valid"] = int((am[keep] != g["argmax"][keep]).sum())
+    rep["n_confident"] = int(confident.sum())
+    # audio rows: compare the rows the placeholders consume
+    n_tok = ((g["fmask"].sum(-1) - 1) // 2 + 1 - 2) // 2 + 1
+    rows = torch.cat([out.audio_hidden_states.float().cpu()[w * 750: w * 750 + int(n)] for w, n in enumerate(n_tok)])
+    rep["audio_rel_l2"] = _rel(rows, g["audio_bf16"])
+    params = dict(m.named_parameters())
+    rep["grad_rel_l2"] = {k: _rel(params[k].grad, v) for k, v in g["grads"].items()}
+    rep["grad_norm_ratio"] = {k: float(params[k].grad.float().norm()) / max(g["grad_norms"][k], 1e-12) for k in g["grads"]}
+    REPORT[f"case{case}"] = rep
+    _dump()
+    assert abs(rep["loss"] - rep["loss_ref"]) <= 1e-2, rep
+    assert rep["logits_max_err"] <= LOGIT_TOL, rep
+    assert rep["argmax_mismatch_confident"] == 0, rep
+    assert rep["audio_rel_l2"] <= 2e-2, rep
+    bad = {k: v for k, v in rep["grad_rel_l2"].items() if v > 6e-2}
+    assert not bad, rep
+
+
+def test_against_cpu_oracle_fresh_inputs(dev):
+    """same comparison against the oracle restatement on inputs that are not in the fixtures (ragged: 3 windows, 2 samples)"""
+    from oracle import af3_oracle as O
+
+    torch.manual_seed(5)
+    sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
+    m = _model(dev)
+    feats = (torch.randn(3, 128, 3000) * 0.5).to(torch.bfloat16)
+    fmask = torch.ones(3, 3000, dtype=torch.int32)
+    fmask[1, 1000:] = 0  # 1000 frames -> 250 tokens
+    n_tok = [750, 250, 750]
+    S = 4 + 1000 + 12
+    ids = torch.randint(0, 1000, (2, S))
+    ids[0, 4:1004] = 1023          # sample 0: windows 0 and 1 (1000 placeholders)
+    ids[1, 2:752] = 1023           # sample 1: window 2
+    labels = torch.full((2, S), -100)
+    labels[:, -12:] = ids[:, -12:]
+    with torch.no_grad():
+        ref = O.forward({k: v.float() for k, v in sd.items()}, dict(enc_heads=4, heads=4, kv_heads=2, eps=1e-6, theta=10000.0, audio_token_id=1023),
+                        ids, feats.float(), fmask.long(), labels=labels)
+    out = m(input_ids=ids.to(dev), input_features=feats.to(dev), input_features_mask=fmask.to(dev), labels=labels.to(dev), return_logits=True)
+    torch.cuda.synchronize()
+    err = float((out.logits.float().cpu() - ref["logits"]).abs().max())
+    REPORT["oracle_ragged"] = {"loss": float(out.loss), "loss_ref": float(ref["loss"]), "logits_max_err": err}
+    _dump()
+    assert abs(float(out.loss) - float(ref["loss"])) <= 1e-2 and err <= LOGIT_TOL, REPORT["oracle_ragged"]
+    with pytest.raises(ValueError, match="do not match"):
+        bad = ids.clone()
+        bad[1, 0] = 1023
+        m(input_ids=bad.to(dev), input_features=feats.to(dev), input_features_mask=fmask.to(dev))
+
+
+def test_generate_greedy_ids_bit_exact(dev):
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    ids = m.generate(g["ids"][:1].to(dev), input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=4)
+    assert ids.cpu().tolist() == g["generate"].tolist()
+
+
+def test_grad_accumulation_and_optimizer_step(dev):
+    from audio_flamingo_amd.arena import FusedAdamW
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    m.zero_grad()
+    m(**kw).loss.backward()
+    g1 = m.arena.grads.float().clone()
+    m(**kw).loss.backward()  # second micro-batch accumulates
+    g2 = m.arena.grads.float()
+    rel = float((g2 - 2 * g1).norm() / (2 * g1).norm())
+    assert rel < 2e-2, rel
+    # scaled upstream gradient (loss / 2)
+    m.zero_grad()
+    (m(**kw).loss * 0.5).backward()
+    rel = float((m.arena.grads.float() - 0.5 * g1).norm() / (0.5 * g1).norm())
+    assert rel < 2e-2, rel
+    # a few optimizer steps reduce the loss on the fixed batch
+    opt = FusedAdamW(m.arena, lr=2e-3)
+    losses = []
+    for _ in range(4):
+        m.zero_grad()
+        out = m(**kw)
+        out.loss.backward()
+        opt.step()
+        losses.append(float(out.loss))
+    REPORT["train_losses"] = losses
+    _dump()
+    assert losses[-1] < losses[0] - 0.05, losses
+
+
+def test_smoke_entry(dev):
+    import __graft_entry__ as ge
+
+    ge.smoke()
