@@ -341,7 +341,7 @@ class LMHeadLossFn(torch.autograd.Function):
         blk = arena[wkey]
         V = blk.shape[0]
         dev = x.device
-        need_grad = torch.is_grad_enabled()
+        need_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])  # grad mode is off inside forward()
         row_loss = torch.empty(M, device=dev, dtype=torch.float32)
         dx = torch.empty_like(x) if need_grad else None
         chunk = min(LMHeadLossFn.CHUNK, M)
