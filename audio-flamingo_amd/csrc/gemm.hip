@@ -18,8 +18,7 @@
 // M row: 8-byte bf16 stores, and bias / residual loads of the same shape.
 // Workgroup ids are remapped XCD-contiguously and walk the tile space in 8-row groups so that the
 // 64 tiles resident on one XCD share 8 A panels and 8 B panels through that XCD's L2.
-#include "common.h"
-#include "../../include/afk.h"
+#include "gemm_common.h"
 #include <vector>
 #include <mutex>
 
@@ -30,24 +29,6 @@ constexpr int ROWB = BK * 2;                   // 128 bytes per LDS row
 constexpr int STAGE_BYTES = (BM + BN) * ROWB;  // 32 KiB
 constexpr int NSTAGE = 2;
 
-struct GemmArgs {
-    const bf16* A;
-    const bf16* B;
-    void* C;
-    void* C2;  // optional second output: pre-activation (bf16) when AFK_GEMM_GELU is set
-    const bf16* bias;
-    const bf16* R;
-    int64_t lda, ldb, ldc, ldr;
-    int M, N, K;
-    int ntm, ntn;
-    int flags;
-    int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
-    float alpha;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -56,20 +37,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
 
-    // ---- workgroup -> tile: XCD-contiguous (bijective) then grouped along M
     int tm, tn;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        constexpr int GM = 8;
-        const int per_group = GM * p.ntn;
-        const int g = swz / per_group, rem = swz - g * per_group;
-        const int first_m = g * GM;
-        const int gsz = min(p.ntm - first_m, GM);
-        tm = first_m + rem % gsz;
-        tn = rem / gsz;
-    }
+    gemm_tile_of_block(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-lane LDS-DMA source pointers: unit u covers LDS rows [8u, 8u+8) of the tile, 1 KiB
@@ -145,7 +114,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
     }
 
     // ---- epilogue. lane holds m = ..+l31 and n = ..+8q+4hi+{0..3} for q = 0..3 (regs 4q..4q+3)
-    const int flags = p.flags;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + l31;
@@ -158,55 +126,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-                if (flags & AFK_GEMM_BIAS) {
-                    const bf16x4 bv = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
-                }
-                if (flags & AFK_GEMM_GELU) {
-                    // oracle applies GELU to the bf16-rounded Linear output
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
-                    if (p.C2) {
-                        bf16x4 pre;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pre[e] = (bf16)v[e];
-                        *(bf16x4*)((bf16*)p.C2 + (int64_t)m * p.ldc + n) = pre;
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-                }
-                if (flags & AFK_GEMM_RESIDUAL) {
-                    const int rm = p.res_mod > 0 ? m % p.res_mod : m;
-                    const bf16x4 rv = *(const bf16x4*)(p.R + (int64_t)rm * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + (float)rv[e];
-                }
-                if (flags & AFK_GEMM_OUT_F32) {
-                    float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                    f32x4 o;
-                    if (flags & AFK_GEMM_ACCUM) {
-                        o = *(const f32x4*)cp;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += v[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = v[e];
-                    }
-                    *(f32x4*)cp = o;
-                } else {
-                    bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
-                    if (flags & AFK_GEMM_ACCUM) {
-                        const bf16x4 old = *(const bf16x4*)cp;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                    *(bf16x4*)cp = o;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                gemm_epilogue_store4(p, m, n, v);
             }
         }
     }
@@ -222,6 +143,7 @@ struct ProfState {
     int64_t launches = 0;
 };
 ProfState g_prof;
+int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256
 
 hipEvent_t prof_next_event() {
     if (g_prof.used == g_prof.pool.size()) {
@@ -233,6 +155,12 @@ hipEvent_t prof_next_event() {
 }
 
 }  // namespace
+
+extern "C" int afk_gemm_set_variant(int v) {
+    AFK_REQUIRE(v >= 0 && v <= 2, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
+    g_variant = v;
+    return AFK_OK;
+}
 
 extern "C" int afk_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -290,11 +218,14 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     p.M = M;
     p.N = N;
     p.K = K;
-    p.ntm = (int)afk_cdiv(M, BM);
-    p.ntn = (int)afk_cdiv(N, BN);
     p.flags = flags;
     p.res_mod = res_mod;
     p.alpha = alpha;
+    // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
+    const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
+    const bool use256 = g_variant == 2 || (g_variant == 0 && tiles256 >= 192);
+    p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
+    p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_nt_bf16_k128, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
@@ -316,7 +247,11 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
         }
     }
     if (prof) hipEventRecord(e0, st);
-    hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg), dim3(256), NSTAGE * STAGE_BYTES, st, p);
+    if (use256) {
+        if (int e = afk_launch_gemm256(p, st)) return e;
+    } else {
+        hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg), dim3(256), NSTAGE * STAGE_BYTES, st, p);
+    }
     if (prof) hipEventRecord(e1, st);
     AFK_LAUNCH_CHECK("afk_gemm_nt_bf16");
     return AFK_OK;

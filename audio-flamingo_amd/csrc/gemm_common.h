@@ -1,0 +1,96 @@
+// Shared pieces of the NT GEMM kernels (argument block, tile->workgroup mapping, fused epilogue).
+#pragma once
+#include "common.h"
+#include "../../include/afk.h"
+
+struct GemmArgs {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    void* C2;  // optional second output: pre-activation (bf16) when AFK_GEMM_GELU is set
+    const bf16* bias;
+    const bf16* R;
+    int64_t lda, ldb, ldc, ldr;
+    int M, N, K;
+    int ntm, ntn;
+    int flags;
+    int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
+    float alpha;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+// workgroup -> tile: XCD-contiguous (bijective remap of the round-robin dispatch) then grouped along M so that
+// the tiles resident on one XCD share A and B panels through that XCD's private L2.
+__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, int& tn) {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GM = 8;
+    const int per_group = GM * p.ntn;
+    const int g = swz / per_group, rem = swz - g * per_group;
+    const int first_m = g * GM;
+    const int gsz = min(p.ntm - first_m, GM);
+    tm = first_m + rem % gsz;
+    tn = rem / gsz;
+}
+
+// epilogue for 4 consecutive n of one row m (values already hold the fp32 accumulators)
+// order: *alpha, +bias[n] -> (round bf16, write preact, GELU-erf) -> (round bf16, +residual) -> (+C if ACCUM) -> store
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, int n, float v[4]) {
+    const int flags = p.flags;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    if (flags & AFK_GEMM_BIAS) {
+        const bf16x4 bv = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+    }
+    if (flags & AFK_GEMM_GELU) {
+        // oracle applies GELU to the bf16-rounded Linear output
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+        if (p.C2) {
+            bf16x4 pre;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[e] = (bf16)v[e];
+            *(bf16x4*)((bf16*)p.C2 + (int64_t)m * p.ldc + n) = pre;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+    }
+    if (flags & AFK_GEMM_RESIDUAL) {
+        const int rm = p.res_mod > 0 ? m % p.res_mod : m;
+        const bf16x4 rv = *(const bf16x4*)(p.R + (int64_t)rm * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + (float)rv[e];
+    }
+    if (flags & AFK_GEMM_OUT_F32) {
+        float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+        f32x4 o;
+        if (flags & AFK_GEMM_ACCUM) {
+            o = *(const f32x4*)cp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e];
+        }
+        *(f32x4*)cp = o;
+    } else {
+        bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
+        if (flags & AFK_GEMM_ACCUM) {
+            const bf16x4 old = *(const bf16x4*)cp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        *(bf16x4*)cp = o;
+    }
+}
+
+// 256x256 ping-pong kernel (gemm256.hip)
+int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);

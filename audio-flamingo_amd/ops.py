@@ -344,6 +344,11 @@ def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay
               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
 
 
+def gemm_set_variant(v: int):
+    """0 auto, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel (tests / microbenchmarks)"""
+    _lib.call("afk_gemm_set_variant", int(v))
+
+
 # ---------------------------------------------------------------------------------------------- profiling
 def prof_enable(on: bool):
     _lib.call("afk_prof_enable", int(on))

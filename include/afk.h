@@ -38,6 +38,8 @@ int afk_prof_collect(double* host_total_ms, double* host_total_flops, int64_t* h
  * residual row index is m, or m % res_mod when res_mod > 0 (broadcast table: embed_positions add, :385).
  * epilogue order: +bias[n] -> (round bf16, write preact_out, GELU-erf) -> (round bf16, +residual[m,n]) -> (+C if ACCUM)
  */
+/* kernel variant override for tests/benchmarks: 0 auto (by tile count), 1 = 128x128x64 kernel, 2 = 256x256x64 ping-pong kernel */
+int afk_gemm_set_variant(int variant);
 #define AFK_GEMM_BIAS 1
 #define AFK_GEMM_GELU 2
 #define AFK_GEMM_RESIDUAL 4

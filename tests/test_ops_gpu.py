@@ -47,6 +47,27 @@ def test_gemm_plain(dev, M, N, K):
     _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 260, 320), (1000, 1280, 1280), (8, 512, 4096),
+                                   (777, 1028, 64), (2048, 256, 2048)])
+def test_gemm_variants(dev, variant, M, N, K):
+    """both kernels on every edge shape: K-tiles 1/2/3/many (prologue + tail waits), M/N tails, tiny M"""
+    ops = _ops()
+    ops.gemm_set_variant(variant)
+    try:
+        a = _rand((M, K), dev, seed=11).to(BF)
+        b = _rand((N, K), dev, seed=12).to(BF)
+        bias = _rand((N,), dev, seed=13).to(BF)
+        c = ops.gemm_nt(a, b, bias=bias)
+        ref = a.float() @ b.float().t() + bias.float()
+        _cmp(f"gemm v{variant} {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
+        # repeat to shake out races between the LDS-DMA ring and the fragment reads: results must be bit-identical
+        for _ in range(3):
+            assert torch.equal(ops.gemm_nt(a, b, bias=bias), c), "non-deterministic GEMM result (LDS race?)"
+    finally:
+        ops.gemm_set_variant(0)
+
+
 def test_gemm_identity_layout(dev):
     """A = I pattern with asymmetric B: output must equal B^T rows exactly (detects transposed C writes)."""
     ops = _ops()

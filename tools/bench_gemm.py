@@ -1,0 +1,36 @@
+"""GEMM microbenchmark on the AF3-7B shapes (random data, guide rule 25): both kernel variants, HIP-event timed through afk_prof_*."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from audio_flamingo_amd import ops
+
+SHAPES = [  # (name, M, N, K)
+    ("dec gate_up fwd", 8192, 37888, 3584), ("dec down fwd", 8192, 3584, 18944), ("dec qkv fwd", 8192, 4608, 3584), ("dec o fwd", 8192, 3584, 3584),
+    ("dec gate_up wgrad", 37888, 3584, 8192), ("dec down wgrad", 3584, 18944, 8192), ("dec gate_up dgrad", 8192, 3584, 37888),
+    ("lm_head chunk", 2048, 152064, 3584), ("lm_head dgrad", 2048, 3584, 152064), ("lm_head wgrad", 152064, 3584, 2048),
+    ("enc qkv fwd", 12000, 3840, 1280), ("enc fc1 fwd", 12000, 5120, 1280), ("enc fc2 fwd", 12000, 1280, 5120), ("enc out fwd", 12000, 1280, 1280),
+    ("enc fc1 wgrad", 5120, 1280, 12032), ("enc qkv wgrad", 3840, 1280, 12032), ("enc out wgrad", 1280, 1280, 12032),
+    ("square 4096", 4096, 4096, 4096), ("square 8192", 8192, 8192, 8192),
+]
+dev = torch.device("cuda")
+res = []
+for name, M, N, K in SHAPES:
+    a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
+    b = (torch.rand((N, K), device=dev) * 2 - 1).to(torch.bfloat16)
+    c = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    row = {"name": name, "M": M, "N": N, "K": K}
+    for v in (1, 2):
+        ops.gemm_set_variant(v)
+        for _ in range(2):
+            ops.gemm_nt(a, b, out=c)
+        torch.cuda.synchronize()
+        ops.prof_reset(); ops.prof_enable(True)
+        for _ in range(5):
+            ops.gemm_nt(a, b, out=c)
+        ops.prof_enable(False)
+        ms, fl, n = ops.prof_collect()
+        row[f"v{v}_tflops"] = round(fl / ms / 1e9, 1)
+        row[f"v{v}_us"] = round(1e3 * ms / n, 1)
+    ops.gemm_set_variant(0)
+    res.append(row)
+    print(json.dumps(row), flush=True)
