@@ -1,0 +1,528 @@
+// Flash attention v2 for gfx950: LDS-staged K/V (forward, dQ) and Q/dO (dK/dV) tiles, transposed MFMA operands taken
+// straight from the row-major LDS image with ds_read_b64_tr_b16 - no transposed copies in HBM at all.
+//
+// Same math / register dataflow as attention.hip (see its header): S^T = K.Q^T with the probabilities landing in the
+// k-operand layout of the next MFMA.  What changes is where the streamed operand comes from:
+//   * a 256-thread block (4 waves x 32 rows) shares each 64-row tile of the streamed tensors through LDS, filled by
+//     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction), double buffered, one barrier per tile;
+//   * row fragments (K, V, Q, dO as "row x 8 consecutive d") are ds_read_b128;
+//   * transposed fragments (V^T for P.V, K^T for dS.K, dO^T for P^T.dO, Q^T for dS^T.Q: "d x 8 keys") are two
+//     ds_read_b64_tr_b16 each: within a 16-lane group lane i receives column i of the 4x16 block whose rows the lanes
+//     address (semantics probed on hardware: profiles/r01_probe_ds_read_b64_tr_b16.txt).  The two reads fetch keys
+//     {16s+4hi+0..3} and {16s+8+4hi+0..3} - exactly the keys a lane's probability registers 8s..8s+7 belong to.
+// LDS image: [64 rows][D] bf16, 16-byte chunk c of row r stored at c ^ f(r) with
+//     D=128 (16 chunks, row = one 256-B bank row): f = ((r&3)<<2) | ((r>>2)&3)
+//     D=64  ( 8 chunks, two rows per bank row):    f = (((r>>1)&1)<<2) | ((r>>2)&3)
+// which makes BOTH access patterns conflict-free: a ds_read_b128 lane group sees 16 distinct slots, and the four rows
+// of a tr-read block land in four different 64-byte windows.  (The permutation is applied to the LDS-DMA source
+// address, the destination stays lane-linear.)
+#include "common.h"
+#include "../../include/afk.h"
+
+namespace {
+
+struct AttnArgs2 {
+    const bf16* Q; int64_t q_bs, q_hs, q_rs;
+    const bf16* K; int64_t k_bs, k_hs, k_rs;
+    const bf16* V; int64_t v_bs, v_hs, v_rs;
+    bf16* O; int64_t o_bs, o_hs, o_rs;
+    const bf16* dO; int64_t do_bs, do_hs, do_rs;
+    bf16* dQ; int64_t dq_bs, dq_hs, dq_rs;
+    bf16* dK; int64_t dk_bs, dk_hs, dk_rs;
+    bf16* dV; int64_t dv_bs, dv_hs, dv_rs;
+    float* LSE;          // [B, Hq, Spad]
+    const float* delta;  // [B, Hq, Spad]
+    const int* kv_len;
+    int B, Hq, Hkv, S, Spad;
+    float scale;
+    int causal;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+constexpr float NEG_INF = -INFINITY;
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define ROW_OF(r, hi) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hi))
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+template <int D>
+__device__ __forceinline__ int swz(int r) {
+    if (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
+    return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+}
+
+template <int D>
+struct Tile {
+    static constexpr int RS = 2 * D;             // row stride, bytes
+    static constexpr int BYTES = 64 * RS;        // one 64-row image
+    static constexpr int UNITS = BYTES / 1024;   // LDS-DMA pieces per image (16 / 8)
+    static constexpr int RPU = 1024 / RS;        // rows per piece (4 / 8)
+    static constexpr int CPR = RS / 16;          // 16-byte chunks per row (16 / 8)
+    static constexpr int KS = D / 16, DT = D / 32;
+
+    // stage rows [row0, row0+64) of a [rows][D] tensor (row stride rs elements) into the image at `img`
+    static __device__ __forceinline__ void stage(char* img, const bf16* base, int64_t rs, int row0, int max_row, int wave, int lane) {
+        const int lrow = lane / CPR, pos = lane % CPR;
+#pragma unroll
+        for (int u0 = 0; u0 < UNITS / 4; ++u0) {
+            const int u = wave + 4 * u0;
+            const int r = u * RPU + lrow;
+            const int chunk = pos ^ swz<D>(r);
+            const int gr = min(row0 + r, max_row);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(base + (int64_t)gr * rs + chunk * 8), (lds_void*)(img + u * 1024), 16, 0, 0);
+        }
+    }
+    // row fragment: row r (0..63), d = 16*ks + 8*hi .. +8
+    static __device__ __forceinline__ bf16x8 row_frag(const char* img, int r, int ks, int hi) {
+        return *(const bf16x8*)(img + r * RS + (((2 * ks + hi) ^ swz<D>(r)) << 4));
+    }
+    // transposed fragment: lane holds d = 32*dt + (lane&31), rows (keys) {16*s4 + 4hi + 0..3, 16*s4 + 8 + 4hi + 0..3}
+    static __device__ __forceinline__ bf16x8 tr_frag(const char* img, int dt, int s4, int lane) {
+        const int g = lane >> 4, i = lane & 15, hi = g >> 1;
+        const int chunk = 4 * dt + 2 * (g & 1) + ((i & 3) >> 1);
+        const int r0 = 16 * s4 + 4 * hi + (i >> 2);
+        const int r1 = r0 + 8;
+        const char* p0 = img + r0 * RS + ((chunk ^ swz<D>(r0)) << 4) + 8 * (i & 1);
+        const char* p1 = img + r1 * RS + ((chunk ^ swz<D>(r1)) << 4) + 8 * (i & 1);
+        const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
+        const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+        bf16x8 v;
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        return v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
+    using T = Tile<D>;
+    constexpr int KS = T::KS, DT = T::DT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][K image | V image]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+    const int qb0 = blockIdx.x * 128;
+    const int q0 = qb0 + wave * 32;
+    const int q = q0 + l31;
+    const int qc = min(q, p.S - 1);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const bool wave_live = q0 < p.S;
+
+    const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+
+    const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
+    const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
+    float m = NEG_INF, l = 0.f;
+
+    const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;
+    const int ntiles = (kv_end_blk + 63) >> 6;
+    const int kv_end = p.causal ? min(kv_len, q0 + 32) : kv_len;  // this wave's horizon
+
+    auto stage = [&](int j) {
+        char* buf = smem + (j & 1) * 2 * T::BYTES;
+        T::stage(buf, Kbase, p.k_rs, j * 64, p.S - 1, wave, lane);
+        T::stage(buf + T::BYTES, Vbase, p.v_rs, j * 64, p.S - 1, wave, lane);
+    };
+    if (ntiles > 0) stage(0);
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) stage(j + 1);
+        const char* kimg = smem + (j & 1) * 2 * T::BYTES;
+        const char* vimg = kimg + T::BYTES;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            const int key0 = j * 64 + kt2 * 32;
+            if (wave_live && key0 < kv_end) {  // wave-uniform
+                f32x16 st = zero16();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) st = MFMA(T::row_frag(kimg, kt2 * 32 + l31, ks, hi), qf[ks], st);
+                float s[16];
+                float mx = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + ROW_OF(r, hi);
+                    const bool dead = (key >= kv_len) || (p.causal && key > q);
+                    s[r] = dead ? NEG_INF : st[r] * p.scale;
+                    mx = fmaxf(mx, s[r]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m, mx);
+                const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
+                const float alpha = __expf(m - m_use);
+                float rs = 0.f;
+                bf16x8 pb[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __expf(s[r] - m_use);
+                    rs += pv;
+                    pb[r >> 3][r & 7] = (bf16)pv;
+                }
+                rs += __shfl_xor(rs, 32, 64);
+                l = l * alpha + rs;
+                m = m_new;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = MFMA(T::tr_frag(vimg, dt, 2 * kt2 + s2, lane), pb[s2], oacc[dt]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (q < p.S) {
+        const float inv = (l > 0.f) ? 1.f / l : 0.f;
+        bf16* Op = p.O + b * p.o_bs + h * p.o_hs + (int64_t)q * p.o_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[dt][4 * qd + e] * inv);
+                *(bf16x4*)(Op + dt * 32 + 8 * qd + 4 * hi) = o;
+            }
+        if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? m + __logf(l) : NEG_INF;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dQ
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
+    using T = Tile<D>;
+    constexpr int KS = T::KS, DT = T::DT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+    const int qb0 = blockIdx.x * 128;
+    const int q0 = qb0 + wave * 32;
+    const int q = q0 + l31;
+    const int qc = min(q, p.S - 1);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const bool wave_live = q0 < p.S;
+
+    const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
+    const bf16* dOp = p.dO + b * p.do_bs + h * p.do_hs + (int64_t)qc * p.do_rs + hi * 8;
+    bf16x8 qf[KS], dof[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+        dof[ks] = *(const bf16x8*)(dOp + ks * 16);
+    }
+    const float lse = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];
+    const float dlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];
+    const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
+    const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
+
+    f32x16 dqacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) dqacc[dt] = zero16();
+
+    const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;
+    const int ntiles = (kv_end_blk + 63) >> 6;
+    const int kv_end = p.causal ? min(kv_len, q0 + 32) : kv_len;
+
+    auto stage = [&](int j) {
+        char* buf = smem + (j & 1) * 2 * T::BYTES;
+        T::stage(buf, Kbase, p.k_rs, j * 64, p.S - 1, wave, lane);
+        T::stage(buf + T::BYTES, Vbase, p.v_rs, j * 64, p.S - 1, wave, lane);
+    };
+    if (ntiles > 0) stage(0);
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) stage(j + 1);
+        const char* kimg = smem + (j & 1) * 2 * T::BYTES;
+        const char* vimg = kimg + T::BYTES;
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2) {
+            const int key0 = j * 64 + kt2 * 32;
+            if (wave_live && key0 < kv_end) {
+                f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    st = MFMA(T::row_frag(kimg, kt2 * 32 + l31, ks, hi), qf[ks], st);
+                    dp = MFMA(T::row_frag(vimg, kt2 * 32 + l31, ks, hi), dof[ks], dp);
+                }
+                bf16x8 dsb[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + ROW_OF(r, hi);
+                    const bool dead = (key >= kv_len) || (p.causal && key > q);
+                    const float pv = dead ? 0.f : __expf(st[r] * p.scale - lse);
+                    dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - dlt) * p.scale);
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) dqacc[dt] = MFMA(T::tr_frag(kimg, dt, 2 * kt2 + s2, lane), dsb[s2], dqacc[dt]);
+            }
+        }
+        __syncthreads();
+    }
+    if (q < p.S) {
+        bf16* dQp = p.dQ + b * p.dq_bs + h * p.dq_hs + (int64_t)q * p.dq_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)dqacc[dt][4 * qd + e];
+                *(bf16x4*)(dQp + dt * 32 + 8 * qd + 4 * hi) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward: dK, dV
+// block = 128 keys of one kv head (wave = 32 keys); streams 64-query tiles of Q and dO of every head of the GQA group.
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) {
+    using T = Tile<D>;
+    constexpr int KS = T::KS, DT = T::DT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][Q image | dO image]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, hk = blockIdx.y, group = p.Hq / p.Hkv;
+    const int kb0 = blockIdx.x * 128;
+    const int key0 = kb0 + wave * 32;
+    const int key = key0 + l31;
+    const int keyc = min(key, p.S - 1);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const bool wave_live = key0 < p.S;
+    const bool key_dead = key >= kv_len;
+
+    const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
+    const bf16* Vp = p.V + b * p.v_bs + hk * p.v_hs + (int64_t)keyc * p.v_rs + hi * 8;
+
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        dkacc[dt] = zero16();
+        dvacc[dt] = zero16();
+    }
+    const int qt_begin = p.causal ? (kb0 >> 6) : 0;  // block-uniform first 64-query tile
+    const int qt_end = (p.S + 63) >> 6;
+    const int per_head = qt_end - qt_begin;
+    const int ntiles = per_head * group;
+
+    auto stage = [&](int t) {
+        const int g = t / per_head, qt = qt_begin + (t - g * per_head);
+        const int h = hk * group + g;
+        char* buf = smem + (t & 1) * 2 * T::BYTES;
+        T::stage(buf, p.Q + b * p.q_bs + h * p.q_hs, p.q_rs, qt * 64, p.S - 1, wave, lane);
+        T::stage(buf + T::BYTES, p.dO + b * p.do_bs + h * p.do_hs, p.do_rs, qt * 64, p.S - 1, wave, lane);
+    };
+    if (ntiles > 0) stage(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage(t + 1);
+        const int g = t / per_head, qt = qt_begin + (t - g * per_head);
+        const int h = hk * group + g;
+        const char* qimg = smem + (t & 1) * 2 * T::BYTES;
+        const char* doimg = qimg + T::BYTES;
+        const float* lse = p.LSE + ((int64_t)b * p.Hq + h) * p.Spad;
+        const float* dlt = p.delta + ((int64_t)b * p.Hq + h) * p.Spad;
+#pragma unroll
+        for (int qt2 = 0; qt2 < 2; ++qt2) {
+            const int qt0 = qt * 64 + qt2 * 32;
+            // causal: a 32-query half entirely before this wave's keys contributes nothing
+            if (wave_live && qt0 < p.S && !(p.causal && qt0 + 31 < key0)) {
+                f32x16 st = zero16(), dp = zero16();
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    st = MFMA(T::row_frag(qimg, qt2 * 32 + l31, ks, hi), *(const bf16x8*)(Kp + ks * 16), st);
+                    dp = MFMA(T::row_frag(doimg, qt2 * 32 + l31, ks, hi), *(const bf16x8*)(Vp + ks * 16), dp);
+                }
+                bf16x8 pb[2], dsb[2];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int qq0 = qt0 + 8 * qd + 4 * hi;  // 4 consecutive queries, inside [0, Spad)
+                    const f32x4 l4 = *(const f32x4*)(lse + qq0);
+                    const f32x4 d4 = *(const f32x4*)(dlt + qq0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * qd + e;
+                        const int qq = qq0 + e;
+                        const bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
+                        const float pv = dead ? 0.f : __expf(st[r] * p.scale - l4[e]);
+                        pb[r >> 3][r & 7] = (bf16)pv;
+                        dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - d4[e]) * p.scale);
+                    }
+                }
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        dvacc[dt] = MFMA(T::tr_frag(doimg, dt, 2 * qt2 + s2, lane), pb[s2], dvacc[dt]);
+                        dkacc[dt] = MFMA(T::tr_frag(qimg, dt, 2 * qt2 + s2, lane), dsb[s2], dkacc[dt]);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    if (key < p.S) {
+        bf16* dKp = p.dK + b * p.dk_bs + hk * p.dk_hs + (int64_t)key * p.dk_rs;
+        bf16* dVp = p.dV + b * p.dv_bs + hk * p.dv_hs + (int64_t)key * p.dv_rs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                bf16x4 ok, ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ok[e] = (bf16)dkacc[dt][4 * qd + e];
+                    ov[e] = (bf16)dvacc[dt][4 * qd + e];
+                }
+                *(bf16x4*)(dKp + dt * 32 + 8 * qd + 4 * hi) = ok;
+                *(bf16x4*)(dVp + dt * 32 + 8 * qd + 4 * hi) = ov;
+            }
+    }
+}
+
+// delta[b,h,s] = sum_d dO*O  written with row pitch Spad
+template <int D>
+__global__ __launch_bounds__(256) void attn2_delta_kernel(const bf16* __restrict__ O, int64_t o_bs, int64_t o_hs, int64_t o_rs,
+                                                          const bf16* __restrict__ dO, int64_t do_bs, int64_t do_hs, int64_t do_rs,
+                                                          float* __restrict__ delta, int B, int H, int S, int Spad) {
+    constexpr int LPR = D / 8, IPB = 256 / LPR;
+    const int64_t total = (int64_t)B * H * S;
+    const int sub = threadIdx.x % LPR;
+    for (int64_t base = (int64_t)blockIdx.x * IPB; base < total; base += (int64_t)gridDim.x * IPB) {
+        const int64_t i = base + threadIdx.x / LPR;
+        float acc = 0.f;
+        const bool ok = i < total;
+        int s = 0;
+        int64_t t = 0;
+        if (ok) {
+            s = (int)(i % S);
+            t = i / S;
+            const int h = (int)(t % H), b = (int)(t / H);
+            const bf16x8 o = *(const bf16x8*)(O + b * o_bs + h * o_hs + (int64_t)s * o_rs + sub * 8);
+            const bf16x8 d = *(const bf16x8*)(dO + b * do_bs + h * do_hs + (int64_t)s * do_rs + sub * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)o[e] * (float)d[e];
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (ok && sub == 0) delta[t * Spad + s] = acc;
+    }
+}
+
+template <typename K>
+int set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 1;
+}
+
+}  // namespace
+
+// LSE / delta rows are Spad long (multiple of 64, zero-initialised by the host) so that the kernels can use aligned float4 reads.
+extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
+                             int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad,
+                             int D, float scale, int causal, void* stream) {
+    AFK_REQUIRE(Q && K && V && O && LSE, "afk_attn2_fwd: null pointer");
+    AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_fwd: bad shape");
+    AFK_REQUIRE(D == 64 || D == 128, "afk_attn2_fwd: head_dim %d unsupported by the LDS kernels (64/128)", D);
+    AFK_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 && o_rs % 4 == 0,
+                "afk_attn2_fwd: strides must keep 16-byte alignment");
+    AttnArgs2 p = {};
+    p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+    p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+    p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
+    p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
+    p.LSE = LSE; p.kv_len = kv_len;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    dim3 grid((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 128) {
+        constexpr int L = 4 * Tile<128>::BYTES;
+        static int once = set_lds(attn_fwd_lds_kernel<128>, L);
+        (void)once;
+        hipLaunchKernelGGL(attn_fwd_lds_kernel<128>, grid, dim3(256), L, st, p);
+    } else {
+        constexpr int L = 4 * Tile<64>::BYTES;
+        static int once = set_lds(attn_fwd_lds_kernel<64>, L);
+        (void)once;
+        hipLaunchKernelGGL(attn_fwd_lds_kernel<64>, grid, dim3(256), L, st, p);
+    }
+    AFK_LAUNCH_CHECK("afk_attn2_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_attn2_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs,
+                               int64_t do_rs, float* delta, int B, int H, int S, int Spad, int D, void* stream) {
+    AFK_REQUIRE(O && dO && delta && (D == 64 || D == 128) && Spad >= S, "afk_attn2_delta: bad args");
+    const int64_t total = (int64_t)B * H * S;
+    int grid = (int)afk_cdiv(total, 256 / (D / 8));
+    if (grid > 8192) grid = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 128)
+        hipLaunchKernelGGL(attn2_delta_kernel<128>, dim3(grid), dim3(256), 0, st, (const bf16*)O, o_bs, o_hs, o_rs, (const bf16*)dO, do_bs, do_hs, do_rs, delta, B, H, S, Spad);
+    else
+        hipLaunchKernelGGL(attn2_delta_kernel<64>, dim3(grid), dim3(256), 0, st, (const bf16*)O, o_bs, o_hs, o_rs, (const bf16*)dO, do_bs, do_hs, do_rs, delta, B, H, S, Spad);
+    AFK_LAUNCH_CHECK("afk_attn2_delta");
+    return AFK_OK;
+}
+
+extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
+                             int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
+                             int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
+                             int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
+                             int Spad, int D, float scale, int causal, void* stream) {
+    AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
+    AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_bwd: bad shape");
+    AFK_REQUIRE(D == 64 || D == 128, "afk_attn2_bwd: head_dim %d unsupported by the LDS kernels (64/128)", D);
+    AFK_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && do_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 &&
+                    do_hs % 8 == 0,
+                "afk_attn2_bwd: strides must keep 16-byte alignment");
+    AttnArgs2 p = {};
+    p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+    p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+    p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
+    p.dO = (const bf16*)dO; p.do_bs = do_bs; p.do_hs = do_hs; p.do_rs = do_rs;
+    p.dQ = (bf16*)dQ; p.dq_bs = dq_bs; p.dq_hs = dq_hs; p.dq_rs = dq_rs;
+    p.dK = (bf16*)dK; p.dk_bs = dk_bs; p.dk_hs = dk_hs; p.dk_rs = dk_rs;
+    p.dV = (bf16*)dV; p.dv_bs = dv_bs; p.dv_hs = dv_hs; p.dv_rs = dv_rs;
+    p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)Hkv, (unsigned)B);
+    dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    if (D == 128) {
+        constexpr int L = 4 * Tile<128>::BYTES;
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, L) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), L, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
+    } else {
+        constexpr int L = 4 * Tile<64>::BYTES;
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, L) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
+        (void)once;
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), L, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+    }
+    AFK_LAUNCH_CHECK("afk_attn2_bwd");
+    return AFK_OK;
+}

@@ -183,15 +183,24 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
     }
 }
 
-// out[c] (+)= sum_p partials[p][which][c]   -> bf16 grads
+// out[c] (+)= sum_p partials[p][which][c]   -> bf16 grads.  32 columns x 8 part-slices per block, LDS fold.
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, int nparts, int D,
                                                             int stride, int offset, bf16* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= D) return;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partials[(int64_t)p * stride + offset + c];
-    if (accumulate) s += (float)out[c];
-    out[c] = (bf16)s;
+    if (c < D)
+        for (int p = sl; p < nparts; p += 8) s += partials[(int64_t)p * stride + offset + c];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < D) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        if (accumulate) t += (float)out[c];
+        out[c] = (bf16)t;
+    }
 }
 
 int norm_grid(int64_t rows) {
@@ -262,9 +271,9 @@ extern "C" int afk_layernorm_bwd(const void* x, const void* w, const void* dy, c
     const int nb = afk_norm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     launch_bwd<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 32)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
                        (bf16*)dw, accumulate);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, D,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 32)), dim3(256), 0, st, workspace, nb, D, 2 * D, D,
                        (bf16*)db, accumulate);
     AFK_LAUNCH_CHECK("afk_layernorm_bwd");
     return AFK_OK;
@@ -278,7 +287,7 @@ extern "C" int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
     const int nb = afk_norm_bwd_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
     launch_bwd<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 32)), dim3(256), 0, st, workspace, nb, D, 2 * D, 0,
                        (bf16*)dw, accumulate);
     AFK_LAUNCH_CHECK("afk_rmsnorm_bwd");
     return AFK_OK;

@@ -276,16 +276,29 @@ def embed_scatter_bwd(ids, src, dout, d_embed, d_audio):
 
 
 # ---------------------------------------------------------------------------------------------- attention
+ATTN_IMPL = "lds"  # "lds" = attention_lds.hip (head_dim 64/128), "direct" = attention.hip (also head_dim 32; A/B reference)
+
+
+def _use_lds(D):
+    return ATTN_IMPL == "lds" and D in (64, 128)
+
+
 def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
-    """qkv [B*S, (Hq+2Hkv)*D] fused projection output (q | k | v).  -> o [B*S, Hq*D], lse [B,Hq,S]"""
+    """qkv [B*S, (Hq+2Hkv)*D] fused projection output (q | k | v).  -> o [B*S, Hq*D], lse [B,Hq,Spad]"""
     _chk(qkv, BF16, "qkv")
     ld = qkv.stride(0)
     spad = pad64(S)
     q = qkv
     k = qkv[:, Hq * D:]
     v = qkv[:, (Hq + Hkv) * D:]
-    vt = transpose_heads(v, B, S, Hkv, D, ld, spad)
     o = torch.empty((B * S, Hq * D), device=qkv.device, dtype=BF16)
+    if _use_lds(D):
+        lse = torch.zeros((B, Hq, spad), device=qkv.device, dtype=torch.float32)
+        _lib.call("afk_attn2_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+                  o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), B, Hq, Hkv, S, spad, D, float(scale),
+                  int(causal), _stream())
+        return o, lse
+    vt = transpose_heads(v, B, S, Hkv, D, ld, spad)
     lse = torch.empty((B, Hq, S), device=qkv.device, dtype=torch.float32)
     _lib.call("afk_attn_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, vt.data_ptr(), o.data_ptr(),
               S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
@@ -300,18 +313,27 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
     k = qkv[:, Hq * D:]
     v = qkv[:, (Hq + Hkv) * D:]
     dev = qkv.device
-    delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)
     ldo = Hq * D
-    _lib.call("afk_attn_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, D,
-              _stream())
-    qt = transpose_heads(q, B, S, Hq, D, ld, spad)
-    kt = transpose_heads(k, B, S, Hkv, D, ld, spad)
-    dot = transpose_heads(do, B, S, Hq, D, ldo, spad)
     dqkv = torch.empty_like(qkv)
     ldd = dqkv.stride(0)
     dq = dqkv
     dk = dqkv[:, Hq * D:]
     dv = dqkv[:, (Hq + Hkv) * D:]
+    if _use_lds(D) and lse.shape[-1] == spad:
+        delta = torch.zeros((B, Hq, spad), device=dev, dtype=torch.float32)
+        _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S,
+                  spad, D, _stream())
+        _lib.call("afk_attn2_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+                  do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
+                  dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), B, Hq, Hkv, S, spad, D,
+                  float(scale), int(causal), _stream())
+        return dqkv
+    delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)
+    _lib.call("afk_attn_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, D,
+              _stream())
+    qt = transpose_heads(q, B, S, Hq, D, ld, spad)
+    kt = transpose_heads(k, B, S, Hkv, D, ld, spad)
+    dot = transpose_heads(do, B, S, Hq, D, ldo, spad)
     _lib.call("afk_attn_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
               do.data_ptr(), S * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr(),
               dq.data_ptr(), S * ldd, D, ldd, dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len),

@@ -118,6 +118,21 @@ int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const 
                  int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale,
                  int causal, void* stream);
 
+/* ---- attention v2: LDS-staged tiles + ds_read_b64_tr_b16 transposed operands; no transposed copies in HBM.
+ * Same oracle lines as afk_attn_*.  head_dim 64 / 128.  LSE and delta are [B, Hq, Spad] (Spad % 64 == 0, zero-initialised). */
+int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                  int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
+                  int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad,
+                  int D, float scale, int causal, void* stream);
+int afk_attn2_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs,
+                    int64_t do_rs, float* delta, int B, int H, int S, int Spad, int D, void* stream);
+int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                  int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
+                  int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
+                  int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
+                  int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
+                  int Spad, int D, float scale, int causal, void* stream);
+
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;
  * denom = device scalar (number of valid labels, or num_items_in_batch). */
