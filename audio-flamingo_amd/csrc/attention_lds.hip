@@ -36,6 +36,7 @@ struct AttnArgs2 {
     int B, Hq, Hkv, S, Spad;
     float scale;
     int causal;
+    int split_heads;  // dK/dV sweep: one block per QUERY head, partial dK/dV per query head (GQA), reduced afterwards
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    const int qb0 = blockIdx.x * 128;
+    // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
+    const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    const int qb0 = blockIdx.x * 128;
+    // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
+    const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -296,14 +299,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // block = 128 keys of one kv head (wave = 32 keys); streams 64-query tiles of Q and dO of every head of the GQA group.
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) {
+__global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
     constexpr int KS = T::KS, DT = T::DT;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][Q image | dO image]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, hk = blockIdx.y, group = p.Hq / p.Hkv;
+    const int b = blockIdx.z, group = p.Hq / p.Hkv;
+    const int hy = blockIdx.y;
+    const int hk = p.split_heads ? hy / group : hy;
+    const int g_begin = p.split_heads ? hy % group : 0;
+    const int g_count = p.split_heads ? 1 : group;
     const int kb0 = blockIdx.x * 128;
     const int key0 = kb0 + wave * 32;
     const int key = key0 + l31;
@@ -314,6 +321,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) 
 
     const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
     const bf16* Vp = p.V + b * p.v_bs + hk * p.v_hs + (int64_t)keyc * p.v_rs + hi * 8;
+    // head_dim 64: this wave's 32 keys stay in registers for the whole sweep; head_dim 128 would spill, it re-reads
+    // its 8 KiB of K/V rows from L1/L2 per tile instead
+    constexpr bool HOIST = true;  // head_dim 128 runs one wave per SIMD (launch bound) so that 64 operand VGPRs fit beside 128 accumulators
+    bf16x8 kf[HOIST ? KS : 1], vf[HOIST ? KS : 1];
+    if (HOIST) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *(const bf16x8*)(Kp + ks * 16);
+            vf[ks] = *(const bf16x8*)(Vp + ks * 16);
+        }
+    }
 
     f32x16 dkacc[DT], dvacc[DT];
 #pragma unroll
@@ -324,11 +342,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) 
     const int qt_begin = p.causal ? (kb0 >> 6) : 0;  // block-uniform first 64-query tile
     const int qt_end = (p.S + 63) >> 6;
     const int per_head = qt_end - qt_begin;
-    const int ntiles = per_head * group;
+    const int ntiles = per_head * g_count;
 
     auto stage = [&](int t) {
-        const int g = t / per_head, qt = qt_begin + (t - g * per_head);
-        const int h = hk * group + g;
+        const int gi = t / per_head, qt = qt_begin + (t - gi * per_head);
+        const int h = hk * group + g_begin + gi;
         char* buf = smem + (t & 1) * 2 * T::BYTES;
         T::stage(buf, p.Q + b * p.q_bs + h * p.q_hs, p.q_rs, qt * 64, p.S - 1, wave, lane);
         T::stage(buf + T::BYTES, p.dO + b * p.do_bs + h * p.do_hs, p.do_rs, qt * 64, p.S - 1, wave, lane);
@@ -337,8 +355,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) 
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) stage(t + 1);
-        const int g = t / per_head, qt = qt_begin + (t - g * per_head);
-        const int h = hk * group + g;
+        const int gi = t / per_head, qt = qt_begin + (t - gi * per_head);
+        const int h = hk * group + g_begin + gi;
         const char* qimg = smem + (t & 1) * 2 * T::BYTES;
         const char* doimg = qimg + T::BYTES;
         const float* lse = p.LSE + ((int64_t)b * p.Hq + h) * p.Spad;
@@ -348,18 +366,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) 
             const int qt0 = qt * 64 + qt2 * 32;
             // causal: a 32-query half entirely before this wave's keys contributes nothing
             if (wave_live && qt0 < p.S && !(p.causal && qt0 + 31 < key0)) {
+                // softmax statistics first: their global-load latency hides under the QK^T / dO.V^T MFMAs
+                f32x4 l4v[4], d4v[4];
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    l4v[qd] = *(const f32x4*)(lse + qt0 + 8 * qd + 4 * hi);  // 4 consecutive queries, inside [0, Spad)
+                    d4v[qd] = *(const f32x4*)(dlt + qt0 + 8 * qd + 4 * hi);
+                }
                 f32x16 st = zero16(), dp = zero16();
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    st = MFMA(T::row_frag(qimg, qt2 * 32 + l31, ks, hi), *(const bf16x8*)(Kp + ks * 16), st);
-                    dp = MFMA(T::row_frag(doimg, qt2 * 32 + l31, ks, hi), *(const bf16x8*)(Vp + ks * 16), dp);
+                    st = MFMA(T::row_frag(qimg, qt2 * 32 + l31, ks, hi), HOIST ? kf[HOIST ? ks : 0] : *(const bf16x8*)(Kp + ks * 16), st);
+                    dp = MFMA(T::row_frag(doimg, qt2 * 32 + l31, ks, hi), HOIST ? vf[HOIST ? ks : 0] : *(const bf16x8*)(Vp + ks * 16), dp);
                 }
                 bf16x8 pb[2], dsb[2];
 #pragma unroll
                 for (int qd = 0; qd < 4; ++qd) {
-                    const int qq0 = qt0 + 8 * qd + 4 * hi;  // 4 consecutive queries, inside [0, Spad)
-                    const f32x4 l4 = *(const f32x4*)(lse + qq0);
-                    const f32x4 d4 = *(const f32x4*)(dlt + qq0);
+                    const int qq0 = qt0 + 8 * qd + 4 * hi;
+                    const f32x4 l4 = l4v[qd];
+                    const f32x4 d4 = d4v[qd];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * qd + e;
@@ -382,8 +407,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) 
         __syncthreads();
     }
     if (key < p.S) {
-        bf16* dKp = p.dK + b * p.dk_bs + hk * p.dk_hs + (int64_t)key * p.dk_rs;
-        bf16* dVp = p.dV + b * p.dv_bs + hk * p.dv_hs + (int64_t)key * p.dv_rs;
+        bf16* dKp = p.dK + b * p.dk_bs + hy * p.dk_hs + (int64_t)key * p.dk_rs;
+        bf16* dVp = p.dV + b * p.dv_bs + hy * p.dv_hs + (int64_t)key * p.dv_rs;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -426,6 +451,30 @@ __global__ __launch_bounds__(256) void attn2_delta_kernel(const bf16* __restrict
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
         if (ok && sub == 0) delta[t * Spad + s] = acc;
+    }
+}
+
+// GQA reduce: out[row][hk][d] = sum_g part[row][hk*group+g][d]   (rows = B*S; part rows are Hq*D wide, out rows ld_out wide)
+__global__ __launch_bounds__(256) void gqa_reduce_kernel(const bf16* __restrict__ part, bf16* __restrict__ out, int64_t rows, int Hkv,
+                                                         int group, int D, int64_t ld_out) {
+    const int vpr = Hkv * D / 8;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const int hk = (v * 8) / D, d = (v * 8) % D;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int g = 0; g < group; ++g) {
+            const bf16x8 t = *(const bf16x8*)(part + r * (int64_t)(Hkv * group * D) + (hk * group + g) * D + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)t[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+        *(bf16x8*)(out + r * ld_out + hk * D + d) = o;
     }
 }
 
@@ -490,7 +539,7 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
                              int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
                              int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
                              int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
-                             int Spad, int D, float scale, int causal, void* stream) {
+                             int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
     AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_bwd: bad shape");
     AFK_REQUIRE(D == 64 || D == 128, "afk_attn2_bwd: head_dim %d unsupported by the LDS kernels (64/128)", D);
@@ -508,20 +557,42 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     hipStream_t st = (hipStream_t)stream;
-    dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)Hkv, (unsigned)B);
+    // GQA: with few kv heads the dK/dV sweep has too few blocks to fill 256 CUs (decoder: 8x4x8 = 256 long blocks).
+    // Given a scratch of 2 * B*S*Hq*D bf16 the sweep runs one block per QUERY head and a reduce folds the group.
+    const int group = Hq / Hkv;
+    const bool split = gqa_scratch != nullptr && group > 1;
+    AttnArgs2 pk = p;
+    if (split) {
+        pk.split_heads = 1;
+        pk.dK = (bf16*)gqa_scratch;
+        pk.dV = (bf16*)gqa_scratch + (int64_t)B * S * Hq * D;
+        pk.dk_bs = pk.dv_bs = (int64_t)S * Hq * D;
+        pk.dk_hs = pk.dv_hs = D;
+        pk.dk_rs = pk.dv_rs = (int64_t)Hq * D;
+    }
+    dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)(split ? Hq : Hkv), (unsigned)B);
     dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
     if (D == 128) {
         constexpr int L = 4 * Tile<128>::BYTES;
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, L) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), L, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), L, st, pk);
         hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
     } else {
         constexpr int L = 4 * Tile<64>::BYTES;
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, L) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), L, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), L, st, pk);
         hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+    }
+    if (split) {
+        AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
+                    "afk_attn2_bwd: GQA split path expects dK/dV inside one [B*S, ld] buffer with contiguous heads");
+        const int64_t rows = (int64_t)B * S;
+        int g = (int)afk_cdiv(rows * (Hkv * D / 8), 256);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dK, (bf16*)dK, rows, Hkv, group, D, dk_rs);
+        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dV, (bf16*)dV, rows, Hkv, group, D, dv_rs);
     }
     AFK_LAUNCH_CHECK("afk_attn2_bwd");
     return AFK_OK;

@@ -254,17 +254,17 @@ class DecoderLayerFn(torch.autograd.Function):
         gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
         a = ops.silu_mul_fwd(gu)
         x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
-        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len)
+        # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
+        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a)
         ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)
         return x3
 
     @staticmethod
     def backward(ctx, dx3):
-        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len = ctx.saved_tensors
+        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a = ctx.saved_tensors
         arena, pfx, B, S, Hq, Hkv, D = ctx.meta
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
-        a = ops.silu_mul_fwd(gu)
         da = linear_bwd(arena, dx3, a, pfx + "mlp.down_proj.weight")
         del a
         dgu = ops.silu_mul_bwd(gu, da)

@@ -323,10 +323,11 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
         delta = torch.zeros((B, Hq, spad), device=dev, dtype=torch.float32)
         _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S,
                   spad, D, _stream())
+        scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
                   dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), B, Hq, Hkv, S, spad, D,
-                  float(scale), int(causal), _stream())
+                  float(scale), int(causal), _p(scratch), _stream())
         return dqkv
     delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)
     _lib.call("afk_attn_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, D,
