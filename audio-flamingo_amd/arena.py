@@ -141,6 +141,11 @@ class Arena:
     def _version_of(self, b: Block) -> int:
         return self.params._version * 1000003 + self.step_counter
 
+    def refresh_bucket_shadows(self, i: int):
+        for b in self.order:
+            if b.bucket == i and b.shadow_kind is not None:
+                self._refresh_one(b)
+
     def refresh_shadows(self, force: bool = True):
         for b in self.order:
             if b.shadow_kind is not None and (force or b.shadow_version != self._version_of(b)):
@@ -186,13 +191,42 @@ class FusedAdamW:
             else:
                 self.segments.append([b.offset, end, wd])
 
+        # per-bucket segments (for optimizer-in-backward overlap)
+        self.bucket_segments = [[] for _ in arena.bucket_names]
+        for blk in arena.order:
+            end = blk.offset + (blk.numel + ALIGN - 1) // ALIGN * ALIGN
+            wd = weight_decay if blk.decay else 0.0
+            segs = self.bucket_segments[blk.bucket]
+            if segs and segs[-1][2] == wd and segs[-1][1] == blk.offset:
+                segs[-1][1] = end
+            else:
+                segs.append([blk.offset, end, wd])
+
+    def _launch(self, s, e, wd, grad_scale):
+        a = self.arena
+        ops.adamw_step(self.master[s:e], self.m[s:e], self.v[s:e], a.grads[s:e], a.params[s:e], lr=self.lr,
+                       beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t,
+                       grad_scale=grad_scale)
+
+    def begin_step(self):
+        """overlapped mode: advance the step count once, then step_bucket() per bucket as its gradients complete"""
+        self.t += 1
+
+    def step_bucket(self, i: int, grad_scale: float = 1.0):
+        for s, e, wd in self.bucket_segments[i]:
+            self._launch(s, e, wd, grad_scale)
+
+    def end_step(self):
+        self.arena.step_counter += 1
+        for b in self.arena.order:  # shadows were refreshed bucket by bucket
+            if b.shadow_kind is not None:
+                b.shadow_version = self.arena._version_of(b)
+
     def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True):
         self.t += 1
         a = self.arena
         for s, e, wd in self.segments:
-            ops.adamw_step(self.master[s:e], self.m[s:e], self.v[s:e], a.grads[s:e], a.params[s:e], lr=self.lr,
-                           beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t,
-                           grad_scale=grad_scale)
+            self._launch(s, e, wd, grad_scale)
         a.step_counter += 1
         if refresh_shadows:
             a.refresh_shadows(force=True)

@@ -222,6 +222,48 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const bf16* __restrict__ in
     if (lane == 0) out[row] = (bf16)(accumulate ? s + (float)out[row] : s);
 }
 
+// column sums (bias gradient straight from the row-major output gradient): out[c] (+)= sum_r in[r][c]
+// stage 1: block = 64 columns x one row slice; 32 row-lanes x 8 column-lanes of bf16x8, LDS fold -> partial[slice][c]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ in, int64_t ld, int64_t rows, int cols,
+                                                             float* __restrict__ partial, int rows_per_slice) {
+    __shared__ float red[32][65];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cl * 8;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t r_end = min(rows, r_begin + rows_per_slice);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < cols) {
+        for (int64_t r = r_begin + rl; r < r_end; r += 32) {
+            const bf16x8 t = *(const bf16x8*)(in + r * ld + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < cols) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+            partial[(int64_t)blockIdx.y * cols + c] = s;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int nslices, int cols, bf16* __restrict__ out,
+                                                          int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += partial[(int64_t)k * cols + c];
+    if (accumulate) s += (float)out[c];
+    out[c] = (bf16)s;
+}
+
 // ------------------------------------------------------------------ conv stem as GEMM: im2col / col2im
 // conv1 (Conv1d(128->1280,k3,p1), modeling_audioflamingo3.py:328,380): x = [W, C, T] (f32 or bf16 log-mel,
 // channel-major as the feature extractor emits it) -> col[(w,t)][kk*C + c] = x[w][c][t+kk-1] (0 outside).
@@ -564,6 +606,25 @@ extern "C" int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int
     hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)afk_cdiv(rows, 4)), dim3(256), 0, ST, (const bf16*)in, ld, C, (bf16*)out,
                        rows, accumulate);
     AFK_LAUNCH_CHECK("afk_rowsum_bf16");
+    return AFK_OK;
+}
+
+extern "C" int afk_colsum_slices(int64_t rows) {
+    int64_t s = afk_cdiv(rows, 512);
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace,
+                               void* stream) {
+    AFK_REQUIRE(in && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "afk_colsum_bf16: bad args");
+    const int ns = afk_colsum_slices(rows);
+    const int rps = (int)afk_cdiv(rows, ns);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)afk_cdiv(cols, 64), (unsigned)ns), dim3(256), 0, ST, (const bf16*)in, ld, rows,
+                       cols, workspace, rps);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)afk_cdiv(cols, 256)), dim3(256), 0, ST, workspace, ns, cols, (bf16*)out, accumulate);
+    AFK_LAUNCH_CHECK("afk_colsum_bf16");
     return AFK_OK;
 }
 

@@ -193,12 +193,15 @@ extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* 
     return AFK_OK;
 }
 
-extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                                int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
-                                int res_mod, void* preact_out, float alpha, int flags, void* stream) {
+static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                     int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                     int res_mod, void* preact_out, float alpha, int flags, void* stream) {
     AFK_REQUIRE(A && B && C, "afk_gemm_nt_bf16: null operand");
     AFK_REQUIRE(M > 0 && N > 0 && K > 0, "afk_gemm_nt_bf16: bad shape %d %d %d", M, N, K);
-    AFK_REQUIRE(K % BK == 0, "afk_gemm_nt_bf16: K=%d must be a multiple of %d (pad the operand)", K, BK);
+    AFK_REQUIRE(!trans_a || trans_b, "afk_gemm_bf16: A^T with k-contiguous B is not implemented (NT, NN, TN are)");
+    AFK_REQUIRE(trans_a || K % BK == 0, "afk_gemm_nt_bf16: K=%d must be a multiple of %d (pad the operand)", K, BK);
+    AFK_REQUIRE(!trans_b || (N % 8 == 0 && N >= 8), "afk_gemm_bf16: N=%d must be a multiple of 8 for a reduction-major B", N);
+    AFK_REQUIRE(!trans_a || (M % 8 == 0 && M >= 8), "afk_gemm_bf16: M=%d must be a multiple of 8 for a reduction-major A", M);
     AFK_REQUIRE(N % 4 == 0, "afk_gemm_nt_bf16: N=%d must be a multiple of 4", N);
     AFK_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "afk_gemm_nt_bf16: leading dims must keep 16-B (A,B) / 8-B (C) alignment");
     AFK_REQUIRE(!(flags & AFK_GEMM_BIAS) || bias, "afk_gemm_nt_bf16: BIAS flag without bias");
@@ -223,7 +226,7 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     p.alpha = alpha;
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = g_variant == 2 || (g_variant == 0 && tiles256 >= 192);
+    const bool use256 = trans_b || g_variant == 2 || (g_variant == 0 && tiles256 >= 192);
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -247,7 +250,9 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
         }
     }
     if (prof) hipEventRecord(e0, st);
-    if (use256) {
+    if (trans_b) {
+        if (int e = afk_launch_gemm256t(p, trans_a, st)) return e;
+    } else if (use256) {
         if (int e = afk_launch_gemm256(p, st)) return e;
     } else {
         hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg), dim3(256), NSTAGE * STAGE_BYTES, st, p);
@@ -255,4 +260,16 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
     if (prof) hipEventRecord(e1, st);
     AFK_LAUNCH_CHECK("afk_gemm_nt_bf16");
     return AFK_OK;
+}
+
+extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                                int res_mod, void* preact_out, float alpha, int flags, void* stream) {
+    return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream);
+}
+
+extern "C" int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                             int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                             int res_mod, void* preact_out, float alpha, int flags, void* stream) {
+    return gemm_impl(trans_a, trans_b, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream);
 }

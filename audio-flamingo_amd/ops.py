@@ -71,6 +71,52 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
     return out
 
 
+def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None,
+         accumulate=False, alpha=1.0):
+    """General form of the MFMA GEMM (C ABI afk_gemm_bf16).
+        NT: a [M,K],  b [N,K]            (forward)
+        NN: a [M,K],  b [K,N]  trans_b   (dgrad: dX = dY . W)
+        TN: a [K,M],  b [K,N]  both      (wgrad: dW = dY^T . X; reduction length K free)"""
+    _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b")
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    if trans_a:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if trans_b:
+        Kb, N = b.shape
+    else:
+        N, Kb = b.shape
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= N
+    flags = 0
+    if bias is not None:
+        flags |= GEMM_BIAS
+    if gelu:
+        flags |= GEMM_GELU
+    if residual is not None:
+        flags |= GEMM_RESIDUAL
+    if out.dtype == torch.float32:
+        flags |= GEMM_OUT_F32
+    if accumulate:
+        flags |= GEMM_ACCUM
+    _lib.call("afk_gemm_bf16", int(trans_a), int(trans_b), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+              out.stride(0), M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
+              _p(preact_out), float(alpha), flags, _stream())
+    return out
+
+
+def colsum(x, out, *, accumulate=False):
+    """out[c] (+)= sum_r x[r][c]   (bias gradient)"""
+    rows, cols = x.shape
+    ns = _lib.load().afk_colsum_slices(rows)
+    ws = torch.empty(ns * cols, device=x.device, dtype=torch.float32)
+    _lib.call("afk_colsum_bf16", x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), int(accumulate), ws.data_ptr(), _stream())
+    return out
+
+
 def transpose(x, out=None, *, rpad=None):
     """x [R, C] (row stride free) -> out [C, Rpad] with zero-filled tail columns."""
     _chk(x, BF16, "transpose x")

@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW after backward instead of bucket-by-bucket inside it")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel engine even with one rank (exercises the RCCL path)")
     args = ap.parse_args()
 
@@ -143,7 +144,7 @@ def main():
 
     from audio_flamingo_amd import ops
     from audio_flamingo_amd.arena import FusedAdamW
-    from audio_flamingo_amd.dp import DataParallelEngine
+    from audio_flamingo_amd.dp import BackwardOverlap, DataParallelEngine
     from audio_flamingo_amd.frontend import LogMelFrontend
     from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration
 
@@ -174,9 +175,18 @@ def main():
     frontend = LogMelFrontend(dev)
     waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev)
 
+    overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
+
     def step():
         feats = frontend(waves, out_dtype=torch.bfloat16)
         model.arena.zero_grad()
+        if overlap is not None:
+            # per bucket, inside backward, on a side stream: [all-reduce] -> AdamW -> W^T shadow refresh
+            overlap.begin_step()
+            out = model(input_ids=ids, input_features=feats, labels=labels)
+            out.loss.backward()
+            overlap.finish()
+            return out.loss
         if engine is not None:
             engine.begin_backward()
         out = model(input_ids=ids, input_features=feats, labels=labels)

@@ -48,6 +48,13 @@ int afk_gemm_set_variant(int variant);
 int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                      int res_mod, void* preact_out, float alpha, int flags, void* stream);
+/* General form: trans_x = 0 -> operand stored [rows][K] (k contiguous, as above); trans_x = 1 -> stored reduction-major
+ * [K][rows] (ld = row pitch).  Implemented: NT (0,0), NN (0,1) = dgrad  dX = dY . W  with W as nn.Linear stores it,
+ * TN (1,1) = wgrad  dW = dY^T . X  with both activations as they lie.  For trans_a the reduction length K is free
+ * (ragged last tile is masked in-kernel); reduction-major operands need their row count (M resp. N) % 8 == 0. */
+int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                  int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
+                  int res_mod, void* preact_out, float alpha, int flags, void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------
  * LayerNorm: nn.LayerNorm(eps=1e-5) at modeling_audioflamingo3.py:207,212 (per layer) and :335,403 (final).
@@ -84,6 +91,11 @@ int afk_cast_f32_bf16(const float* in, void* out, int64_t n, void* stream);
 int afk_scale_add_bf16(const void* x, void* y, int64_t n, const float* scale_dev, int accumulate, void* stream);
 /* out[r] (+)= sum_c in[r][c] : bias gradient from the transposed output-gradient */
 int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int accumulate, void* stream);
+
+/* out[c] (+)= sum_r in[r][c] : bias gradient straight from the row-major output gradient;
+ * workspace = afk_colsum_slices(rows) * cols floats */
+int afk_colsum_slices(int64_t rows);
+int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, void* stream);
 
 /* ---- conv stem as GEMM (modeling_audioflamingo3.py:328-329,380-382) ------------------------------------ */
 int afk_im2col_conv1(const void* x, int x_is_f32, void* col, int W, int C, int T, void* stream);

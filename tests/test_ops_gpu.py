@@ -68,6 +68,45 @@ def test_gemm_variants(dev, variant, M, N, K):
         ops.gemm_set_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (304, 264, 320), (1000, 1280, 1280), (8, 512, 4096), (2048, 256, 2048)])
+def test_gemm_nn_dgrad_form(dev, M, N, K):
+    """C = A[M,K] . Bt[K,N]  (B stored reduction-major, as dX = dY . W needs it)"""
+    ops = _ops()
+    a = _rand((M, K), dev, seed=21).to(BF)
+    bt = _rand((K, N), dev, seed=22).to(BF)
+    c = ops.gemm(a, bt, trans_b=True)
+    _cmp(f"gemm NN {M}x{N}x{K}", c, a.float() @ bt.float(), atol=0.02 * math.sqrt(K), rtol=1e-2)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, bt, trans_b=True), c), "non-deterministic NN GEMM (LDS race?)"
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (304, 264, 320), (1280, 1280, 12000), (3840, 1280, 6000), (8, 512, 100),
+                                   (384, 1280, 24000), (2048, 256, 2048)])
+def test_gemm_tn_wgrad_form(dev, M, N, K):
+    """C = At[K,M]^T . Bt[K,N]  (both reduction-major; ragged K exercises the in-kernel tail mask)"""
+    ops = _ops()
+    at = _rand((K, M), dev, seed=31).to(BF)
+    bt = _rand((K, N), dev, seed=32).to(BF)
+    base = _rand((M, N), dev, seed=33).to(BF)
+    c = ops.gemm(at, bt, trans_a=True, trans_b=True)
+    ref = at.float().t() @ bt.float()
+    _cmp(f"gemm TN {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
+    c2 = base.clone()
+    ops.gemm(at, bt, out=c2, trans_a=True, trans_b=True, accumulate=True)
+    _cmp("gemm TN accumulate", c2, ref + base.float(), atol=0.03 * math.sqrt(K), rtol=1e-2)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(at, bt, trans_a=True, trans_b=True), c), "non-deterministic TN GEMM (LDS race?)"
+
+
+def test_colsum(dev):
+    ops = _ops()
+    for rows, cols in [(100, 64), (12000, 1280), (8192, 4608), (513, 72)]:
+        x = _rand((rows, cols), dev, seed=rows).to(BF)
+        out = torch.ones(cols, device=dev, dtype=BF)
+        ops.colsum(x, out, accumulate=True)
+        _cmp("colsum", out, x.float().sum(0) + 1.0, atol=0.02 * math.sqrt(rows) + 0.05, rtol=1e-2)
+
+
 def test_gemm_identity_layout(dev):
     """A = I pattern with asymmetric B: output must equal B^T rows exactly (detects transposed C writes)."""
     ops = _ops()

@@ -34,3 +34,30 @@ for name, M, N, K in SHAPES:
     ops.gemm_set_variant(0)
     res.append(row)
     print(json.dumps(row), flush=True)
+
+# ---- backward forms: NN (dgrad) and TN (wgrad) against the NT kernel fed with pre-transposed operands
+print("--- NN / TN forms (v2 = 256 kernels); nt_* = same contraction on the NT kernel incl. nothing else", flush=True)
+BW = [("dec gate_up dgrad NN", "NN", 8192, 3584, 37888), ("dec down dgrad NN", "NN", 8192, 18944, 3584), ("dec qkv dgrad NN", "NN", 8192, 3584, 4608),
+      ("lm_head dgrad NN", "NN", 2048, 3584, 152064), ("enc fc1 dgrad NN", "NN", 12000, 1280, 5120), ("enc qkv dgrad NN", "NN", 12000, 1280, 3840),
+      ("dec gate_up wgrad TN", "TN", 37888, 3584, 8192), ("dec down wgrad TN", "TN", 3584, 18944, 8192), ("dec qkv wgrad TN", "TN", 4608, 3584, 8192),
+      ("lm_head wgrad TN", "TN", 152064, 3584, 2048), ("enc fc1 wgrad TN", "TN", 5120, 1280, 12000), ("enc qkv wgrad TN", "TN", 3840, 1280, 12000),
+      ("enc out wgrad TN", "TN", 1280, 1280, 12000), ("proj l2 wgrad TN", "TN", 3584, 3584, 6000)]
+for name, form, M, N, K in BW:
+    if form == "NN":
+        a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand((K, N), device=dev) * 2 - 1).to(torch.bfloat16)
+        kw = dict(trans_b=True)
+    else:
+        a = (torch.rand((K, M), device=dev) * 2 - 1).to(torch.bfloat16)
+        b = (torch.rand((K, N), device=dev) * 2 - 1).to(torch.bfloat16)
+        kw = dict(trans_a=True, trans_b=True)
+    c = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    for _ in range(2):
+        ops.gemm(a, b, out=c, **kw)
+    torch.cuda.synchronize()
+    ops.prof_reset(); ops.prof_enable(True)
+    for _ in range(5):
+        ops.gemm(a, b, out=c, **kw)
+    ops.prof_enable(False)
+    ms, fl, n = ops.prof_collect()
+    print(json.dumps({"name": name, "M": M, "N": N, "K": K, "tflops": round(fl / ms / 1e9, 1), "us": round(1e3 * ms / n, 1)}), flush=True)
