@@ -56,6 +56,10 @@ class Arena:
         self._bucket_pending: List[int] = []
         self._bucket_sizes: List[int] = []
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
+        # optional second compute stream for the weight-gradient branch of every Linear backward (functional.linear_bwd):
+        # dgrad and wgrad of a layer are independent given dY, so running them on two streams lets one GEMM's blocks fill
+        # the partially empty last wave of the other (448-tile GEMMs leave 25 % of the CUs idle in their second round)
+        self.wgrad_stream: Optional[torch.cuda.Stream] = None
 
     # ------------------------------------------------------------------ layout
     def new_bucket(self, name: str) -> int:
@@ -122,6 +126,24 @@ class Arena:
 
     def begin_backward(self):
         self._bucket_pending = list(self._bucket_sizes)
+
+    def enable_wgrad_stream(self, on: bool = True):
+        self.wgrad_stream = torch.cuda.Stream(device=self.device) if on and self.device.type == "cuda" else None
+
+    def join_streams(self):
+        """make the current stream wait for everything enqueued on the wgrad stream (call before reading .grad)"""
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
+    def ready_events(self):
+        """events that together cover every gradient kernel enqueued so far (compute stream + wgrad stream)"""
+        evs = [torch.cuda.Event()]
+        evs[0].record(torch.cuda.current_stream())
+        if self.wgrad_stream is not None:
+            e = torch.cuda.Event()
+            e.record(self.wgrad_stream)
+            evs.append(e)
+        return evs
 
     # ------------------------------------------------------------------ shadows
     def _refresh_one(self, b: Block):
@@ -225,6 +247,7 @@ class FusedAdamW:
     def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True):
         self.t += 1
         a = self.arena
+        a.join_streams()
         for s, e, wd in self.segments:
             self._launch(s, e, wd, grad_scale)
         a.step_counter += 1

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
                                                        const float* __restrict__ rstd_in, bf16* __restrict__ dx,
                                                        const bf16* __restrict__ dx_add, float* __restrict__ partials,
                                                        int64_t rows, int D) {
-    __shared__ float red[2][VPL * 256];  // cross-wave fold of the column partials (LDS atomics)
+    __shared__ float red[2][VPL * 256];  // cross-wave fold of the column partials
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nvec = D >> 2;
     const float invD = 1.f / (float)D;
@@ -119,41 +119,61 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
         const bf16* dyr = dy + row * D;
         const float mean = RMS ? 0.f : mean_in[row];
         const float rstd = rstd_in[row];
-        float xh[VPL][4], g[VPL][4];
+        // the row stays in registers as PACKED bf16 (2 VGPRs per 4 elements): 56 instead of 112 VGPRs at D=3584, which
+        // is what lets 3 waves/SIMD be resident and keep enough loads in flight for an HBM-bound kernel
+        bf16x4 xv[VPL], dv[VPL];
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                const bf16x4 xt = *(const bf16x4*)(xr + 4 * vi);
-                const bf16x4 dt = *(const bf16x4*)(dyr + 4 * vi);
+                xv[i] = *(const bf16x4*)(xr + 4 * vi);
+                dv[i] = *(const bf16x4*)(dyr + 4 * vi);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[i][e] = dv[i][e] = (bf16)0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int vi = lane + 64 * i;
+            if (vi < nvec) {
                 const bf16x4 wt = *(const bf16x4*)(w + 4 * vi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float d = (float)dt[e];
-                    xh[i][e] = ((float)xt[e] - mean) * rstd;
-                    g[i][e] = d * (float)wt[e];
-                    sg += g[i][e];
-                    sgx += g[i][e] * xh[i][e];
-                    pw[i][e] += d * (RMS ? rbf(xh[i][e]) : xh[i][e]);
+                    const float d = (float)dv[i][e];
+                    const float xh = ((float)xv[i][e] - mean) * rstd;
+                    const float g = d * (float)wt[e];
+                    sg += g;
+                    sgx += g * xh;
+                    pw[i][e] += d * (RMS ? rbf(xh) : xh);
                     if (!RMS) pb[i][e] += d;
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xh[i][e] = g[i][e] = 0.f;
             }
         }
         sgx = wave_sum(sgx) * invD;
         sg = RMS ? 0.f : wave_sum(sg) * invD;
+        // opaque to the optimiser: the second pass must re-derive xh/g from the packed row instead of keeping the
+        // first pass's fp32 values alive (that is what blew the register budget)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            asm volatile("" : "+v"(*(uint2*)&xv[i]));
+            asm volatile("" : "+v"(*(uint2*)&dv[i]));
+        }
         bf16* dxr = dx + row * D;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
+                const bf16x4 wt = *(const bf16x4*)(w + 4 * vi);
                 bf16x4 o;
                 float r[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = rstd * (g[i][e] - sg - xh[i][e] * sgx);
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = ((float)xv[i][e] - mean) * rstd;
+                    const float g = (float)dv[i][e] * (float)wt[e];
+                    r[e] = rstd * (g - sg - xh * sgx);
+                }
                 if (dx_add) {  // fused residual-gradient merge: dx = bf16(norm-branch) + skip-branch
                     const bf16x4 a = *(const bf16x4*)(dx_add + row * D + 4 * vi);
 #pragma unroll
@@ -165,17 +185,22 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
             }
         }
     }
-    // fold the 4 waves' partials (LDS float atomics) and write this block's partial row:
-    // partials[block][0][D] = dw, [1][D] = db
+    // fold the 4 waves' partials in a FIXED order (wave 0,1,2,3 take turns: bit-reproducible, unlike LDS float atomics)
+    // and write this block's partial row: partials[block][0][D] = dw, [1][D] = db
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VPL; ++i)
+    for (int turn = 0; turn < ROWS_PER_BLOCK; ++turn) {
+        if (wv == turn) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            atomicAdd(&red[0][(lane + 64 * i) * 4 + e], pw[i][e]);
-            if (!RMS) atomicAdd(&red[1][(lane + 64 * i) * 4 + e], pb[i][e]);
+            for (int i = 0; i < VPL; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[0][(lane + 64 * i) * 4 + e] += pw[i][e];
+                    if (!RMS) red[1][(lane + 64 * i) * 4 + e] += pb[i][e];
+                }
         }
-    __syncthreads();
+        __syncthreads();
+    }
     float* outp = partials + (int64_t)blockIdx.x * 2 * D;
     for (int c = threadIdx.x; c < D; c += 256) {
         outp[c] = red[0][c];

@@ -65,10 +65,10 @@ class DataParallelEngine:
         if buf.numel() == 0:
             return
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
+            evs = self.arena.ready_events()
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
+                for ev in evs:
+                    self.comm_stream.wait_event(ev)
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             self._works.append(w)
         elif self._native_bf16:
@@ -96,6 +96,7 @@ class DataParallelEngine:
         for w in self._works:
             w.wait()  # on the nccl backend this makes the CURRENT stream wait; it does not block the host
         self._works = []
+        self.arena.join_streams()
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
@@ -144,10 +145,10 @@ class BackwardOverlap:
         if self._done[i]:
             return
         self._done[i] = True
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        evs = self.arena.ready_events()
         with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
+            for ev in evs:
+                self.side.wait_event(ev)
             if self.engine is not None and self.engine.world > 1:
                 buf = self.arena.bucket_grads(i)
                 if buf.numel():
@@ -158,6 +159,7 @@ class BackwardOverlap:
     def finish(self):
         for i in range(len(self._done)):
             self._ready(i)
+        self.arena.join_streams()
         torch.cuda.current_stream().wait_stream(self.side)
         self.opt.end_step()
         self.arena.on_bucket_ready = self.engine._on_bucket_ready if self.engine is not None else None

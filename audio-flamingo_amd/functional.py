@@ -36,13 +36,28 @@ def _wgrad(arena: Arena, blk: Block, dyt, xt, Mvalid, *, bias_blk=None, bias_sli
 
 
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True):
-    """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena."""
+    """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena.
+    The weight-gradient branch (two operand transposes + wgrad GEMM + bias row-sum) is independent of the data-gradient
+    GEMM; with ``arena.wgrad_stream`` set it is enqueued on that stream so the two GEMMs fill each other's tile tails."""
     M = dy.shape[0]
     blk = arena[wkey]
-    dyt = ops.transpose(dy)  # [N, Mp]
-    xt = ops.transpose(x)    # [K, Mp]
-    _wgrad(arena, blk, dyt, xt, M, bias_blk=arena[bkey] if bkey else None, bias_slices=bias_slices)
-    del dyt, xt
+    side = arena.wgrad_stream
+
+    def wgrad_branch():
+        dyt = ops.transpose(dy)  # [N, Mp]
+        xt = ops.transpose(x)    # [K, Mp]
+        _wgrad(arena, blk, dyt, xt, M, bias_blk=arena[bkey] if bkey else None, bias_slices=bias_slices)
+
+    if side is None:
+        wgrad_branch()
+    else:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            wgrad_branch()
+        dy.record_stream(side)
+        x.record_stream(side)
     if not need_dx:
         return None
     wt = arena.shadow(wkey)  # [K, pad64(N)]
@@ -333,7 +348,7 @@ class LMHeadLossFn(torch.autograd.Function):
     gradient of 1 and rescaled by the device-side grad_output in backward (no host sync).
     """
 
-    CHUNK = 2048
+    CHUNK = 4096  # 16x14 = 224 tiles of 256x256 for the dgrad GEMM: enough to fill the chip with the fast kernel
 
     @staticmethod
     def forward(ctx, x, anchor, arena, wkey, shift_labels, denom):

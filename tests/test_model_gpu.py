@@ -157,6 +157,36 @@ def test_grad_accumulation_and_optimizer_step(dev):
     assert losses[-1] < losses[0] - 0.05, losses
 
 
+def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
+    """the two-stream backward (wgrad branch on its own stream) and the per-bucket optimizer-in-backward schedule must give
+    bit-identical gradients / parameters to the serial schedule: same kernels, same order per tensor"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import BackwardOverlap
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    ma, mb = _model(dev), _model(dev)
+    oa, ob = FusedAdamW(ma.arena, lr=1e-3, weight_decay=0.01), FusedAdamW(mb.arena, lr=1e-3, weight_decay=0.01)
+    mb.arena.enable_wgrad_stream(True)
+    ov = BackwardOverlap(mb.arena, ob)
+    for _ in range(3):
+        ma.zero_grad()
+        la = ma(**kw).loss
+        la.backward()
+        oa.step()
+        mb.zero_grad()
+        ov.begin_step()
+        lb = mb(**kw).loss
+        lb.backward()
+        ov.finish()
+        torch.cuda.synchronize()
+        assert float(la) == float(lb)
+        assert torch.equal(ma.arena.grads, mb.arena.grads), "gradients differ between serial and overlapped schedules"
+        assert torch.equal(ma.arena.params, mb.arena.params), "parameters differ after the optimizer step"
+        for k in ("model.language_model.layers.0.mlp.gate_up.weight", "model.audio_tower.conv2.weight"):
+            assert torch.equal(ma.arena.shadow(k), mb.arena.shadow(k)), f"stale W^T shadow for {k}"
+
+
 def test_smoke_entry(dev):
     import __graft_entry__ as ge
 
