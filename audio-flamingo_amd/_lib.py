@@ -37,7 +37,10 @@ def parse_header(path: str = HEADER_PATH):
         if args and args != "void":
             for a in args.split(","):
                 a = " ".join(a.split())
-                if "*" in a:
+                if a.startswith("const char*"):
+                    argtypes.append(ctypes.c_char_p)
+                    argnames.append(a.split("*")[-1].strip())
+                elif "*" in a:
                     argtypes.append(ctypes.c_void_p)
                     argnames.append(a.split("*")[-1].strip())
                 else:

@@ -224,19 +224,19 @@ class FusedAdamW:
             else:
                 segs.append([blk.offset, end, wd])
 
-    def _launch(self, s, e, wd, grad_scale):
+    def _launch(self, s, e, wd, grad_scale, max_blocks=0):
         a = self.arena
         ops.adamw_step(self.master[s:e], self.m[s:e], self.v[s:e], a.grads[s:e], a.params[s:e], lr=self.lr,
                        beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t,
-                       grad_scale=grad_scale)
+                       grad_scale=grad_scale, max_blocks=max_blocks)
 
     def begin_step(self):
         """overlapped mode: advance the step count once, then step_bucket() per bucket as its gradients complete"""
         self.t += 1
 
-    def step_bucket(self, i: int, grad_scale: float = 1.0):
+    def step_bucket(self, i: int, grad_scale: float = 1.0, max_blocks: int = 0):
         for s, e, wd in self.bucket_segments[i]:
-            self._launch(s, e, wd, grad_scale)
+            self._launch(s, e, wd, grad_scale, max_blocks)
 
     def end_step(self):
         self.arena.step_counter += 1

@@ -706,14 +706,19 @@ extern "C" int afk_embed_scatter_bwd(const int64_t* ids, const int* src, const v
 }
 
 extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream) {
     AFK_REQUIRE(master && m && v && grad && param && n > 0 && step >= 1, "afk_adamw_step: bad args");
     AFK_REQUIRE(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                     ((uintptr_t)grad % 8 == 0) && ((uintptr_t)param % 8 == 0),
                 "afk_adamw_step: misaligned buffer");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(afk_cdiv(n, 4), 256)), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
+    // max_blocks > 0 caps the grid (grid-stride covers the rest): a THIN launch (one block per CU, 1 wave/SIMD, 56 VGPRs)
+    // can stay resident beside a 2 x 224-VGPR GEMM workgroup, so the optimizer's HBM stream overlaps MFMA-bound backward
+    // kernels; a full-size grid would instead fill every SIMD and lock the GEMM out until it drains.
+    int grid = ew_grid(afk_cdiv(n, 4), 256);
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
                        (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
     AFK_LAUNCH_CHECK("afk_adamw_step");
     return AFK_OK;

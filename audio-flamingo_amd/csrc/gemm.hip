@@ -141,6 +141,8 @@ struct ProfState {
     size_t used = 0;
     double flops = 0.0;
     int64_t launches = 0;
+    struct Rec { int M, N, K, variant; };
+    std::vector<Rec> recs;
 };
 ProfState g_prof;
 int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256
@@ -173,6 +175,7 @@ extern "C" int afk_prof_reset(void) {
     g_prof.used = 0;
     g_prof.flops = 0.0;
     g_prof.launches = 0;
+    g_prof.recs.clear();
     return AFK_OK;
 }
 
@@ -247,6 +250,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
             e1 = prof_next_event();
             g_prof.flops += 2.0 * (double)M * (double)N * (double)K;
             g_prof.launches += 1;
+            g_prof.recs.push_back({M, N, K, trans_b ? (trans_a ? 4 : 3) : (use256 ? 2 : 1)});
         }
     }
     if (prof) hipEventRecord(e0, st);
@@ -272,4 +276,20 @@ extern "C" int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t ld
                              int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                              int res_mod, void* preact_out, float alpha, int flags, void* stream) {
     return gemm_impl(trans_a, trans_b, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream);
+}
+
+// per-launch records of the profiling window as CSV: M,N,K,variant(1=nt128,2=nt256,3=nn256,4=tn256),ms
+extern "C" int afk_prof_dump(const char* host_path) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    FILE* f = fopen(host_path, "w");
+    if (!f) return afk_set_error(AFK_ERR_ARG, "afk_prof_dump: cannot open %s", host_path);
+    fprintf(f, "M,N,K,variant,ms\n");
+    for (size_t i = 0; i < g_prof.recs.size() && 2 * i + 1 < g_prof.used; ++i) {
+        float ms = 0.f;
+        hipEventSynchronize(g_prof.pool[2 * i + 1]);
+        hipEventElapsedTime(&ms, g_prof.pool[2 * i], g_prof.pool[2 * i + 1]);
+        fprintf(f, "%d,%d,%d,%d,%.6f\n", g_prof.recs[i].M, g_prof.recs[i].N, g_prof.recs[i].K, g_prof.recs[i].variant, ms);
+    }
+    fclose(f);
+    return AFK_OK;
 }

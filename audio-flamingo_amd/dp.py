@@ -134,6 +134,7 @@ class BackwardOverlap:
         self.side = torch.cuda.Stream(device=arena.device)
         self._done: List[bool] = []
         self.grad_scale = engine.grad_scale if engine is not None else 1.0
+        self.thin_blocks = 256  # optimizer launches of one block per CU so that they co-reside with the GEMM workgroups
 
     def begin_step(self):
         self.opt.begin_step()
@@ -153,7 +154,7 @@ class BackwardOverlap:
                 buf = self.arena.bucket_grads(i)
                 if buf.numel():
                     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.engine.pg)  # ordered on the side stream
-            self.opt.step_bucket(i, self.grad_scale)
+            self.opt.step_bucket(i, self.grad_scale, self.thin_blocks)
             self.arena.refresh_bucket_shadows(i)
 
     def finish(self):

@@ -408,9 +408,10 @@ def loss_reduce(row_loss, denom, loss, *, accumulate=False):
 
 
 # ---------------------------------------------------------------------------------------------- optimizer
-def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_blocks=0):
     _lib.call("afk_adamw_step", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), param.numel(),
-              float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+              float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+              int(max_blocks), _stream())
 
 
 def gemm_set_variant(v: int):

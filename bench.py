@@ -178,6 +178,8 @@ def main():
     waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev)
 
     overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
+    if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
+        overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
 
     def step():
         feats = frontend(waves, out_dtype=torch.bfloat16)
@@ -232,6 +234,9 @@ def main():
         ops.prof_enable(False)
         gemm_ms, gemm_flops, gemm_launches = ops.prof_collect()
         prof_steps = 1
+        if os.environ.get("AFK_PROF_DUMP"):
+            from audio_flamingo_amd import _lib
+            _lib.call("afk_prof_dump", os.environ["AFK_PROF_DUMP"].encode())
     else:
         gemm_ms, gemm_flops, gemm_launches, prof_steps = ov_ms, ov_flops, ov_launches, args.steps
     if use_dp:

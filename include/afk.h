@@ -28,6 +28,8 @@ const char* afk_last_error(void);
 int afk_prof_enable(int on);
 int afk_prof_reset(void);
 int afk_prof_collect(double* host_total_ms, double* host_total_flops, int64_t* host_launches);
+/* CSV of the profiling window: M,N,K,variant,ms per GEMM launch (host_path is a host string) */
+int afk_prof_dump(const char* host_path);
 
 /* ---- dense contraction ------------------------------------------------------------------------------
  * C[M,N] = epi(alpha * A[M,K] . B[N,K]^T)  bf16 in, fp32 MFMA accumulate, bf16 (or f32) out.
@@ -162,7 +164,7 @@ int afk_logmel(const float* wav, int W, int64_t nsamp, const float* cosb, const 
 
 /* ---- optimizer: AdamW on a flat parameter arena (bf16 param + fp32 master/m/v, 28 B/param) ------------- */
 int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream);
 
 #ifdef __cplusplus
 }
