@@ -54,6 +54,14 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// exchange with lane^32 through v_permlane32_swap (no LDS round trip): returns the partner half's value
+__device__ __forceinline__ float other_half(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = {lo: x_lo, hi: x_lo}, r[1] = {lo: x_hi, hi: x_hi}
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
 template <int D>
 __device__ __forceinline__ int swz(int r) {
     if (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
@@ -81,20 +89,38 @@ struct Tile {
             __builtin_amdgcn_global_load_lds((gbl_void*)(base + (int64_t)gr * rs + chunk * 8), (lds_void*)(img + u * 1024), 16, 0, 0);
         }
     }
-    // row fragment: row r (0..63), d = 16*ks + 8*hi .. +8
-    static __device__ __forceinline__ bf16x8 row_frag(const char* img, int r, int ks, int hi) {
-        return *(const bf16x8*)(img + r * RS + (((2 * ks + hi) ^ swz<D>(r)) << 4));
+    // Lane-constant fragment offsets.  Neither swizzle term depends on the 32-row half (kt2) or on the 16-key step (s4):
+    // adding 32 (resp. 16) rows leaves r&3, (r>>1)&1 and (r>>2)&3 unchanged, so every fragment address is
+    // "precomputed lane offset + compile-time immediate" - the loops issue ds_reads with no address VALU at all
+    // (computing the swizzles per read cost more issue slots than the MFMAs they fed).
+    struct Offs {
+        int row[KS];      // row fragment (row = lane&31 of half 0), k-step ks
+        int tr[DT][2];    // transposed fragment, d-tile dt, piece pc (s4 = 0)
+    };
+    static __device__ __forceinline__ Offs make_offs(int lane) {
+        Offs o;
+        const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) o.row[ks] = l31 * RS + (((2 * ks + hi) ^ swz<D>(l31)) << 4);
+        const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int chunk = 4 * dt + 2 * (g & 1) + ((i & 3) >> 1);
+                const int r = 4 * hi + (i >> 2) + 8 * pc;
+                o.tr[dt][pc] = r * RS + ((chunk ^ swz<D>(r)) << 4) + 8 * (i & 1);
+            }
+        return o;
+    }
+    // row fragment: row 32*kt2 + (lane&31), d = 16*ks + 8*hi .. +8
+    static __device__ __forceinline__ bf16x8 row_frag(const char* img, const Offs& o, int kt2, int ks) {
+        return *(const bf16x8*)(img + o.row[ks] + kt2 * 32 * RS);
     }
     // transposed fragment: lane holds d = 32*dt + (lane&31), rows (keys) {16*s4 + 4hi + 0..3, 16*s4 + 8 + 4hi + 0..3}
-    static __device__ __forceinline__ bf16x8 tr_frag(const char* img, int dt, int s4, int lane) {
-        const int g = lane >> 4, i = lane & 15, hi = g >> 1;
-        const int chunk = 4 * dt + 2 * (g & 1) + ((i & 3) >> 1);
-        const int r0 = 16 * s4 + 4 * hi + (i >> 2);
-        const int r1 = r0 + 8;
-        const char* p0 = img + r0 * RS + ((chunk ^ swz<D>(r0)) << 4) + 8 * (i & 1);
-        const char* p1 = img + r1 * RS + ((chunk ^ swz<D>(r1)) << 4) + 8 * (i & 1);
-        const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p0);
-        const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p1);
+    static __device__ __forceinline__ bf16x8 tr_frag(const char* img, const Offs& o, int dt, int s4) {
+        const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o.tr[dt][0] + s4 * 16 * RS));
+        const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + o.tr[dt][1] + s4 * 16 * RS));
         bf16x8 v;
         v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
         v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
@@ -111,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    const typename T::Offs offs = T::make_offs(lane);
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
     // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
     const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
@@ -131,7 +158,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
-    float m = NEG_INF, l = 0.f;
+    float m = NEG_INF, l = 0.f;  // running max in the log2 domain
+    const float c2 = p.scale * LOG2E;
 
     const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;
     const int ntiles = (kv_end_blk + 63) >> 6;
@@ -154,38 +182,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
             if (wave_live && key0 < kv_end) {  // wave-uniform
                 f32x16 st = zero16();
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) st = MFMA(T::row_frag(kimg, kt2 * 32 + l31, ks, hi), qf[ks], st);
-                float s[16];
+                for (int ks = 0; ks < KS; ++ks) st = MFMA(T::row_frag(kimg, offs, kt2, ks), qf[ks], st);
+                // softmax in the log2 domain: t = s*scale*log2(e); p = 2^(t - m).  The kernels are VALU-bound, so the mask
+                // arithmetic runs only on boundary tiles (wave-uniform test), the O rescale only when some row max moved.
+                const bool need_mask = (key0 + 32 > kv_len) || (p.causal && key0 + 31 > q0);
+                float t[16];
                 float mx = NEG_INF;
+                if (need_mask) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + ROW_OF(r, hi);
-                    const bool dead = (key >= kv_len) || (p.causal && key > q);
-                    s[r] = dead ? NEG_INF : st[r] * p.scale;
-                    mx = fmaxf(mx, s[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + ROW_OF(r, hi);
+                        const bool dead = (key >= kv_len) || (p.causal && key > q);
+                        t[r] = dead ? NEG_INF : st[r] * c2;
+                        mx = fmaxf(mx, t[r]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        t[r] = st[r] * c2;
+                        mx = fmaxf(mx, t[r]);
+                    }
                 }
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = fmaxf(mx, other_half(mx));
                 const float m_new = fmaxf(m, mx);
                 const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                const float alpha = __expf(m - m_use);
                 float rs = 0.f;
                 bf16x8 pb[2];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __expf(s[r] - m_use);
+                    const float pv = __builtin_amdgcn_exp2f(t[r] - m_use);
                     rs += pv;
                     pb[r >> 3][r & 7] = (bf16)pv;
                 }
-                rs += __shfl_xor(rs, 32, 64);
-                l = l * alpha + rs;
+                rs += other_half(rs);
+                if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {  // some row's running max moved: rescale (rare after the first tiles)
+                    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+                    l *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                }
+                l += rs;
                 m = m_new;
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = MFMA(T::tr_frag(vimg, dt, 2 * kt2 + s2, lane), pb[s2], oacc[dt]);
-                }
+                    for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = MFMA(T::tr_frag(vimg, offs, dt, 2 * kt2 + s2), pb[s2], oacc[dt]);
             }
         }
         __syncthreads();
@@ -202,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[dt][4 * qd + e] * inv);
                 *(bf16x4*)(Op + dt * 32 + 8 * qd + 4 * hi) = o;
             }
-        if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? m + __logf(l) : NEG_INF;
+        if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? m + __log2f(l) : NEG_INF;  // log2 domain (internal to the v2 kernels)
     }
 }
 
@@ -215,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    const typename T::Offs offs = T::make_offs(lane);
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
     // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
     const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
@@ -232,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         qf[ks] = *(const bf16x8*)(Qp + ks * 16);
         dof[ks] = *(const bf16x8*)(dOp + ks * 16);
     }
-    const float lse = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];
+    const float c2 = p.scale * LOG2E;
+    const float lse2 = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];  // already in the log2 domain
     const float dlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];
     const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
     const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
@@ -263,21 +308,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
                 f32x16 st = zero16(), dp = zero16();
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    st = MFMA(T::row_frag(kimg, kt2 * 32 + l31, ks, hi), qf[ks], st);
-                    dp = MFMA(T::row_frag(vimg, kt2 * 32 + l31, ks, hi), dof[ks], dp);
+                    st = MFMA(T::row_frag(kimg, offs, kt2, ks), qf[ks], st);
+                    dp = MFMA(T::row_frag(vimg, offs, kt2, ks), dof[ks], dp);
                 }
                 bf16x8 dsb[2];
+                const bool need_mask = (key0 + 32 > kv_len) || (p.causal && key0 + 31 > q0);
+                if (need_mask) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + ROW_OF(r, hi);
-                    const bool dead = (key >= kv_len) || (p.causal && key > q);
-                    const float pv = dead ? 0.f : __expf(st[r] * p.scale - lse);
-                    dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - dlt) * p.scale);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + ROW_OF(r, hi);
+                        const bool dead = (key >= kv_len) || (p.causal && key > q);
+                        const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - lse2);
+                        dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - dlt));
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - lse2);
+                        dsb[r >> 3][r & 7] = (bf16)(pv * (dp[r] - dlt));
+                    }
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) dqacc[dt] = MFMA(T::tr_frag(kimg, dt, 2 * kt2 + s2, lane), dsb[s2], dqacc[dt]);
+                    for (int s2 = 0; s2 < 2; ++s2) dqacc[dt] = MFMA(T::tr_frag(kimg, offs, dt, 2 * kt2 + s2), dsb[s2], dqacc[dt]);
             }
         }
         __syncthreads();
@@ -290,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
             for (int qd = 0; qd < 4; ++qd) {
                 bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)dqacc[dt][4 * qd + e];
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dqacc[dt][4 * qd + e] * p.scale);  // softmax scale folded out of dS
                 *(bf16x4*)(dQp + dt * 32 + 8 * qd + 4 * hi) = o;
             }
     }
@@ -306,6 +360,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
+    const typename T::Offs offs = T::make_offs(lane);
     const int b = blockIdx.z, group = p.Hq / p.Hkv;
     const int hy = blockIdx.y;
     const int hk = p.split_heads ? hy / group : hy;
@@ -318,6 +373,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
     const bool wave_live = key0 < p.S;
     const bool key_dead = key >= kv_len;
+    const float c2 = p.scale * LOG2E;
 
     const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
     const bf16* Vp = p.V + b * p.v_bs + hk * p.v_hs + (int64_t)keyc * p.v_rs + hi * 8;
@@ -376,31 +432,42 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
                 f32x16 st = zero16(), dp = zero16();
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    st = MFMA(T::row_frag(qimg, qt2 * 32 + l31, ks, hi), HOIST ? kf[HOIST ? ks : 0] : *(const bf16x8*)(Kp + ks * 16), st);
-                    dp = MFMA(T::row_frag(doimg, qt2 * 32 + l31, ks, hi), HOIST ? vf[HOIST ? ks : 0] : *(const bf16x8*)(Vp + ks * 16), dp);
+                    st = MFMA(T::row_frag(qimg, offs, qt2, ks), HOIST ? kf[HOIST ? ks : 0] : *(const bf16x8*)(Kp + ks * 16), st);
+                    dp = MFMA(T::row_frag(doimg, offs, qt2, ks), HOIST ? vf[HOIST ? ks : 0] : *(const bf16x8*)(Vp + ks * 16), dp);
                 }
                 bf16x8 pb[2], dsb[2];
+                const bool need_mask = (key0 + 32 > kv_len) || (qt0 + 32 > p.S) || (p.causal && key0 + 31 > qt0);
+                if (need_mask) {
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const int qq0 = qt0 + 8 * qd + 4 * hi;
-                    const f32x4 l4 = l4v[qd];
-                    const f32x4 d4 = d4v[qd];
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int qq0 = qt0 + 8 * qd + 4 * hi;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * qd + e;
-                        const int qq = qq0 + e;
-                        const bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
-                        const float pv = dead ? 0.f : __expf(st[r] * p.scale - l4[e]);
-                        pb[r >> 3][r & 7] = (bf16)pv;
-                        dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - d4[e]) * p.scale);
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * qd + e;
+                            const int qq = qq0 + e;
+                            const bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
+                            const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(st[r] * c2 - l4v[qd][e]);
+                            pb[r >> 3][r & 7] = (bf16)pv;
+                            dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - d4v[qd][e]));
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * qd + e;
+                            const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - l4v[qd][e]);
+                            pb[r >> 3][r & 7] = (bf16)pv;
+                            dsb[r >> 3][r & 7] = (bf16)(pv * (dp[r] - d4v[qd][e]));
+                        }
                 }
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        dvacc[dt] = MFMA(T::tr_frag(doimg, dt, 2 * qt2 + s2, lane), pb[s2], dvacc[dt]);
-                        dkacc[dt] = MFMA(T::tr_frag(qimg, dt, 2 * qt2 + s2, lane), dsb[s2], dkacc[dt]);
+                        dvacc[dt] = MFMA(T::tr_frag(doimg, offs, dt, 2 * qt2 + s2), pb[s2], dvacc[dt]);
+                        dkacc[dt] = MFMA(T::tr_frag(qimg, offs, dt, 2 * qt2 + s2), dsb[s2], dkacc[dt]);
                     }
             }
         }
@@ -416,7 +483,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
                 bf16x4 ok, ov;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ok[e] = (bf16)dkacc[dt][4 * qd + e];
+                    ok[e] = (bf16)(dkacc[dt][4 * qd + e] * p.scale);  // softmax scale folded out of dS
                     ov[e] = (bf16)dvacc[dt][4 * qd + e];
                 }
                 *(bf16x4*)(dKp + dt * 32 + 8 * qd + 4 * hi) = ok;

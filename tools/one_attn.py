@@ -1,0 +1,14 @@
+"""attention driver for rocprofv3 PMC passes: python tools/one_attn.py enc|dec reps"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from audio_flamingo_amd import ops
+which, reps = sys.argv[1], int(sys.argv[2])
+B, S, Hq, Hkv, D, causal = (8, 1500, 20, 20, 64, False) if which == "enc" else (8, 1024, 28, 4, 128, True)
+dev = torch.device("cuda")
+qkv = (torch.randn((B * S, (Hq + 2 * Hkv) * D), device=dev) * 0.5).to(torch.bfloat16)
+do = (torch.randn((B * S, Hq * D), device=dev) * 0.5).to(torch.bfloat16)
+for _ in range(reps):
+    o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal)
+    ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal)
+torch.cuda.synchronize()
