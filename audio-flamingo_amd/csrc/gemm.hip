@@ -146,6 +146,7 @@ struct ProfState {
 };
 ProfState g_prof;
 int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256
+int g_gm = 0;       // rasterization group height override (0 = default 8)
 
 hipEvent_t prof_next_event() {
     if (g_prof.used == g_prof.pool.size()) {
@@ -159,6 +160,10 @@ hipEvent_t prof_next_event() {
 }  // namespace
 
 extern "C" int afk_gemm_set_variant(int v) {
+    // v = base + 16*exp + 256*gm : experiment bits / group height are tuning knobs of tools/bench_gemm.py
+    g_gemm256_exp = (v >> 4) & 15;
+    g_gm = (v >> 8) & 255;
+    v &= 15;
     AFK_REQUIRE(v >= 0 && v <= 2, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
     g_variant = v;
     return AFK_OK;
@@ -227,6 +232,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.flags = flags;
     p.res_mod = res_mod;
     p.alpha = alpha;
+    p.gm = g_gm;
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
     const bool use256 = trans_b || g_variant == 2 || (g_variant == 0 && tiles256 >= 192);

@@ -45,6 +45,7 @@ constexpr int LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
+template <int V>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -171,11 +172,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) af[i][s] = *(const bf16x8*)(buf + a_row0 + i * 32 * ROWB + koffb[s]);
-        AFK_LGKMCNT0();
+        if (!(V & 1)) AFK_LGKMCNT0();
         AFK_VMCNT(6);
         AFK_BARRIER();
         // ================= MFMA_a(t) (+ Y(t+1): 2 pieces)
-        __builtin_amdgcn_s_setprio(1);
+        if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
         AFK_MFMA4(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_global_load_lds((gbl_void*)(ysrc[0] + oy), (lds_void*)(by + ydst[0]), 16, 0, 0);
@@ -194,11 +195,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) af[i][s] = *(const bf16x8*)(buf + a_row0 + (i + 2) * 32 * ROWB + koffb[s]);
-        AFK_LGKMCNT0();
+        if (!(V & 1)) AFK_LGKMCNT0();
         AFK_VMCNT(2);
         AFK_BARRIER();
         // ================= MFMA_b(t) (+ X(t+2): 6 pieces)
-        __builtin_amdgcn_s_setprio(1);
+        if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -244,14 +245,25 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
 }  // namespace
 
+int g_gemm256_exp = 0;  // experiment selector (tools/bench only)
+
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_k256, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
+        bool ok = true;
+        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
+        if (!ok) return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
         attr_set = true;
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
-    hipLaunchKernelGGL(gemm_nt_bf16_k256, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+    switch (g_gemm256_exp & 3) {
+        case 1: hipLaunchKernelGGL(gemm_nt_bf16_k256<1>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
+        case 2: hipLaunchKernelGGL(gemm_nt_bf16_k256<2>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
+        case 3: hipLaunchKernelGGL(gemm_nt_bf16_k256<3>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
+        default: hipLaunchKernelGGL(gemm_nt_bf16_k256<0>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
+    }
     return AFK_OK;
 }

@@ -16,6 +16,7 @@ struct GemmArgs {
     int flags;
     int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
     float alpha;
+    int gm;  // M-tiles per rasterization group (L2 locality)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -26,8 +27,8 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, int& tn) {
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GM = 8;
+    const int swz = (p.gm & 0x80) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bit 7 of gm: raw dispatch order (experiment)
+    const int GM = (p.gm & 0x7f) > 0 ? (p.gm & 0x7f) : 4;
     const int per_group = GM * p.ntn;
     const int g = swz / per_group, rem = swz - g * per_group;
     const int first_m = g * GM;
@@ -94,5 +95,6 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, i
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
+extern int g_gemm256_exp;
 // transposed-operand variants (gemm256t.hip): NN (trans_a = 0) and TN (trans_a = 1); B is reduction-major in both
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st);

@@ -177,6 +177,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
         self._at, self._pj, self._lm = at, pj, lm
         self._rope_cache = {}
+        self.gradient_checkpointing = False
         if init_seed is not None:
             self.init_weights(init_seed)
         self.training = True
@@ -220,6 +221,21 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             self._rope_cache[S] = (emb.cos().to(torch.bfloat16).contiguous(), emb.sin().to(torch.bfloat16).contiguous())
         return self._rope_cache[S]
 
+    # per-layer activation checkpointing (oracle: GradientCheckpointingLayer.__call__, transformers/modeling_layers.py:79-114,
+    # switched on by gradient_checkpointing_enable, modeling_utils.py:3187): each transformer layer re-runs its forward in backward
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        self.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
+    def _layer(self, fn, *args):
+        if self.gradient_checkpointing and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+
+            return checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
+
     def _require_hip(self):
         if self.device_.type != "cuda" or not torch.cuda.is_available():
             raise AfkError("audio_flamingo_amd: forward needs a HIP device (MI355X); this package has no CPU arithmetic path")
@@ -257,7 +273,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                                 self.embed_positions.data, W, T, C)
         for i in range(self.enc_layers):
             p = f"{at}layers.{i}."
-            x = F_.EncoderLayerFn.apply(x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len)
+            x = self._layer(F_.EncoderLayerFn.apply, x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len)
         T3 = T2 // 2
         x = F_.PoolNormFn.apply(x, self._anchor(at + "layer_norm.weight"), a, at + "layer_norm.weight", at + "layer_norm.bias", W * T3)
         x = F_.ProjectorFn.apply(x, self._anchor(self._pj + "linear_1.weight"), a, self._pj)
@@ -310,8 +326,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         audio_hidden = audio
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
-            x = F_.DecoderLayerFn.apply(x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
-                                        self.rms_eps, cos, sin, pos, kv_len)
+            x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
+                            self.rms_eps, cos, sin, pos, kv_len)
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
         loss, logits = None, None
         if labels is not None:

@@ -187,6 +187,45 @@ def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
             assert torch.equal(ma.arena.shadow(k), mb.arena.shadow(k)), f"stale W^T shadow for {k}"
 
 
+def test_gradient_checkpointing_matches(dev):
+    """per-layer recompute (oracle row a19) must not change loss or gradients"""
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    ma, mb = _model(dev), _model(dev)
+    mb.gradient_checkpointing_enable()
+    ma.zero_grad(), mb.zero_grad()
+    la, lb = ma(**kw).loss, mb(**kw).loss
+    la.backward(), lb.backward()
+    torch.cuda.synchronize()
+    assert float(la) == float(lb)
+    assert torch.equal(ma.arena.grads, mb.arena.grads)
+
+
+def test_long_audio_shape_config5_like(dev):
+    """several windows per sample and a long decoder sequence (BASELINE config 5 shape, scaled): 4 windows -> 3000 <sound> tokens"""
+    from oracle import af3_oracle as O
+
+    torch.manual_seed(11)
+    sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
+    m = _model(dev)
+    m.gradient_checkpointing_enable()
+    feats = (torch.randn(4, 128, 3000) * 0.5).to(torch.bfloat16)
+    S = 9 + 3000 + 9 + 40
+    ids = torch.randint(0, 1000, (1, S))
+    ids[0, 9:3009] = 1023
+    labels = torch.full((1, S), -100)
+    labels[:, -40:] = ids[:, -40:]
+    with torch.no_grad():
+        ref = O.forward({k: v.float() for k, v in sd.items()}, dict(enc_heads=4, heads=4, kv_heads=2, eps=1e-6, theta=10000.0, audio_token_id=1023),
+                        ids, feats.float(), None, labels=labels)
+    out = m(input_ids=ids.to(dev), input_features=feats.to(dev), labels=labels.to(dev), return_logits=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    err = float((out.logits.float().cpu() - ref["logits"]).abs().max())
+    assert abs(float(out.loss) - float(ref["loss"])) <= 1e-2 and err <= LOGIT_TOL, (float(out.loss), float(ref["loss"]), err)
+    assert torch.isfinite(m.arena.grads.float()).all()
+
+
 def test_smoke_entry(dev):
     import __graft_entry__ as ge
 
