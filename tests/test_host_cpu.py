@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
         g.build()
     protos = _lib.prototypes()
-    assert len(protos) >= 38
+    assert len(protos) >= 46
     lib = _lib.load()
     for name in protos:
         assert hasattr(lib, name), name
