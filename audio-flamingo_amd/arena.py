@@ -60,6 +60,7 @@ class Arena:
         # dgrad and wgrad of a layer are independent given dY, so running them on two streams lets one GEMM's blocks fill
         # the partially empty last wave of the other (448-tile GEMMs leave 25 % of the CUs idle in their second round)
         self.wgrad_stream: Optional[torch.cuda.Stream] = None
+        self.thin_blocks = 0  # grid cap for the transposes issued on the wgrad stream (0 = full grid)
 
     # ------------------------------------------------------------------ layout
     def new_bucket(self, name: str) -> int:

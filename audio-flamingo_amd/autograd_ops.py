@@ -1,0 +1,202 @@
+"""Stand-alone autograd wrappers over the afk kernels (one op = one Function, gradients returned as tensors).
+
+The AF3 path (functional.py) uses layer-level Functions that write weight gradients straight into the arena; the ops here
+are the general-purpose form of the same kernels, used by the Flamingo blocks of BASELINE config 4 (flamingo.py).  The
+backward of ``linear`` runs on the transposed-operand MFMA kernels (NN dgrad, TN wgrad): no transposed copies.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from .ops import BF16, _p, _stream
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual):
+        y = ops.gemm_nt(x, w, bias=b, residual=residual)
+        ctx.save_for_backward(x, w)
+        ctx.has_b, ctx.has_r = b is not None, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gemm(dy, w, trans_b=True)                      # dX = dY . W
+        dw = ops.gemm(dy, x, trans_a=True, trans_b=True)        # dW = dY^T . X
+        db = None
+        if ctx.has_b:
+            db = torch.empty(w.shape[0], device=dy.device, dtype=BF16)
+            ops.colsum(dy, db)
+        return dx, dw, db, (dy if ctx.has_r else None)
+
+
+def linear(x, w, b=None, residual=None):
+    """y = x @ w^T (+ b) (+ residual)   x [M, K], w [N, K]"""
+    return _Linear.apply(x, w, b, residual)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, w, b, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        dw, db = torch.empty_like(w), torch.empty_like(w)
+        dx = ops.layernorm_bwd(x, w, dy.contiguous(), mean, rstd, dw, db)
+        return dx, dw, db, None
+
+
+def layer_norm(x, w, b, eps=1e-5):
+    return _LayerNorm.apply(x, w, b, eps)
+
+
+class _RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        y, rstd = ops.rmsnorm_fwd(x, w, eps)
+        ctx.save_for_backward(x, w, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, rstd = ctx.saved_tensors
+        dw = torch.empty_like(w)
+        dx = ops.rmsnorm_bwd(x, w, dy.contiguous(), rstd, dw)
+        return dx, dw, None
+
+
+def rms_norm(x, w, eps=1e-6):
+    return _RMSNorm.apply(x, w, eps)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _lib.call("afk_relu_fwd", x.data_ptr(), y.data_ptr(), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _lib.call("afk_relu_bwd", dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _stream())
+        return dx
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+class _SiluMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gu):
+        ctx.save_for_backward(gu)
+        return ops.silu_mul_fwd(gu)
+
+    @staticmethod
+    def backward(ctx, dh):
+        (gu,) = ctx.saved_tensors
+        return ops.silu_mul_bwd(gu, dh.contiguous())
+
+
+def silu_mul(gu):
+    """[rows, 2I] (gate | up) -> silu(gate) * up"""
+    return _SiluMul.apply(gu)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add(a, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _Gate(torch.autograd.Function):
+    """y = x + tanh(alpha) * (gate[row] ? h : 0)   (IdeficsGatedCrossAttentionLayer, modeling_idefics.py:792-793,800)"""
+
+    @staticmethod
+    def forward(ctx, x, h, alpha, gate):
+        rows, D = x.shape
+        y = torch.empty_like(x)
+        vec = int(alpha.numel() == D and D > 1)
+        _lib.call("afk_gate_fwd", x.data_ptr(), h.data_ptr(), alpha.data_ptr(), vec, _p(gate), y.data_ptr(), rows, D, _stream())
+        ctx.save_for_backward(h, alpha, gate)
+        ctx.vec = vec
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, alpha, gate = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, D = dy.shape
+        dh = torch.empty_like(dy)
+        ns = _lib.load().afk_colsum_slices(rows)
+        fws = torch.empty((ns + 1) * D, device=dy.device, dtype=torch.float32)
+        dalpha = torch.empty_like(alpha)
+        _lib.call("afk_gate_bwd", dy.data_ptr(), h.data_ptr(), alpha.data_ptr(), ctx.vec, _p(gate), dh.data_ptr(),
+                  fws.data_ptr(), dalpha.data_ptr(), 0, rows, D, _stream())
+        return dy, dh, dalpha, None
+
+
+def gated_residual(x, h, alpha, gate=None):
+    return _Gate.apply(x, h, alpha, gate)
+
+
+class _XAttn(torch.autograd.Function):
+    """softmax(q k^T * scale + segment mask) v with Sq != Sk; q [B*Sq, H*D], k / v [B*Sk, H*D]; krange int32 [B, Sq, 2] or None"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, krange, B, Sq, Sk, H, D, scale):
+        sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
+        vt = ops.transpose_heads(v, B, Sk, H, D, v.stride(0), skp)
+        o = torch.empty((B * Sq, H * D), device=q.device, dtype=BF16)
+        lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+        _lib.call("afk_xattn_fwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
+                  vt.data_ptr(), o.data_ptr(), Sq * H * D, D, H * D, lse.data_ptr(), 0, _p(krange), B, H, H, Sq, Sk, sqp, skp, D,
+                  float(scale), _stream())
+        ctx.save_for_backward(q, k, v, o, lse, krange)
+        ctx.meta = (B, Sq, Sk, H, D, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, krange = ctx.saved_tensors
+        B, Sq, Sk, H, D, scale = ctx.meta
+        do = do.contiguous()
+        dev = q.device
+        sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
+        ldo = H * D
+        delta = torch.empty((B, H, Sq), device=dev, dtype=torch.float32)
+        _lib.call("afk_attn_delta", o.data_ptr(), Sq * ldo, D, ldo, do.data_ptr(), Sq * ldo, D, ldo, delta.data_ptr(), B, H, Sq, D, _stream())
+        qt = ops.transpose_heads(q, B, Sq, H, D, q.stride(0), sqp)
+        kt = ops.transpose_heads(k, B, Sk, H, D, k.stride(0), skp)
+        dot = ops.transpose_heads(do, B, Sq, H, D, ldo, sqp)
+        dq = torch.empty((B * Sq, H * D), device=dev, dtype=BF16)
+        dk = torch.empty((B * Sk, H * D), device=dev, dtype=BF16)
+        dv = torch.empty((B * Sk, H * D), device=dev, dtype=BF16)
+        _lib.call("afk_xattn_bwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
+                  v.data_ptr(), Sk * v.stride(0), D, v.stride(0), do.data_ptr(), Sq * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(),
+                  dot.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Sq * ldo, D, ldo, dk.data_ptr(), Sk * ldo, D, ldo,
+                  dv.data_ptr(), Sk * ldo, D, ldo, 0, _p(krange), B, H, H, Sq, Sk, sqp, skp, D, float(scale), _stream())
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def cross_attention(q, k, v, *, B, Sq, Sk, H, D, scale, krange=None):
+    return _XAttn.apply(q, k, v, krange, B, Sq, Sk, H, D, scale)

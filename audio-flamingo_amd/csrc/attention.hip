@@ -35,7 +35,9 @@ struct AttnArgs {
     float* LSE;          // [B, Hq, S]
     const float* delta;  // [B, Hq, S]
     const int* kv_len;   // [B] or null
-    int B, Hq, Hkv, S, Spad;
+    const int* krange;   // [B, S, 2] = per-query [key_begin, key_end) or null (cross-attention segment masks)
+    int B, Hq, Hkv, S, Spad;   // S / Spad: QUERY length (and pitch of Qt / dOt / LSE / delta)
+    int Sk, Skpad;             // KEY length (and pitch of Kt / Vt); == S, Spad for self-attention
     float scale;
     int causal;
 };
@@ -71,7 +73,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     if (q0 >= p.S) return;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
-    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    int kb = 0, ke = p.Sk;
+    if (p.krange) {
+        kb = p.krange[((int64_t)b * p.S + qc) * 2];
+        ke = p.krange[((int64_t)b * p.S + qc) * 2 + 1];
+    }
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     bf16x8 qf[KS];
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     for (int ks = 0; ks < KS; ++ks) qf[ks] = ld8(Qp + ks * 16);
 
     const bf16* Kb = p.K + b * p.k_bs + hk * p.k_hs + hi * 8;
-    const bf16* Vtb = p.Vt + ((int64_t)(b * p.Hkv + hk) * D + l31) * p.Spad + 4 * hi;
+    const bf16* Vtb = p.Vt + ((int64_t)(b * p.Hkv + hk) * D + l31) * p.Skpad + 4 * hi;
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int ntiles = (kv_end + 31) >> 5;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 32;
-        const int krow = min(key0 + l31, p.S - 1);
+        const int krow = min(key0 + l31, p.Sk - 1);
         const bf16* Kp = Kb + (int64_t)krow * p.k_rs;
         f32x16 st = zero16();
 #pragma unroll
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + ROW_OF(r, hi);
-            const bool dead = (key >= kv_len) || (p.causal && key > q);
+            const bool dead = (key >= kv_len) || (p.causal && key > q) || (key < kb) || (key >= ke);
             s[r] = dead ? NEG_INF : st[r] * p.scale;
             mx = fmaxf(mx, s[r]);
         }
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             for (int e = 0; e < 8; ++e) pb[s2][e] = (bf16)pr[8 * s2 + e];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const bf16* vp = Vtb + (int64_t)dt * 32 * p.Spad + key0;
+            const bf16* vp = Vtb + (int64_t)dt * 32 * p.Skpad + key0;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = MFMA(ld4x2(vp + 16 * s2, vp + 16 * s2 + 8), pb[s2], oacc[dt]);
         }
@@ -187,10 +194,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, hk = blockIdx.y, group = p.Hq / p.Hkv;
     const int key0 = blockIdx.x * 128 + wave * 32;
-    if (key0 >= p.S) return;
+    if (key0 >= p.Sk) return;
     const int key = key0 + l31;
-    const int keyc = min(key, p.S - 1);
-    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int keyc = min(key, p.Sk - 1);
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
 
     const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
     const bf16* Vp = p.V + b * p.v_bs + hk * p.v_hs + (int64_t)keyc * p.v_rs + hi * 8;
@@ -227,8 +234,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = qt0 + ROW_OF(r, hi);
-                const bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
                 const int qi = min(qq, p.S - 1);
+                bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
+                if (p.krange) dead = dead || key < p.krange[((int64_t)b * p.S + qi) * 2] || key >= p.krange[((int64_t)b * p.S + qi) * 2 + 1];
                 const float pv = dead ? 0.f : __expf(st[r] * p.scale - lse[qi]);
                 const float dsv = pv * (dp[r] - dlt[qi]) * p.scale;
                 pb[r >> 3][r & 7] = (bf16)pv;
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
             }
         }
     }
-    if (key < p.S) {
+    if (key < p.Sk) {
         bf16* dKp = p.dK + b * p.dk_bs + hk * p.dk_hs + (int64_t)key * p.dk_rs;
         bf16* dVp = p.dV + b * p.dv_bs + hk * p.dv_hs + (int64_t)key * p.dv_rs;
 #pragma unroll
@@ -276,7 +284,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     if (q0 >= p.S) return;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
-    const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int kv_len = p.kv_len ? min(p.kv_len[b], p.Sk) : p.Sk;
+    int kb = 0, ke = p.Sk;
+    if (p.krange) {
+        kb = p.krange[((int64_t)b * p.S + qc) * 2];
+        ke = p.krange[((int64_t)b * p.S + qc) * 2 + 1];
+    }
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     const bf16* dOp = p.dO + b * p.do_bs + h * p.do_hs + (int64_t)qc * p.do_rs + hi * 8;
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const float dlt = p.delta[((int64_t)b * p.Hq + h) * p.S + qc];
     const bf16* Kb = p.K + b * p.k_bs + hk * p.k_hs + hi * 8;
     const bf16* Vb = p.V + b * p.v_bs + hk * p.v_hs + hi * 8;
-    const bf16* Ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D + l31) * p.Spad + 4 * hi;
+    const bf16* Ktb = p.Kt + ((int64_t)(b * p.Hkv + hk) * D + l31) * p.Skpad + 4 * hi;
 
     f32x16 dqacc[DT];
 #pragma unroll
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const int ntiles = (kv_end + 31) >> 5;
     for (int kt = 0; kt < ntiles; ++kt) {
         const int key0 = kt * 32;
-        const int krow = min(key0 + l31, p.S - 1);
+        const int krow = min(key0 + l31, p.Sk - 1);
         const bf16* Kp = Kb + (int64_t)krow * p.k_rs;
         const bf16* Vp = Vb + (int64_t)krow * p.v_rs;
         f32x16 st = zero16(), dp = zero16();
@@ -313,13 +326,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + ROW_OF(r, hi);
-            const bool dead = (key >= kv_len) || (p.causal && key > q);
+            const bool dead = (key >= kv_len) || (p.causal && key > q) || (key < kb) || (key >= ke);
             const float pv = dead ? 0.f : __expf(st[r] * p.scale - lse);
             dsb[r >> 3][r & 7] = (bf16)(pv * (dp[r] - dlt) * p.scale);
         }
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const bf16* kp = Ktb + (int64_t)dt * 32 * p.Spad + key0;
+            const bf16* kp = Ktb + (int64_t)dt * 32 * p.Skpad + key0;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) dqacc[dt] = MFMA(ld4x2(kp + 16 * s2, kp + 16 * s2 + 8), dsb[s2], dqacc[dt]);
         }
@@ -361,7 +374,7 @@ extern "C" int afk_attn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
     p.Vt = (const bf16*)Vt;
     p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
     p.LSE = LSE; p.kv_len = kv_len;
-    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.Sk = S; p.Skpad = Spad; p.scale = scale; p.causal = causal;
     dim3 grid((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, st, p);
@@ -405,7 +418,7 @@ extern "C" int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
     p.dV = (bf16*)dV; p.dv_bs = dv_bs; p.dv_hs = dv_hs; p.dv_rs = dv_rs;
     p.Qt = (const bf16*)Qt; p.Kt = (const bf16*)Kt; p.dOt = (const bf16*)dOt;
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len;
-    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.Sk = S; p.Skpad = Spad; p.scale = scale; p.causal = causal;
     hipStream_t st = (hipStream_t)stream;
     dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)Hkv, (unsigned)B);
     dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
@@ -420,5 +433,68 @@ extern "C" int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
         hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, st, p);
     }
     AFK_LAUNCH_CHECK("afk_attn_bwd");
+    return AFK_OK;
+}
+
+// ---- cross-attention form: Sq != Sk, optional per-query key range (block-diagonal "attend only to your own media segment"
+// masks of the Flamingo gated cross-attention, BASELINE config 4).  Qt/dOt/LSE/delta use the query pitch, Kt/Vt the key pitch.
+extern "C" int afk_xattn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* Vt, void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, float* LSE,
+                             const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk, int Sqpad, int Skpad,
+                             int D, float scale, void* stream) {
+    AFK_REQUIRE(Q && K && Vt && O && LSE, "afk_xattn_fwd: null pointer");
+    if (int e = check_common("afk_xattn_fwd", B, Hq, Hkv, Sq, Sqpad, D)) return e;
+    if (int e = check_common("afk_xattn_fwd", B, Hq, Hkv, Sk, Skpad, D)) return e;
+    AttnArgs p = {};
+    p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+    p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+    p.Vt = (const bf16*)Vt;
+    p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
+    p.LSE = LSE; p.kv_len = kv_len; p.krange = krange;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = Sq; p.Spad = Sqpad; p.Sk = Sk; p.Skpad = Skpad; p.scale = scale; p.causal = 0;
+    dim3 grid((unsigned)afk_cdiv(Sq, 128), (unsigned)Hq, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, st, p);
+    else if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, p);
+    AFK_LAUNCH_CHECK("afk_xattn_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_xattn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO,
+                             int64_t do_bs, int64_t do_hs, int64_t do_rs, const void* Qt, const void* Kt, const void* dOt,
+                             const float* LSE, const float* delta, void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs,
+                             void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV, int64_t dv_bs, int64_t dv_hs,
+                             int64_t dv_rs, const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk,
+                             int Sqpad, int Skpad, int D, float scale, void* stream) {
+    AFK_REQUIRE(Q && K && V && dO && Qt && Kt && dOt && LSE && delta && dQ && dK && dV, "afk_xattn_bwd: null pointer");
+    if (int e = check_common("afk_xattn_bwd", B, Hq, Hkv, Sq, Sqpad, D)) return e;
+    if (int e = check_common("afk_xattn_bwd", B, Hq, Hkv, Sk, Skpad, D)) return e;
+    AttnArgs p = {};
+    p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+    p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+    p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
+    p.dO = (const bf16*)dO; p.do_bs = do_bs; p.do_hs = do_hs; p.do_rs = do_rs;
+    p.dQ = (bf16*)dQ; p.dq_bs = dq_bs; p.dq_hs = dq_hs; p.dq_rs = dq_rs;
+    p.dK = (bf16*)dK; p.dk_bs = dk_bs; p.dk_hs = dk_hs; p.dk_rs = dk_rs;
+    p.dV = (bf16*)dV; p.dv_bs = dv_bs; p.dv_hs = dv_hs; p.dv_rs = dv_rs;
+    p.Qt = (const bf16*)Qt; p.Kt = (const bf16*)Kt; p.dOt = (const bf16*)dOt;
+    p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len; p.krange = krange;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = Sq; p.Spad = Sqpad; p.Sk = Sk; p.Skpad = Skpad; p.scale = scale; p.causal = 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gkv((unsigned)afk_cdiv(Sk, 128), (unsigned)Hkv, (unsigned)B);
+    dim3 gq((unsigned)afk_cdiv(Sq, 128), (unsigned)Hq, (unsigned)B);
+    if (D == 128) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<128>, gkv, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
+    } else if (D == 64) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<64>, gkv, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, gq, dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<32>, gkv, dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, gq, dim3(256), 0, st, p);
+    }
+    AFK_LAUNCH_CHECK("afk_xattn_bwd");
     return AFK_OK;
 }

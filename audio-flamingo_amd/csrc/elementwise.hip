@@ -17,47 +17,56 @@ inline int ew_grid(int64_t n_items, int per_block) {
 // out[b1][b2][c][r] = in[b1][b2][r][c], r < R, c < C; columns R..Rpad-1 of out are zero-filled so that the
 // transposed operand can be fed to the NT GEMM with K padded to a multiple of 64.
 // 64x64 tile through LDS: 16-byte row reads, 2-byte conflict-free column writes to LDS, 16-byte row writes out.
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int R, int C,
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16* __restrict__ in0, bf16* __restrict__ out0, int R, int C,
                                                         int Rpad, int64_t ld_in, int64_t ld_out, int nb2,
-                                                        int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out) {
+                                                        int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out,
+                                                        int tiles_x, int tiles_y, int64_t ntiles) {
     __shared__ bf16 tile[64][66];  // tile[c][r], +2 pad: column writes hit distinct banks
-    const int b = blockIdx.z, b1 = b / nb2, b2 = b - b1 * nb2;
-    in += b1 * bs1_in + b2 * bs2_in;
-    out += b1 * bs1_out + b2 * bs2_out;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int t = threadIdx.x;
-    // load: 64 rows x 8 chunks of 8 bf16 = 512 chunks, 2 per thread
+    // persistent over tiles: a capped grid ("thin" launch, one block per CU) can stay resident beside the 2 x 224-VGPR GEMM
+    // workgroups of the other stream instead of flooding every CU at a kernel boundary
+    for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        const int bx = (int)(tix % tiles_x);
+        const int by = (int)((tix / tiles_x) % tiles_y);
+        const int b = (int)(tix / ((int64_t)tiles_x * tiles_y));
+        const int b1 = b / nb2, b2 = b - b1 * nb2;
+        const bf16* in = in0 + b1 * bs1_in + b2 * bs2_in;
+        bf16* out = out0 + b1 * bs1_out + b2 * bs2_out;
+        const int r0 = by * 64, c0 = bx * 64;
+        // load: 64 rows x 8 chunks of 8 bf16 = 512 chunks, 2 per thread
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int idx = t + 256 * k;
-        const int r = idx >> 3, ch = idx & 7;
-        const int gr = r0 + r, gc = c0 + ch * 8;
-        bf16x8 v;
-        if (gr < R && gc + 7 < C) {
-            v = *(const bf16x8*)(in + (int64_t)gr * ld_in + gc);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (gr < R && gc + e < C) ? in[(int64_t)gr * ld_in + gc + e] : (bf16)0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) tile[ch * 8 + e][r] = v[e];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int idx = t + 256 * k;
-        const int c = idx >> 3, ch = idx & 7;
-        const int gc = c0 + c, gr = r0 + ch * 8;
-        if (gc < C && gr < Rpad) {
+        for (int k = 0; k < 2; ++k) {
+            const int idx = t + 256 * k;
+            const int r = idx >> 3, ch = idx & 7;
+            const int gr = r0 + r, gc = c0 + ch * 8;
             bf16x8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tile[c][ch * 8 + e];
-            if (gr + 7 < Rpad) {
-                *(bf16x8*)(out + (int64_t)gc * ld_out + gr) = v;
+            if (gr < R && gc + 7 < C) {
+                v = *(const bf16x8*)(in + (int64_t)gr * ld_in + gc);
             } else {
-                for (int e = 0; e < 8 && gr + e < Rpad; ++e) out[(int64_t)gc * ld_out + gr + e] = v[e];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (gr < R && gc + e < C) ? in[(int64_t)gr * ld_in + gc + e] : (bf16)0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[ch * 8 + e][r] = v[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int idx = t + 256 * k;
+            const int c = idx >> 3, ch = idx & 7;
+            const int gc = c0 + c, gr = r0 + ch * 8;
+            if (gc < C && gr < Rpad) {
+                bf16x8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = tile[c][ch * 8 + e];
+                if (gr + 7 < Rpad) {
+                    *(bf16x8*)(out + (int64_t)gc * ld_out + gr) = v;
+                } else {
+                    for (int e = 0; e < 8 && gr + e < Rpad; ++e) out[(int64_t)gc * ld_out + gr + e] = v[e];
+                }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -519,21 +528,154 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     }
 }
 
+
+// ------------------------------------------------------------------ Flamingo glue (BASELINE config 4; stand-in oracle: Idefics)
+// ReLU (IdeficsMLP of the Perceiver resampler, perceiver.py:171-187)
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(x + 8 * i);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e] > 0.f ? v[e] : (bf16)0.f;
+        *(bf16x8*)(y + 8 * i) = o;
+    }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dx,
+                                                       int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 d = *(const bf16x8*)(dy + 8 * i), v = *(const bf16x8*)(y + 8 * i);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (float)v[e] > 0.f ? d[e] : (bf16)0.f;
+        *(bf16x8*)(dx + 8 * i) = o;
+    }
+}
+// tanh-gated residual (IdeficsGatedCrossAttentionLayer.forward, modeling_idefics.py:792-793,800):
+//   y = x + tanh(alpha) * (gate[row] ? h : 0)      alpha: vector [D] or scalar [1]; gate: int32 [rows] or null
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ h, const bf16* __restrict__ alpha,
+                                                       int alpha_vec, const int* __restrict__ gate, bf16* __restrict__ y, int64_t rows,
+                                                       int D) {
+    const int vpr = D >> 3;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const bf16x8 xv = *(const bf16x8*)(x + r * D + 8 * v), hv = *(const bf16x8*)(h + r * D + 8 * v);
+        const bool on = gate ? gate[r] != 0 : true;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = rbf(tanhf((float)alpha[alpha_vec ? 8 * v + e : 0]));  // tanh of a bf16 parameter is a bf16 tensor in the oracle
+            const float g = on ? rbf(t * (float)hv[e]) : 0.f;
+            o[e] = (bf16)((float)xv[e] + g);
+        }
+        *(bf16x8*)(y + r * D + 8 * v) = o;
+    }
+}
+// backward: dh = dy * tanh(alpha) * gate   (d alpha comes from gate_prod_colsum_kernel)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h, const bf16* __restrict__ alpha,
+                                                       int alpha_vec, const int* __restrict__ gate, bf16* __restrict__ dh,
+                                                       int64_t rows, int D) {
+    const int vpr = D >> 3;
+    const int64_t total = rows * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int v = (int)(i % vpr);
+        const int64_t r = i / vpr;
+        const bf16x8 dv = *(const bf16x8*)(dy + r * D + 8 * v), hv = *(const bf16x8*)(h + r * D + 8 * v);
+        const bool on = gate ? gate[r] != 0 : true;
+        bf16x8 o;
+        (void)hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = rbf(tanhf((float)alpha[alpha_vec ? 8 * v + e : 0]));
+            o[e] = (bf16)(on ? (float)dv[e] * t : 0.f);
+        }
+        *(bf16x8*)(dh + r * D + 8 * v) = o;
+    }
+}
+// partial[slice][c] = sum over the slice's rows of dy*h*gate, accumulated in fp32 (the alpha gradient is a heavily cancelling
+// sum: rounding the products to bf16 first costs ~25 % relative error on the scalar-alpha form)
+__global__ __launch_bounds__(256) void gate_prod_colsum_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h,
+                                                               const int* __restrict__ gate, int64_t rows, int cols,
+                                                               float* __restrict__ partial, int rows_per_slice) {
+    __shared__ float red[32][65];
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cl * 8;
+    const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slice;
+    const int64_t r_end = min(rows, r_begin + rows_per_slice);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c0 < cols) {
+        for (int64_t r = r_begin + rl; r < r_end; r += 32) {
+            if (gate && gate[r] == 0) continue;
+            const bf16x8 a = *(const bf16x8*)(dy + r * cols + c0), b = *(const bf16x8*)(h + r * cols + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)a[e] * (float)b[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < cols) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+            partial[(int64_t)blockIdx.y * cols + c] = s;
+        }
+    }
+}
+// d alpha from the column sums cs[D] (fp32): vector: out[d] (+)= (1 - tanh^2(alpha_d)) cs[d]; scalar: out[0] (+)= (1 - tanh^2(alpha)) sum_d cs[d]
+__global__ __launch_bounds__(1024) void gate_alpha_grad_kernel(const float* __restrict__ cs, const bf16* __restrict__ alpha, int alpha_vec,
+                                                               bf16* __restrict__ out, int D, int accumulate) {
+    __shared__ float scratch[16];
+    if (alpha_vec) {
+        for (int d = threadIdx.x; d < D; d += 1024) {
+            const float t = tanhf((float)alpha[d]);
+            const float g = (1.f - t * t) * cs[d];
+            out[d] = (bf16)(accumulate ? (float)out[d] + g : g);
+        }
+    } else {
+        float s = 0.f;
+        for (int d = threadIdx.x; d < D; d += 1024) s += cs[d];
+        s = block_sum<16>(s, scratch);
+        if (threadIdx.x == 0) {
+            const float t = tanhf((float)alpha[0]);
+            const float g = (1.f - t * t) * s;
+            out[0] = (bf16)(accumulate ? (float)out[0] + g : g);
+        }
+    }
+}
+// fp32 column sums (deterministic two-stage) used by the alpha gradient
+__global__ __launch_bounds__(256) void colsum_fold_f32_kernel(const float* __restrict__ partial, int nslices, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < nslices; ++k) s += partial[(int64_t)k * cols + c];
+    out[c] = s;
+}
+
 }  // namespace
 
 // ==================================================================== C ABI
 #define ST ((hipStream_t)stream)
 
 extern "C" int afk_transpose_bf16(const void* in, void* out, int R, int C, int Rpad, int64_t ld_in, int64_t ld_out, int nb1,
-                                  int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, void* stream) {
+                                  int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, int max_blocks,
+                                  void* stream) {
     AFK_REQUIRE(in && out && R > 0 && C > 0 && Rpad >= R && nb1 > 0 && nb2 > 0, "afk_transpose_bf16: bad args");
     AFK_REQUIRE(ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) &&
                     bs1_in % 8 == 0 && bs2_in % 8 == 0 && bs1_out % 8 == 0 && bs2_out % 8 == 0,
                 "afk_transpose_bf16: 16-byte alignment required");
-    AFK_REQUIRE((int64_t)nb1 * nb2 <= 65535, "afk_transpose_bf16: batch too large");
-    dim3 grid((unsigned)afk_cdiv(C, 64), (unsigned)afk_cdiv(Rpad, 64), (unsigned)(nb1 * nb2));
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ST, (const bf16*)in, (bf16*)out, R, C, Rpad, ld_in, ld_out, nb2,
-                       bs1_in, bs2_in, bs1_out, bs2_out);
+    const int tiles_x = (int)afk_cdiv(C, 64), tiles_y = (int)afk_cdiv(Rpad, 64);
+    const int64_t ntiles = (int64_t)tiles_x * tiles_y * nb1 * nb2;
+    int64_t grid = ntiles;
+    if (grid > 65536) grid = 65536;
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)grid), dim3(256), 0, ST, (const bf16*)in, (bf16*)out, R, C, Rpad, ld_in, ld_out,
+                       nb2, bs1_in, bs2_in, bs1_out, bs2_out, tiles_x, tiles_y, ntiles);
     AFK_LAUNCH_CHECK("afk_transpose_bf16");
     return AFK_OK;
 }
@@ -721,5 +863,46 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
                        (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
     AFK_LAUNCH_CHECK("afk_adamw_step");
+    return AFK_OK;
+}
+
+extern "C" int afk_relu_fwd(const void* x, void* y, int64_t n, void* stream) {
+    AFK_REQUIRE(x && y && n % 8 == 0, "afk_relu_fwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n / 8);
+    AFK_LAUNCH_CHECK("afk_relu_fwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, void* stream) {
+    AFK_REQUIRE(dy && y && dx && n % 8 == 0, "afk_relu_bwd: n must be a multiple of 8");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)dy, (const bf16*)y, (bf16*)dx, n / 8);
+    AFK_LAUNCH_CHECK("afk_relu_bwd");
+    return AFK_OK;
+}
+
+extern "C" int afk_gate_fwd(const void* x, const void* h, const void* alpha, int alpha_is_vector, const int* gate, void* y, int64_t rows,
+                            int D, void* stream) {
+    AFK_REQUIRE(x && h && alpha && y && rows > 0 && D % 8 == 0, "afk_gate_fwd: bad args");
+    hipLaunchKernelGGL(gate_fwd_kernel, dim3(ew_grid(rows * (D / 8), 256)), dim3(256), 0, ST, (const bf16*)x, (const bf16*)h,
+                       (const bf16*)alpha, alpha_is_vector, gate, (bf16*)y, rows, D);
+    AFK_LAUNCH_CHECK("afk_gate_fwd");
+    return AFK_OK;
+}
+
+// workspace `fws` = (afk_colsum_slices(rows) + 1) * D floats
+extern "C" int afk_gate_bwd(const void* dy, const void* h, const void* alpha, int alpha_is_vector, const int* gate, void* dh,
+                            float* fws, void* dalpha, int accumulate, int64_t rows, int D, void* stream) {
+    AFK_REQUIRE(dy && h && alpha && dh && fws && dalpha && rows > 0 && D % 8 == 0, "afk_gate_bwd: bad args");
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(ew_grid(rows * (D / 8), 256)), dim3(256), 0, ST, (const bf16*)dy, (const bf16*)h,
+                       (const bf16*)alpha, alpha_is_vector, gate, (bf16*)dh, rows, D);
+    const int ns = afk_colsum_slices(rows);
+    const int rps = (int)afk_cdiv(rows, ns);
+    float* cs = fws + (int64_t)ns * D;
+    hipLaunchKernelGGL(gate_prod_colsum_kernel, dim3((unsigned)afk_cdiv(D, 64), (unsigned)ns), dim3(256), 0, ST, (const bf16*)dy,
+                       (const bf16*)h, gate, rows, D, fws, rps);
+    hipLaunchKernelGGL(colsum_fold_f32_kernel, dim3((unsigned)afk_cdiv(D, 256)), dim3(256), 0, ST, fws, ns, D, cs);
+    hipLaunchKernelGGL(gate_alpha_grad_kernel, dim3(1), dim3(1024), 0, ST, cs, (const bf16*)alpha, alpha_is_vector, (bf16*)dalpha, D,
+                       accumulate);
+    AFK_LAUNCH_CHECK("afk_gate_bwd");
     return AFK_OK;
 }

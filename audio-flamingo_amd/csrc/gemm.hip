@@ -160,8 +160,7 @@ hipEvent_t prof_next_event() {
 }  // namespace
 
 extern "C" int afk_gemm_set_variant(int v) {
-    // v = base + 16*exp + 256*gm : experiment bits / group height are tuning knobs of tools/bench_gemm.py
-    g_gemm256_exp = (v >> 4) & 15;
+    // v = base + 256*gm : the rasterization group height is a tuning knob of tools/exp_gemm.py
     g_gm = (v >> 8) & 255;
     v &= 15;
     AFK_REQUIRE(v >= 0 && v <= 2, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");

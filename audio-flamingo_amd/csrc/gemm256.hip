@@ -45,7 +45,6 @@ constexpr int LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
-template <int V>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -145,22 +144,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)          \
             acc[ACC0 + i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j_][s], af[i_][s], acc[ACC0 + i_][j_], 0, 0, 0); \
     } while (0)
-#define AFK_DMA(SRC, DST, t_)                                                                                      \
-    do {                                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-        __builtin_amdgcn_global_load_lds((gbl_void*)((SRC) + (t_) * BK), (lds_void*)(smem + ((t_) & 1) * BUF_BYTES + (DST)), 16, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                         \
-    } while (0)
     // Branch-free steady state: past the last K-tile the prefetch index is clamped to T-1, i.e. the tail re-loads the
     // last tile into slots nobody reads again (dead by the same lifetime argument), so the vmcnt ladder never changes.
     for (int t = 0; t < T; ++t) {
         const char* buf = smem + (t & 1) * BUF_BYTES;
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         const int e1 = (t + 1) & 1, e2 = t & 1;  // destination buffer parity follows the UNclamped tile index
-        const bf16* ky = (const bf16*)nullptr + (int64_t)t1 * BK;
-        const bf16* kx = (const bf16*)nullptr + (int64_t)t2 * BK;
         const int64_t oy = (int64_t)t1 * BK, ox = (int64_t)t2 * BK;
-        (void)ky; (void)kx;
         char* by = smem + e1 * BUF_BYTES;
         char* bx = smem + e2 * BUF_BYTES;
         // ================= MEM_a(t): B fragments (whole tile) + A rows 0..63
@@ -172,11 +162,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) af[i][s] = *(const bf16x8*)(buf + a_row0 + i * 32 * ROWB + koffb[s]);
-        if (!(V & 1)) AFK_LGKMCNT0();
+        AFK_LGKMCNT0();
         AFK_VMCNT(6);
         AFK_BARRIER();
         // ================= MFMA_a(t) (+ Y(t+1): 2 pieces)
-        if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         AFK_MFMA4(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_global_load_lds((gbl_void*)(ysrc[0] + oy), (lds_void*)(by + ydst[0]), 16, 0, 0);
@@ -195,11 +185,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int s = 0; s < 4; ++s) af[i][s] = *(const bf16x8*)(buf + a_row0 + (i + 2) * 32 * ROWB + koffb[s]);
-        if (!(V & 1)) AFK_LGKMCNT0();
+        AFK_LGKMCNT0();
         AFK_VMCNT(2);
         AFK_BARRIER();
         // ================= MFMA_b(t) (+ X(t+2): 6 pieces)
-        if (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -220,7 +210,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
     }
     AFK_VMCNT(0);  // no LDS-DMA may be in flight when the workgroup releases its LDS
 #undef AFK_MFMA4
-#undef AFK_DMA
     if (wm == 0) AFK_BARRIER();  // equalise barrier counts
 
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
@@ -245,25 +234,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
 }  // namespace
 
-int g_gemm256_exp = 0;  // experiment selector (tools/bench only)
-
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        bool ok = true;
-        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) == hipSuccess;
-        if (!ok) return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
+        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_k256, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
         attr_set = true;
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
-    switch (g_gemm256_exp & 3) {
-        case 1: hipLaunchKernelGGL(gemm_nt_bf16_k256<1>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
-        case 2: hipLaunchKernelGGL(gemm_nt_bf16_k256<2>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
-        case 3: hipLaunchKernelGGL(gemm_nt_bf16_k256<3>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
-        default: hipLaunchKernelGGL(gemm_nt_bf16_k256<0>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p); break;
-    }
+    hipLaunchKernelGGL(gemm_nt_bf16_k256, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
     return AFK_OK;
 }

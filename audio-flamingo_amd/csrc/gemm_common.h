@@ -95,6 +95,5 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, i
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
-extern int g_gemm256_exp;
 // transposed-operand variants (gemm256t.hip): NN (trans_a = 0) and TN (trans_a = 1); B is reduction-major in both
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st);

@@ -55,7 +55,11 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             side.wait_event(ev)
-            wgrad_branch()
+            ops.THIN_BLOCKS = arena.thin_blocks  # operand transposes trickle beside the dgrad GEMM instead of evicting it
+            try:
+                wgrad_branch()
+            finally:
+                ops.THIN_BLOCKS = 0
         dy.record_stream(side)
         x.record_stream(side)
     if not need_dx:

@@ -117,6 +117,9 @@ def colsum(x, out, *, accumulate=False):
     return out
 
 
+THIN_BLOCKS = 0  # > 0: cap transposes to that many persistent blocks (set while enqueueing on a side stream beside GEMMs)
+
+
 def transpose(x, out=None, *, rpad=None):
     """x [R, C] (row stride free) -> out [C, Rpad] with zero-filled tail columns."""
     _chk(x, BF16, "transpose x")
@@ -126,7 +129,7 @@ def transpose(x, out=None, *, rpad=None):
     if out is None:
         out = torch.empty((C, rpad), device=x.device, dtype=BF16)
     _lib.call("afk_transpose_bf16", x.data_ptr(), out.data_ptr(), R, C, rpad, x.stride(0), out.stride(0), 1, 1, 0, 0, 0, 0,
-              _stream())
+              THIN_BLOCKS, _stream())
     return out
 
 
@@ -136,7 +139,7 @@ def transpose_heads(x, B, S, H, D, ld, spad, out=None):
     if out is None:
         out = torch.empty((B, H, D, spad), device=x.device, dtype=BF16)
     _lib.call("afk_transpose_bf16", x.data_ptr(), out.data_ptr(), S, D, spad, ld, spad, B, H, S * ld, D, H * D * spad,
-              D * spad, _stream())
+              D * spad, 0, _stream())
     return out
 
 

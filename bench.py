@@ -174,6 +174,7 @@ def main():
         opt.master.copy_(model.arena.params)
     model.arena.refresh_shadows(force=True)
     model.arena.enable_wgrad_stream(not args.no_wgrad_stream)
+    model.arena.thin_blocks = int(os.environ.get("AFK_THIN_TRANSPOSE", "0"))
     frontend = LogMelFrontend(dev)
     waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev)
 
@@ -270,7 +271,7 @@ def main():
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "loss": final_loss, "peak_mem_gib": round(peak_mem, 1),
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k128 (all dense contractions: fwd, dgrad, wgrad, lm_head)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",
                          "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic,
                          "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "gemm_ms_per_step": gemm_ms / prof_steps,

@@ -77,7 +77,8 @@ int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* r
  * transpose: out[b1][b2][c][r] = in[b1][b2][r][c]; columns R..Rpad-1 of out are zero (K padding for wgrad GEMMs,
  *            and the [B,H,D,Spad] operand copies of the attention kernels). */
 int afk_transpose_bf16(const void* in, void* out, int R, int C, int Rpad, int64_t ld_in, int64_t ld_out, int nb1,
-                       int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, void* stream);
+                       int nb2, int64_t bs1_in, int64_t bs2_in, int64_t bs1_out, int64_t bs2_out, int max_blocks, void* stream);
+/* max_blocks > 0 caps the (persistent) grid: a thin launch that co-resides with GEMM workgroups of another stream */
 /* exact-erf GELU (transformers/activations.py:70-89) */
 int afk_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int afk_gelu_bwd(const void* dy, const void* pre, void* dx, int64_t n, void* stream);
@@ -98,6 +99,16 @@ int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int 
  * workspace = afk_colsum_slices(rows) * cols floats */
 int afk_colsum_slices(int64_t rows);
 int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, void* stream);
+
+/* ---- Flamingo glue (BASELINE config 4; stand-in oracle lines: transformers/models/idefics) --------------------------------
+ * ReLU of the Perceiver MLP (perceiver.py:171-187); tanh-gated residual of the gated cross-attention layer
+ * (modeling_idefics.py:792-793,800):  y = x + tanh(alpha) * (gate[row] ? h : 0), alpha a vector [D] or a scalar. */
+int afk_relu_fwd(const void* x, void* y, int64_t n, void* stream);
+int afk_relu_bwd(const void* dy, const void* y, void* dx, int64_t n, void* stream);
+int afk_gate_fwd(const void* x, const void* h, const void* alpha, int alpha_is_vector, const int* gate, void* y, int64_t rows,
+                 int D, void* stream);
+int afk_gate_bwd(const void* dy, const void* h, const void* alpha, int alpha_is_vector, const int* gate, void* dh,
+                 float* fws, void* dalpha, int accumulate, int64_t rows, int D, void* stream);
 
 /* ---- conv stem as GEMM (modeling_audioflamingo3.py:328-329,380-382) ------------------------------------ */
 int afk_im2col_conv1(const void* x, int x_is_f32, void* col, int W, int C, int T, void* stream);
@@ -131,6 +142,22 @@ int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const 
                  void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV, int64_t dv_bs, int64_t dv_hs,
                  int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale,
                  int causal, void* stream);
+
+/* cross-attention form (BASELINE config 4: Perceiver resampler and Flamingo gated cross-attention; stand-in oracle lines
+ * transformers/models/idefics/perceiver.py:106-168, modeling_idefics.py:776-802): Sq != Sk, optional per-query key range
+ * krange[B, Sq, 2] = [begin, end) ("attend only to the media of your own segment"; an empty range yields a zero row).
+ * Qt/dOt/LSE/delta use the query pitch Sqpad / Sq, Kt/Vt the key pitch Skpad. */
+int afk_xattn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                  int64_t k_rs, const void* Vt, void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, float* LSE,
+                  const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk, int Sqpad, int Skpad,
+                  int D, float scale, void* stream);
+int afk_xattn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                  int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO,
+                  int64_t do_bs, int64_t do_hs, int64_t do_rs, const void* Qt, const void* Kt, const void* dOt,
+                  const float* LSE, const float* delta, void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs,
+                  void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV, int64_t dv_bs, int64_t dv_hs,
+                  int64_t dv_rs, const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk,
+                  int Sqpad, int Skpad, int D, float scale, void* stream);
 
 /* ---- attention v2: LDS-staged tiles + ds_read_b64_tr_b16 transposed operands; no transposed copies in HBM.
  * Same oracle lines as afk_attn_*.  head_dim 64 / 128.  LSE and delta are [B, Hq, Spad] (Spad % 64 == 0, zero-initialised). */

@@ -63,3 +63,38 @@ def test_mel_bank_matches_third_party():
     from audio_flamingo_amd.frontend import mel_filter_bank as mine
 
     assert np.abs(mine(128) - ref).max() < 1e-12
+
+
+def test_flamingo_oracle_matches_structural_stand_in():
+    """config 4 (AF1/AF2) has no reference code: the restatement is pinned to the Idefics stand-in it declares as its spec"""
+    pytest.importorskip("transformers")
+    from transformers.models.idefics.configuration_idefics import IdeficsConfig
+    from transformers.models.idefics.modeling_idefics import IdeficsGatedCrossAttentionLayer
+    from transformers.models.idefics.perceiver import IdeficsPerceiverResampler
+
+    from oracle import flamingo_oracle as FO
+
+    torch.manual_seed(0)
+    cfg = IdeficsConfig(hidden_size=128, intermediate_size=256, num_attention_heads=4, num_hidden_layers=2, vocab_size=100,
+                        alpha_initializer="normal", alphas_initializer_range=0.5, alpha_type="vector",
+                        vision_config=dict(embed_dim=128), perceiver_config=dict(qk_layer_norms_perceiver=False))
+    pr = IdeficsPerceiverResampler(cfg, embed_dim=128, depth=2, n_heads=4, head_dim=32, n_latents=16).eval()
+    ctx = torch.randn(3, 50, 128)
+    with torch.no_grad():
+        ref = pr(ctx)
+        got = FO.perceiver_resampler(dict(pr.state_dict()), ctx, 4, 32)
+    assert (ref - got).abs().max() < 1e-5
+    layer = IdeficsGatedCrossAttentionLayer(cfg, layer_idx=0).eval()
+    B, S, Sk = 2, 40, 32
+    x, media = torch.randn(B, S, 128), torch.randn(B, Sk, 128)
+    keep = torch.zeros(B, S, Sk, dtype=torch.bool)
+    gate = torch.zeros(B, S)
+    for b in range(B):
+        keep[b, 5:20, 0:16] = True
+        keep[b, 20:, 16:32] = True
+        gate[b, 5:] = 1
+    add_mask = torch.zeros(B, 1, S, Sk).masked_fill(~keep[:, None], torch.finfo(torch.float32).min)
+    with torch.no_grad():
+        ref = layer(x, image_hidden_states=media, image_attention_mask=add_mask, cross_attention_gate=gate)
+        got = FO.gated_cross_attention(dict(layer.state_dict()), x, media, keep, gate, 4, cfg.rms_norm_eps)
+    assert (ref - got).abs().max() < 1e-5

@@ -4,7 +4,7 @@ import torch
 from audio_flamingo_amd import ops
 dev = torch.device("cuda")
 shapes = [(8192, 37888, 3584), (8192, 3584, 18944), (37888, 3584, 8192), (3584, 18944, 8192), (8192, 18944, 3584), (8192, 3584, 37888), (8192, 8192, 8192), (12000, 5120, 1280), (8192, 3584, 3584)]
-cfgs = [("gm4", 2 + 256 * 4), ("gm3", 2 + 256 * 3), ("gm5", 2 + 256 * 5), ("gm6", 2 + 256 * 6), ("gm8", 2 + 256 * 8), ("raw_gm4", 2 + 256 * (128 + 4)), ("raw_gm8", 2 + 256 * (128 + 8)), ("raw_gm2", 2 + 256 * (128 + 2))]
+cfgs = [("gm4", 2 + 256 * 4), ("gm2", 2 + 256 * 2), ("gm8", 2 + 256 * 8), ("gm16", 2 + 256 * 16), ("raw_gm4", 2 + 256 * (128 + 4))]
 for M, N, K in shapes:
     a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand((N, K), device=dev) * 2 - 1).to(torch.bfloat16)
