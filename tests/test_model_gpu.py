@@ -230,3 +230,37 @@ def test_smoke_entry(dev):
     import __graft_entry__ as ge
 
     ge.smoke()
+
+
+def test_on_device_audio_preprocessing_matches_reference_processor(dev):
+    """window split + GPU log-mel + masks + token counts vs the reference feature extractor / processor formulae"""
+    import numpy as np
+    from transformers import WhisperFeatureExtractor
+
+    from audio_flamingo_amd.processing import AudioPreprocessor, expand_sound_tokens
+
+    rng = np.random.default_rng(3)
+    clips = [rng.standard_normal(80000).astype(np.float32) * 0.1, rng.standard_normal(70 * 16000).astype(np.float32) * 0.1]
+    out = AudioPreprocessor(dev)(clips, out_dtype=torch.float32)
+    assert out["windows_per_sample"] == [1, 3]
+    assert out["input_features"].shape == (4, 128, 3000)
+    assert out["input_features_mask"].sum(-1).tolist() == [500, 3000, 3000, 1000]
+    assert out["num_audio_tokens"].tolist() == [125, 1750]
+    fe = WhisperFeatureExtractor(feature_size=128)
+    chunks = [clips[0], clips[1][:480000], clips[1][480000:960000], clips[1][960000:]]
+    ref = fe(chunks, sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="pt")
+    assert torch.equal(ref["attention_mask"].to(torch.int32), out["input_features_mask"].cpu())
+    err = (out["input_features"].cpu() - ref["input_features"]).abs()
+    assert err.max() < 2e-4 and err.median() < 1e-5, (float(err.max()), float(err.median()))
+    assert expand_sound_tokens([5, 1023, 7], 1023, 3) == [5, 1023, 1023, 1023, 7]
+    # and the whole thing drives the model: ragged windows -> encoder -> scatter
+    m = _model(dev)
+    n = int(out["num_audio_tokens"].sum())
+    ids = torch.cat([torch.tensor(expand_sound_tokens([3, 1023, 4], 1023, 125)), torch.zeros(1750 - 125, dtype=torch.long)])[None]
+    ids2 = torch.tensor(expand_sound_tokens([3, 1023, 4], 1023, 1750))[None]
+    ids = torch.cat([ids, ids2], 0)
+    att = torch.ones_like(ids)
+    att[0, 127:] = 0
+    o = m(input_ids=ids.to(dev), input_features=out["input_features"].to(torch.bfloat16), input_features_mask=out["input_features_mask"],
+          attention_mask=att.to(dev))
+    assert o.logits.shape == (2, 1752, 1024) and torch.isfinite(o.logits.float()[1]).all() and n == 1875
