@@ -163,40 +163,83 @@ class _XAttn(torch.autograd.Function):
     """softmax(q k^T * scale + segment mask) v with Sq != Sk; q [B*Sq, H*D], k / v [B*Sk, H*D]; krange int32 [B, Sq, 2] or None"""
 
     @staticmethod
-    def forward(ctx, q, k, v, krange, B, Sq, Sk, H, D, scale):
+    def forward(ctx, q, k, v, krange, B, Sq, Sk, H, D, scale, Hkv=None):
+        Hkv = Hkv or H
         sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
-        vt = ops.transpose_heads(v, B, Sk, H, D, v.stride(0), skp)
+        vt = ops.transpose_heads(v, B, Sk, Hkv, D, v.stride(0), skp)
         o = torch.empty((B * Sq, H * D), device=q.device, dtype=BF16)
         lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
         _lib.call("afk_xattn_fwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
-                  vt.data_ptr(), o.data_ptr(), Sq * H * D, D, H * D, lse.data_ptr(), 0, _p(krange), B, H, H, Sq, Sk, sqp, skp, D,
+                  vt.data_ptr(), o.data_ptr(), Sq * H * D, D, H * D, lse.data_ptr(), 0, _p(krange), B, H, Hkv, Sq, Sk, sqp, skp, D,
                   float(scale), _stream())
         ctx.save_for_backward(q, k, v, o, lse, krange)
-        ctx.meta = (B, Sq, Sk, H, D, scale)
+        ctx.meta = (B, Sq, Sk, H, D, scale, Hkv)
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse, krange = ctx.saved_tensors
-        B, Sq, Sk, H, D, scale = ctx.meta
+        B, Sq, Sk, H, D, scale, Hkv = ctx.meta
         do = do.contiguous()
         dev = q.device
         sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
-        ldo = H * D
+        ldo, ldk = H * D, Hkv * D
         delta = torch.empty((B, H, Sq), device=dev, dtype=torch.float32)
         _lib.call("afk_attn_delta", o.data_ptr(), Sq * ldo, D, ldo, do.data_ptr(), Sq * ldo, D, ldo, delta.data_ptr(), B, H, Sq, D, _stream())
         qt = ops.transpose_heads(q, B, Sq, H, D, q.stride(0), sqp)
-        kt = ops.transpose_heads(k, B, Sk, H, D, k.stride(0), skp)
+        kt = ops.transpose_heads(k, B, Sk, Hkv, D, k.stride(0), skp)
         dot = ops.transpose_heads(do, B, Sq, H, D, ldo, sqp)
-        dq = torch.empty((B * Sq, H * D), device=dev, dtype=BF16)
-        dk = torch.empty((B * Sk, H * D), device=dev, dtype=BF16)
-        dv = torch.empty((B * Sk, H * D), device=dev, dtype=BF16)
+        dq = torch.empty((B * Sq, ldo), device=dev, dtype=BF16)
+        dk = torch.empty((B * Sk, ldk), device=dev, dtype=BF16)
+        dv = torch.empty((B * Sk, ldk), device=dev, dtype=BF16)
         _lib.call("afk_xattn_bwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
                   v.data_ptr(), Sk * v.stride(0), D, v.stride(0), do.data_ptr(), Sq * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(),
-                  dot.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Sq * ldo, D, ldo, dk.data_ptr(), Sk * ldo, D, ldo,
-                  dv.data_ptr(), Sk * ldo, D, ldo, 0, _p(krange), B, H, H, Sq, Sk, sqp, skp, D, float(scale), _stream())
-        return dq, dk, dv, None, None, None, None, None, None, None
+                  dot.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Sq * ldo, D, ldo, dk.data_ptr(), Sk * ldk, D, ldk,
+                  dv.data_ptr(), Sk * ldk, D, ldk, 0, _p(krange), B, H, Hkv, Sq, Sk, sqp, skp, D, float(scale), _stream())
+        return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
-def cross_attention(q, k, v, *, B, Sq, Sk, H, D, scale, krange=None):
-    return _XAttn.apply(q, k, v, krange, B, Sq, Sk, H, D, scale)
+def cross_attention(q, k, v, *, B, Sq, Sk, H, D, scale, krange=None, Hkv=None):
+    """q [B*Sq, H*D], k / v [B*Sk, Hkv*D] (row-strided views allowed); krange int32 [B, Sq, 2] = visible key interval per query"""
+    return _XAttn.apply(q, k, v, krange, B, Sq, Sk, H, D, scale, Hkv)
+
+
+class _SelfAttn(torch.autograd.Function):
+    """Sq == Sk self-attention on the LDS-staged kernels (head_dim 64 / 128): full or causal, optional right key padding kv_len[B];
+    q [B*S, Hq*D], k / v [B*S, Hkv*D] row-strided views (e.g. slices of a fused projection).  GQA when Hkv < Hq."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal):
+        spad = ops.pad64(S)
+        o = torch.empty((B * S, Hq * D), device=q.device, dtype=BF16)
+        lse = torch.zeros((B, Hq, spad), device=q.device, dtype=torch.float32)
+        _lib.call("afk_attn2_fwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
+                  v.data_ptr(), S * v.stride(0), D, v.stride(0), o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len),
+                  B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+        ctx.save_for_backward(q, k, v, o, lse, kv_len)
+        ctx.meta = (B, S, Hq, Hkv, D, scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse, kv_len = ctx.saved_tensors
+        B, S, Hq, Hkv, D, scale, causal = ctx.meta
+        do = do.contiguous()
+        dev, spad, ldo, ldk = q.device, ops.pad64(S), Hq * D, Hkv * D
+        delta = torch.zeros((B, Hq, spad), device=dev, dtype=torch.float32)
+        _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, spad, D, _stream())
+        dq = torch.empty((B * S, ldo), device=dev, dtype=BF16)
+        dk = torch.empty((B * S, ldk), device=dev, dtype=BF16)
+        dv = torch.empty((B * S, ldk), device=dev, dtype=BF16)
+        scratch = torch.empty((2, B * S, ldo), device=dev, dtype=BF16) if Hq != Hkv else None
+        _lib.call("afk_attn2_bwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
+                  v.data_ptr(), S * v.stride(0), D, v.stride(0), do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(),
+                  dq.data_ptr(), S * ldo, D, ldo, dk.data_ptr(), S * ldk, D, ldk, dv.data_ptr(), S * ldk, D, ldk, _p(kv_len),
+                  B, Hq, Hkv, S, spad, D, float(scale), int(causal), _p(scratch), _stream())
+        return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+def self_attention(q, k, v, *, B, S, Hq, Hkv, D, scale, causal, kv_len=None):
+    if D not in (64, 128):
+        raise ValueError(f"self_attention: head_dim {D} not supported by the LDS-staged kernels (64 / 128); use cross_attention")
+    return _SelfAttn.apply(q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal)

@@ -29,6 +29,9 @@ import torch
 
 S_TOK, N_AUDIO_TOK, N_ANSWER, AUDIO_ID = 1024, 750, 256, 151669
 CLIP_SECONDS = 30.0
+# BASELINE.json configs[1]/[2] ("clip30": one 30 s window per sample, micro-batch 8) and configs[4] ("long5min": one 5-minute clip =
+# 10 full windows per sample, 7 500 <sound> tokens, S = 7 774, micro-batch 1, per-layer activation checkpointing on both towers).
+WORKLOADS = {"clip30": dict(windows=1, batch=8, checkpoint=False), "long5min": dict(windows=10, batch=1, checkpoint=True)}
 
 
 def af3_7b_config(enc_layers=32, dec_layers=28):
@@ -44,27 +47,33 @@ def af3_7b_config(enc_layers=32, dec_layers=28):
     )
 
 
-def synthetic_batch(batch, first_idx, device):
-    """SURVEY.md §8(d) synthetic inputs; sample i uses numpy default_rng(1234 + i)"""
-    waves = np.empty((batch, int(CLIP_SECONDS * 16000)), np.float32)
-    ids = np.empty((batch, S_TOK), np.int64)
+def synthetic_batch(batch, first_idx, device, windows=1):
+    """SURVEY.md §8(d) synthetic inputs; sample i uses numpy default_rng(1234 + i).  A sample is `windows` consecutive full 30 s windows
+    (waves [batch * windows, 480 000], window-major inside a sample) and 9 prompt + 750*windows <sound> + 9 prompt + 256 answer ids."""
+    n_audio = N_AUDIO_TOK * windows
+    S = 9 + n_audio + 9 + N_ANSWER
+    waves = np.empty((batch * windows, int(CLIP_SECONDS * 16000)), np.float32)
+    ids = np.empty((batch, S), np.int64)
     for b in range(batch):
         rng = np.random.default_rng(1234 + first_idx + b)
-        waves[b] = (0.1 * rng.standard_normal(waves.shape[1])).astype(np.float32)
+        waves[b * windows:(b + 1) * windows] = (0.1 * rng.standard_normal((windows, waves.shape[1]))).astype(np.float32)
         text = rng.integers(0, 151643, size=9 + 9 + N_ANSWER)
-        ids[b] = np.concatenate([text[:9], np.full(N_AUDIO_TOK, AUDIO_ID), text[9:18], text[18:]])
+        ids[b] = np.concatenate([text[:9], np.full(n_audio, AUDIO_ID), text[9:18], text[18:]])
     labels = ids.copy()
-    labels[:, : S_TOK - N_ANSWER] = -100
+    labels[:, : S - N_ANSWER] = -100
     return (torch.from_numpy(waves).to(device), torch.from_numpy(ids).to(device), torch.from_numpy(labels).to(device))
 
 
-def train_flops_per_sample(S=S_TOK):
-    """algorithmic FLOPs (2*MACs, causal attention at 1/2), forward x 3"""
-    enc = 2 * 3000 * 128 * 3 * 1280 + 2 * 1500 * 1280 * 3 * 1280 + 32 * (2 * 1500 * (4 * 1280 ** 2 + 2 * 1280 * 5120) + 4 * 1500 ** 2 * 1280)
-    proj = 2 * 750 * (1280 * 3584 + 3584 * 3584)
+def train_flops_per_sample(S=S_TOK, windows=1, recompute=False):
+    """algorithmic FLOPs (2*MACs, causal attention at 1/2), forward x 3; recompute=True adds the checkpointed layers' second
+    forward (x 4 on the layer stacks) - reported separately as hardware FLOPs, never as model FLOPs"""
+    enc_l = 32 * (2 * 1500 * (4 * 1280 ** 2 + 2 * 1280 * 5120) + 4 * 1500 ** 2 * 1280)
+    enc = windows * (2 * 3000 * 128 * 3 * 1280 + 2 * 1500 * 1280 * 3 * 1280)
+    proj = windows * 2 * 750 * (1280 * 3584 + 3584 * 3584)
     dec = 28 * (2 * S * (2 * 3584 ** 2 + 2 * 3584 * 512 + 3 * 3584 * 18944) + 2 * S ** 2 * 3584)
     lm = 2 * S * 3584 * 152064
-    return 3.0 * (enc + proj + dec + lm)
+    layers = windows * enc_l + dec
+    return 3.0 * (enc + proj + lm) + (4.0 if recompute else 3.0) * layers
 
 
 def cpu_baseline(seconds_budget=30.0):
@@ -131,7 +140,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="micro-batch per GPU (BASELINE config: 8)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="clip30", help="clip30 = BASELINE configs[1]/[2] (the headline); long5min = configs[4]")
+    ap.add_argument("--batch", type=int, default=0, help="micro-batch (samples) per GPU; default 8 for clip30 (BASELINE config), 1 for long5min")
+    ap.add_argument("--no-checkpoint", action="store_true", help="long5min only: keep all activations instead of per-layer recompute")
     ap.add_argument("--enc-layers", type=int, default=32)
     ap.add_argument("--dec-layers", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +151,11 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient branch on the compute stream")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel engine even with one rank (exercises the RCCL path)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.batch = args.batch or wl["batch"]
+    windows, ckpt = wl["windows"], wl["checkpoint"] and not args.no_checkpoint
+    n_audio_tok = N_AUDIO_TOK * windows
+    s_tok = 9 + n_audio_tok + 9 + N_ANSWER
 
     import torch.distributed as dist
 
@@ -166,6 +182,8 @@ def main():
     full_model = args.enc_layers == 32 and args.dec_layers == 28
     model = AudioFlamingo3ForConditionalGeneration(af3_7b_config(args.enc_layers, args.dec_layers), device=dev, init_seed=0)
     model.check_placeholders = False  # the count assertion is a host sync; shapes are static in this benchmark
+    if ckpt:
+        model.gradient_checkpointing_enable()
     opt = FusedAdamW(model.arena, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     engine = None
     if use_dp:
@@ -176,7 +194,7 @@ def main():
     model.arena.enable_wgrad_stream(not args.no_wgrad_stream)
     model.arena.thin_blocks = int(os.environ.get("AFK_THIN_TRANSPOSE", "0"))
     frontend = LogMelFrontend(dev)
-    waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev)
+    waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev, windows)
 
     overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
     if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
@@ -258,19 +276,24 @@ def main():
                 tj = json.load(f)
             traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                        "shape": tj["shape"], "source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
-        model_tf = train_flops_per_sample() * samples_per_s / world / 1e12 if full_model else None
+        model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
+        hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
         res = {
             "metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train",
-            "value": samples_per_s * CLIP_SECONDS, "unit": "audio-s/s",
-            "decoder_tokens_per_s": samples_per_s * S_TOK, "answer_tokens_per_s": samples_per_s * N_ANSWER,
+            "value": samples_per_s * CLIP_SECONDS * windows, "unit": "audio-s/s",
+            "decoder_tokens_per_s": samples_per_s * s_tok, "answer_tokens_per_s": samples_per_s * N_ANSWER,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("AF3 (AF-Whisper 32L + Qwen2.5-7B 28L, MLP projector) bf16 train step fwd+bwd+AdamW, 30 s clips, S=1024" if full_model
+            "config": {"workload": ((("AF3 (AF-Whisper 32L + Qwen2.5-7B 28L, MLP projector) bf16 train step fwd+bwd+AdamW, 30 s clips, S=1024" if windows == 1 else
+                                      f"AF3-7B bf16 train step fwd+bwd+AdamW, LONG AUDIO: 5-min clips = {windows} windows/sample, S={s_tok}, "
+                                      f"per-layer activation checkpointing {'ON' if ckpt else 'OFF'} (BASELINE configs[4])")) if full_model
                                     else f"DEPTH-REDUCED AF3 ({args.enc_layers} enc + {args.dec_layers} dec layers) - not the BASELINE config"),
-                       "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": S_TOK, "audio_tokens": N_AUDIO_TOK,
+                       "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": s_tok, "audio_tokens": n_audio_tok,
+                       "windows_per_sample": windows, "activation_checkpointing": ckpt,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "loss": final_loss, "peak_mem_gib": round(peak_mem, 1),
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
+            "hardware_tflops_per_gpu": hw_tf,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",
                          "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic,
                          "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),

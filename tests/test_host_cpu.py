@@ -149,3 +149,24 @@ def test_dp_bucket_allreduce_gloo_world2(tmp_path):
            "--master-port", "29533", str(script), ROOT]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and r.stdout.count("OK") == 2, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_hf_attention_plugin_registers_and_refuses_cpu():
+    """the reference's plugin registry accepts the HIP attention; on CPU tensors the plugin refuses instead of falling back"""
+    import pytest
+    import torch
+    from transformers import AttentionInterface
+
+    from audio_flamingo_amd import hf_plugin
+
+    name = hf_plugin.register()
+    assert name in AttentionInterface()._global_mapping or name in AttentionInterface._global_mapping
+    q = torch.zeros(1, 2, 4, 64, dtype=torch.bfloat16)
+    with pytest.raises(TypeError):
+        hf_plugin.afk_attention(torch.nn.Identity(), q, q, q, None)
+    m = torch.ones(1, 1, 4, 4, dtype=torch.bool)
+    m[0, 0, 2, 1] = False  # row 2 sees keys {0, 2, 3}: a hole
+    with pytest.raises(NotImplementedError):
+        hf_plugin._intervals(m)
+    kr = hf_plugin._intervals(torch.ones(4, 4, dtype=torch.bool).tril()[None, None])
+    assert kr.tolist() == [[[0, 1], [0, 2], [0, 3], [0, 4]]]
