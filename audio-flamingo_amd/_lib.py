@@ -11,7 +11,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libafk.so")
+LIB_PATH = os.environ.get("AFK_LIB_PATH") or os.path.join(_HERE, "lib", "libafk.so")  # AFK_LIB_PATH: A/B a second build of the same ABI
 HEADER_PATH = os.path.join(_REPO, "include", "afk.h")
 
 _CTYPE = {

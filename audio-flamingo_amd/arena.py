@@ -61,6 +61,9 @@ class Arena:
         # the partially empty last wave of the other (448-tile GEMMs leave 25 % of the CUs idle in their second round)
         self.wgrad_stream: Optional[torch.cuda.Stream] = None
         self.thin_blocks = 0  # grid cap for the transposes issued on the wgrad stream (0 = full grid)
+        # W^T shadows on demand only: set when dgrad runs on the NN kernel (functional.BWD_FORM == "direct"), where most of them
+        # are never read; the eager per-bucket refresh after the optimizer then skips them and arena.shadow() rebuilds a stale one
+        self.lazy_T_shadows = False
 
     # ------------------------------------------------------------------ layout
     def new_bucket(self, name: str) -> int:
@@ -166,11 +169,13 @@ class Arena:
 
     def refresh_bucket_shadows(self, i: int):
         for b in self.order:
-            if b.bucket == i and b.shadow_kind is not None:
+            if b.bucket == i and b.shadow_kind is not None and not (self.lazy_T_shadows and b.shadow_kind == "T"):
                 self._refresh_one(b)
 
     def refresh_shadows(self, force: bool = True):
         for b in self.order:
+            if self.lazy_T_shadows and b.shadow_kind == "T":
+                continue
             if b.shadow_kind is not None and (force or b.shadow_version != self._version_of(b)):
                 self._refresh_one(b)
 
@@ -241,8 +246,8 @@ class FusedAdamW:
 
     def end_step(self):
         self.arena.step_counter += 1
-        for b in self.arena.order:  # shadows were refreshed bucket by bucket
-            if b.shadow_kind is not None:
+        for b in self.arena.order:  # shadows were refreshed bucket by bucket (lazy W^T shadows stay stale until used)
+            if b.shadow_kind is not None and not (self.arena.lazy_T_shadows and b.shadow_kind == "T"):
                 b.shadow_version = self.arena._version_of(b)
 
     def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True):

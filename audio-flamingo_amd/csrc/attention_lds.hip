@@ -129,6 +129,25 @@ struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------ forward
+// One block = 128 query rows (4 waves x 32), two blocks per CU.  Per 64-key tile and wave:
+//     S^T = K.Q^T (2 x KS MFMAs, two independent accumulators)  ->  one online-softmax step over all 64 keys
+//     ->  O^T += V^T.P (4 x DT MFMAs, V^T fragments by ds_read_b64_tr_b16)
+// The key loop is split into an INTERIOR part (every key of the tile visible to every row of the block: no mask, no liveness
+// test - the only branches are the loop edge and the rare rescale) and a BOUNDARY part (causal diagonal / ragged tail): a taken
+// branch costs an instruction-buffer refill, and the first version of this kernel spent ~30 % of its cycles on them.
+// Lazy rescale: the running max only moves (and O, l are only rescaled) when some row's max grew by more than 2^8; until then
+// probabilities are taken against the stale max (<= 2^8, exact in fp32 / same relative precision in bf16).  The row sum is kept
+// per lane half and folded once at the end.  The V^T reads are issued (opaque asm, common.h) BEFORE the softmax arithmetic so
+// their latency hides under it; the K(j+1)/V(j+1) LDS-DMA is in flight during the whole tile (vmcnt(0) only at the barrier).
+#define AFK_ATTN_BARRIER()                                    \
+    do {                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        __builtin_amdgcn_s_barrier();                         \
+        __builtin_amdgcn_sched_barrier(0);                    \
+    } while (0)
+constexpr float RESCALE_THR = 8.f;  // log2 domain
+
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
@@ -145,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
-    const bool wave_live = q0 < p.S;
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     bf16x8 qf[KS];
@@ -158,82 +176,138 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
-    float m = NEG_INF, l = 0.f;  // running max in the log2 domain
+    float m = NEG_INF, l = 0.f;  // running (possibly stale) max in the log2 domain; row sum of THIS lane half
     const float c2 = p.scale * LOG2E;
 
-    const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;
+    const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;  // keys any row of the block can see
     const int ntiles = (kv_end_blk + 63) >> 6;
-    const int kv_end = p.causal ? min(kv_len, q0 + 32) : kv_len;  // this wave's horizon
+    // interior tiles: all 64 keys valid and visible to every row of the block
+    const int n_int = p.causal ? min(qb0, kv_len) >> 6 : kv_len >> 6;
+    const int kv_end = p.causal ? min(kv_len, q0 + 32) : kv_len;  // this wave's horizon (boundary tiles)
+    const uint32_t lds0 = afk_lds_addr(smem);
+    uint32_t vtr[DT][2];  // V^T fragment addresses in buffer 0
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) vtr[dt][pc] = lds0 + T::BYTES + offs.tr[dt][pc];
 
-    auto stage = [&](int j) {
+    auto stage = [&](int j) {  // general form (row clamp): prologue and boundary tiles
         char* buf = smem + (j & 1) * 2 * T::BYTES;
         T::stage(buf, Kbase, p.k_rs, j * 64, p.S - 1, wave, lane);
         T::stage(buf + T::BYTES, Vbase, p.v_rs, j * 64, p.S - 1, wave, lane);
     };
-    if (ntiles > 0) stage(0);
-    __syncthreads();
-    for (int j = 0; j < ntiles; ++j) {
-        if (j + 1 < ntiles) stage(j + 1);
+    // interior form: lane-constant source pointers of tile 0, advanced by whole tiles (no per-tile address arithmetic beyond one
+    // 64-bit add per piece); only legal while all 64 rows of the staged tile exist
+    constexpr int NP = T::UNITS / 4;
+    const bf16* ksrc[NP];
+    const bf16* vsrc[NP];
+#pragma unroll
+    for (int u0 = 0; u0 < NP; ++u0) {
+        const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
+        ksrc[u0] = Kbase + (int64_t)r * p.k_rs + chunk * 8;
+        vsrc[u0] = Vbase + (int64_t)r * p.v_rs + chunk * 8;
+    }
+    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
+    auto stage_fast = [&](int j) {
+        char* buf = smem + (j & 1) * 2 * T::BYTES;
+#pragma unroll
+        for (int u0 = 0; u0 < NP; ++u0) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ksrc[u0] + j * kstep), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc[u0] + j * vstep), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+        }
+    };
+    const int n_full = p.S >> 6;  // tiles whose 64 rows all exist
+
+    // one 64-key tile.  MASKED: per-element visibility (key < kv_len, causal key <= q) is applied to the scores.
+    auto tile = [&](int j, auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
         const char* kimg = smem + (j & 1) * 2 * T::BYTES;
-        const char* vimg = kimg + T::BYTES;
+        const uint32_t boff = (j & 1) * 2 * T::BYTES;
+        f32x16 st[2] = {zero16(), zero16()};
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            const int key0 = j * 64 + kt2 * 32;
-            if (wave_live && key0 < kv_end) {  // wave-uniform
-                f32x16 st = zero16();
+        for (int ks = 0; ks < KS; ++ks) {
+            st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
+            st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+        }
+        // V^T fragments of d-tile 0: in flight during the softmax; the other d-tiles follow through the two-deep ring below
+        bf16x8 fa[4], fb[4];
+        auto issue = [&](auto g_, bf16x8(&dst)[4]) {
+            constexpr int dt = decltype(g_)::value;
+            const uint32_t a0 = vtr[dt][0] + boff, a1 = vtr[dt][1] + boff;
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<s4 * 16 * T::RS>(a0, a1); });
+        };
+        issue(std::integral_constant<int, 0>{}, fa);
+        if (MASKED) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) st = MFMA(T::row_frag(kimg, offs, kt2, ks), qf[ks], st);
-                // softmax in the log2 domain: t = s*scale*log2(e); p = 2^(t - m).  The kernels are VALU-bound, so the mask
-                // arithmetic runs only on boundary tiles (wave-uniform test), the O rescale only when some row max moved.
-                const bool need_mask = (key0 + 32 > kv_len) || (p.causal && key0 + 31 > q0);
-                float t[16];
-                float mx = NEG_INF;
-                if (need_mask) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + ROW_OF(r, hi);
-                        const bool dead = (key >= kv_len) || (p.causal && key > q);
-                        t[r] = dead ? NEG_INF : st[r] * c2;
-                        mx = fmaxf(mx, t[r]);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        t[r] = st[r] * c2;
-                        mx = fmaxf(mx, t[r]);
-                    }
-                }
-                mx = fmaxf(mx, other_half(mx));
-                const float m_new = fmaxf(m, mx);
-                const float m_use = (m_new == NEG_INF) ? 0.f : m_new;
-                float rs = 0.f;
-                bf16x8 pb[2];
+            for (int kt2 = 0; kt2 < 2; ++kt2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(t[r] - m_use);
-                    rs += pv;
-                    pb[r >> 3][r & 7] = (bf16)pv;
+                    const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);
+                    const bool dead = (key >= kv_len) || (p.causal && key > q);
+                    st[kt2][r] = dead ? NEG_INF : st[kt2][r];
                 }
-                rs += other_half(rs);
-                if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {  // some row's running max moved: rescale (rare after the first tiles)
-                    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
-                    l *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-                }
-                l += rs;
-                m = m_new;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) oacc[dt] = MFMA(T::tr_frag(vimg, offs, dt, 2 * kt2 + s2), pb[s2], oacc[dt]);
-            }
         }
-        __syncthreads();
+        // (no inline asm on MFMA results: the compiler's hazard recogniser does not see through asm and would not insert the
+        //  MFMA-write -> VALU-read wait states; this file is built with -fno-honor-nans so the maxima fold to bare v_max3_f32)
+        float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);
+        mx = fmaxf(mx, other_half(mx)) * c2;  // c2 > 0
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m + RESCALE_THR) != 0, 0)) {  // first tile (m = -inf), then rare
+            asm volatile("" ::);  // keeps this a real (almost never taken) branch: the compiler would otherwise speculate the O rescale
+            const float m_new = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - ((m_new == NEG_INF) ? 0.f : m_new));  // m = -inf -> 0
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m = m_new;
+        }
+        const float nm = (m == NEG_INF) ? 0.f : -m;
+        const f32x2 c2v = {c2, c2}, nmv = {nm, nm};
+        bf16x8 pb[4];
+        f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {  // packed fp32: v_pk_fma_f32 / v_pk_add_f32
+                const f32x2 s2 = {st[kt2][r], st[kt2][r + 1]};
+                const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, nmv);
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                rs2 += p2;
+                pb[2 * kt2 + (r >> 3)][r & 7] = (bf16)p2[0];
+                pb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
+            }
+        l += rs2[0] + rs2[1];
+        afk_frag_ring<DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
+            constexpr int dt = decltype(g_)::value;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) oacc[dt] = MFMA(f[s4], pb[s4], oacc[dt]);
+        }, fa, fb);
+    };
+
+    if (ntiles > 0) stage(0);
+    AFK_ATTN_BARRIER();
+    int j = 0;
+    const int n_fast = min(n_int, n_full - 1);  // tile j+1 must be a full tile for the pointer form of the prefetch
+    for (; j < n_fast; ++j) {
+        stage_fast(j + 1);
+        tile(j, std::false_type{});
+        AFK_ATTN_BARRIER();
+    }
+    for (; j < n_int; ++j) {
+        stage(min(j + 1, ntiles - 1));  // a redundant re-stage of the last tile lands in the other buffer and is never read
+        tile(j, std::false_type{});
+        AFK_ATTN_BARRIER();
+    }
+    for (; j < ntiles; ++j) {
+        stage(min(j + 1, ntiles - 1));
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});  // wave-uniform
+        AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
+        l += other_half(l);
         const float inv = (l > 0.f) ? 1.f / l : 0.f;
         bf16* Op = p.O + b * p.o_bs + h * p.o_hs + (int64_t)q * p.o_rs;
 #pragma unroll
@@ -250,6 +324,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ
+// Same geometry and loop structure as the forward (interior / boundary key tiles, opaque tr-reads issued ahead of the VALU block,
+// K/V prefetch in flight for the whole tile).  Per 64-key tile and wave: S^T = K.Q^T and dP^T = V.dO^T (4 x KS MFMAs on four
+// independent accumulators), dS = P o (dP - delta) with P = 2^(S*c2 - lse), dQ^T += K^T.dS (4 x DT MFMAs).
 template <int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
@@ -260,13 +337,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const typename T::Offs offs = T::make_offs(lane);
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
     const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
-    const bool wave_live = q0 < p.S;
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     const bf16* dOp = p.dO + b * p.do_bs + h * p.do_hs + (int64_t)qc * p.do_rs + hi * 8;
@@ -277,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         dof[ks] = *(const bf16x8*)(dOp + ks * 16);
     }
     const float c2 = p.scale * LOG2E;
-    const float lse2 = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];  // already in the log2 domain
-    const float dlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];
+    const float nlse = -p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];  // log2 domain
+    const float ndlt = -p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];
     const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
     const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
 
@@ -288,53 +363,104 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
 
     const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;
     const int ntiles = (kv_end_blk + 63) >> 6;
+    const int n_int = p.causal ? min(qb0, kv_len) >> 6 : kv_len >> 6;
     const int kv_end = p.causal ? min(kv_len, q0 + 32) : kv_len;
+    const int n_full = p.S >> 6;
+    const uint32_t lds0 = afk_lds_addr(smem);
+    uint32_t ktr[DT][2];  // K^T fragment addresses in buffer 0
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) ktr[dt][pc] = lds0 + offs.tr[dt][pc];
 
     auto stage = [&](int j) {
         char* buf = smem + (j & 1) * 2 * T::BYTES;
         T::stage(buf, Kbase, p.k_rs, j * 64, p.S - 1, wave, lane);
         T::stage(buf + T::BYTES, Vbase, p.v_rs, j * 64, p.S - 1, wave, lane);
     };
-    if (ntiles > 0) stage(0);
-    __syncthreads();
-    for (int j = 0; j < ntiles; ++j) {
-        if (j + 1 < ntiles) stage(j + 1);
+    constexpr int NP = T::UNITS / 4;
+    const bf16* ksrc[NP];
+    const bf16* vsrc[NP];
+#pragma unroll
+    for (int u0 = 0; u0 < NP; ++u0) {
+        const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
+        ksrc[u0] = Kbase + (int64_t)r * p.k_rs + chunk * 8;
+        vsrc[u0] = Vbase + (int64_t)r * p.v_rs + chunk * 8;
+    }
+    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
+    auto stage_fast = [&](int j) {
+        char* buf = smem + (j & 1) * 2 * T::BYTES;
+#pragma unroll
+        for (int u0 = 0; u0 < NP; ++u0) {
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ksrc[u0] + j * kstep), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc[u0] + j * vstep), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+        }
+    };
+
+    auto tile = [&](int j, auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
         const char* kimg = smem + (j & 1) * 2 * T::BYTES;
         const char* vimg = kimg + T::BYTES;
+        const uint32_t boff = (j & 1) * 2 * T::BYTES;
+        f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
 #pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2) {
-            const int key0 = j * 64 + kt2 * 32;
-            if (wave_live && key0 < kv_end) {
-                f32x16 st = zero16(), dp = zero16();
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    st = MFMA(T::row_frag(kimg, offs, kt2, ks), qf[ks], st);
-                    dp = MFMA(T::row_frag(vimg, offs, kt2, ks), dof[ks], dp);
-                }
-                bf16x8 dsb[2];
-                const bool need_mask = (key0 + 32 > kv_len) || (p.causal && key0 + 31 > q0);
-                if (need_mask) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + ROW_OF(r, hi);
-                        const bool dead = (key >= kv_len) || (p.causal && key > q);
-                        const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - lse2);
-                        dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - dlt));
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - lse2);
-                        dsb[r >> 3][r & 7] = (bf16)(pv * (dp[r] - dlt));
-                    }
-                }
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) dqacc[dt] = MFMA(T::tr_frag(kimg, offs, dt, 2 * kt2 + s2), dsb[s2], dqacc[dt]);
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
+            st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+            dp[0] = MFMA(T::row_frag(vimg, offs, 0, ks), dof[ks], dp[0]);
+            dp[1] = MFMA(T::row_frag(vimg, offs, 1, ks), dof[ks], dp[1]);
         }
-        __syncthreads();
+        bf16x8 fa[4], fb[4];  // K^T fragments: d-tile 0 in flight during the VALU block, the rest through the ring
+        auto issue = [&](auto g_, bf16x8(&dst)[4]) {
+            constexpr int dt = decltype(g_)::value;
+            const uint32_t a0 = ktr[dt][0] + boff, a1 = ktr[dt][1] + boff;
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<s4 * 16 * T::RS>(a0, a1); });
+        };
+        issue(std::integral_constant<int, 0>{}, fa);
+        const f32x2 c2v = {c2, c2}, nl = {nlse, nlse}, nd = {ndlt, ndlt};
+        bf16x8 dsb[4];
+#pragma unroll
+        for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 s2 = {st[kt2][r], st[kt2][r + 1]};
+                const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, nl);
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                const f32x2 d2 = {dp[kt2][r], dp[kt2][r + 1]};
+                f32x2 ds2 = p2 * (d2 + nd);
+                if (MASKED) {
+                    const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);  // r even: rows key, key+1
+                    if ((key >= kv_len) || (p.causal && key > q)) ds2[0] = 0.f;
+                    if ((key + 1 >= kv_len) || (p.causal && key + 1 > q)) ds2[1] = 0.f;
+                }
+                dsb[2 * kt2 + (r >> 3)][r & 7] = (bf16)ds2[0];
+                dsb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)ds2[1];
+            }
+        afk_frag_ring<DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
+            constexpr int dt = decltype(g_)::value;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) dqacc[dt] = MFMA(f[s4], dsb[s4], dqacc[dt]);
+        }, fa, fb);
+    };
+
+    if (ntiles > 0) stage(0);
+    AFK_ATTN_BARRIER();
+    int j = 0;
+    const int n_fast = min(n_int, n_full - 1);
+    for (; j < n_fast; ++j) {
+        stage_fast(j + 1);
+        tile(j, std::false_type{});
+        AFK_ATTN_BARRIER();
+    }
+    for (; j < n_int; ++j) {
+        stage(min(j + 1, ntiles - 1));
+        tile(j, std::false_type{});
+        AFK_ATTN_BARRIER();
+    }
+    for (; j < ntiles; ++j) {
+        stage(min(j + 1, ntiles - 1));
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
         bf16* dQp = p.dQ + b * p.dq_bs + h * p.dq_hs + (int64_t)q * p.dq_rs;
@@ -352,6 +478,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // block = 128 keys of one kv head (wave = 32 keys); streams 64-query tiles of Q and dO of every head of the GQA group.
+// Per tile and wave: S = Q.K^T and dP = dO.V^T (4 x KS MFMAs, K/V of the wave's 32 keys live in registers), P / dS as in the dQ
+// kernel (per-query lse / delta: two float4 loads per 8 queries, issued BEFORE the tile's LDS-DMA prefetch so that waiting for them
+// never waits for the prefetch), dV^T += dO^T.P and dK^T += Q^T.dS (8 x DT MFMAs, transposed fragments by opaque tr-reads in two
+// halves).  Interior tiles = every (query, key) pair of the tile visible; boundary = causal diagonal, ragged S, padded keys.
 template <int D>
 __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
@@ -377,16 +507,11 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
 
     const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
     const bf16* Vp = p.V + b * p.v_bs + hk * p.v_hs + (int64_t)keyc * p.v_rs + hi * 8;
-    // head_dim 64: this wave's 32 keys stay in registers for the whole sweep; head_dim 128 would spill, it re-reads
-    // its 8 KiB of K/V rows from L1/L2 per tile instead
-    constexpr bool HOIST = true;  // head_dim 128 runs one wave per SIMD (launch bound) so that 64 operand VGPRs fit beside 128 accumulators
-    bf16x8 kf[HOIST ? KS : 1], vf[HOIST ? KS : 1];
-    if (HOIST) {
+    bf16x8 kf[KS], vf[KS];  // this wave's 32 keys, resident for the whole sweep (head_dim 128 runs one wave per SIMD to afford it)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = *(const bf16x8*)(Kp + ks * 16);
-            vf[ks] = *(const bf16x8*)(Vp + ks * 16);
-        }
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *(const bf16x8*)(Kp + ks * 16);
+        vf[ks] = *(const bf16x8*)(Vp + ks * 16);
     }
 
     f32x16 dkacc[DT], dvacc[DT];
@@ -399,79 +524,113 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     const int qt_end = (p.S + 63) >> 6;
     const int per_head = qt_end - qt_begin;
     const int ntiles = per_head * g_count;
+    // interior query tiles of one head: [qt_int0, qt_int1): all 64 queries exist, causal: every query >= every key of the block;
+    // a block holding padded keys (kb0 + 128 > kv_len) has none
+    const int qt_int0 = (kb0 + 128 > kv_len) ? qt_end : (p.causal ? min((kb0 + 128 + 63) >> 6, qt_end) : 0);
+    const int qt_int1 = max(p.S >> 6, qt_int0);
+    const uint32_t lds0 = afk_lds_addr(smem);
+    uint32_t qtr[DT][2];  // Q^T fragment addresses in buffer 0 (dO^T: + T::BYTES)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) qtr[dt][pc] = lds0 + offs.tr[dt][pc];
 
+    // lse / delta of the tile's 64 queries travel with the tile: one extra 1-KiB LDS-DMA piece per tile (wave 0; lanes 0-15 fetch
+    // lse[64], lanes 16-31 delta[64], the upper half duplicates them) into a stats strip behind the two images.  Each lane then
+    // ds_reads the 4 consecutive queries it needs right where it uses them - as global loads they either sat in 64 VGPRs or made
+    // the wave wait for the prefetch queued behind them.
+    constexpr int STATS = 2 * T::BYTES;      // offset of the strip inside a buffer
+    constexpr int BUF = 2 * T::BYTES + 1024;  // buffer pitch
+    auto stage_stats = [&](int t, int h, int qt) {
+        if (wave == 0) {
+            const float* src = ((lane & 16) ? p.delta : p.LSE) + ((int64_t)b * p.Hq + h) * p.Spad + qt * 64 + (lane & 15) * 4;
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + (t & 1) * BUF + STATS), 16, 0, 0);
+        }
+    };
     auto stage = [&](int t) {
-        const int gi = t / per_head, qt = qt_begin + (t - gi * per_head);
+        const int tt = min(t, ntiles - 1);
+        const int gi = tt / per_head, qt = qt_begin + (tt - gi * per_head);
         const int h = hk * group + g_begin + gi;
-        char* buf = smem + (t & 1) * 2 * T::BYTES;
+        char* buf = smem + (t & 1) * BUF;
         T::stage(buf, p.Q + b * p.q_bs + h * p.q_hs, p.q_rs, qt * 64, p.S - 1, wave, lane);
         T::stage(buf + T::BYTES, p.dO + b * p.do_bs + h * p.do_hs, p.do_rs, qt * 64, p.S - 1, wave, lane);
+        stage_stats(t, h, qt);
     };
-    if (ntiles > 0) stage(0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) stage(t + 1);
-        const int gi = t / per_head, qt = qt_begin + (t - gi * per_head);
-        const int h = hk * group + g_begin + gi;
-        const char* qimg = smem + (t & 1) * 2 * T::BYTES;
+
+    auto body = [&](int t, int qt, auto masked_) {
+        constexpr bool MASKED = decltype(masked_)::value;
+        const char* qimg = smem + (t & 1) * BUF;
         const char* doimg = qimg + T::BYTES;
-        const float* lse = p.LSE + ((int64_t)b * p.Hq + h) * p.Spad;
-        const float* dlt = p.delta + ((int64_t)b * p.Hq + h) * p.Spad;
+        const float* stats = (const float*)(qimg + STATS) + 4 * hi;
+        const uint32_t boff = (t & 1) * BUF;
+        f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
 #pragma unroll
-        for (int qt2 = 0; qt2 < 2; ++qt2) {
-            const int qt0 = qt * 64 + qt2 * 32;
-            // causal: a 32-query half entirely before this wave's keys contributes nothing
-            if (wave_live && qt0 < p.S && !(p.causal && qt0 + 31 < key0)) {
-                // softmax statistics first: their global-load latency hides under the QK^T / dO.V^T MFMAs
-                f32x4 l4v[4], d4v[4];
-#pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    l4v[qd] = *(const f32x4*)(lse + qt0 + 8 * qd + 4 * hi);  // 4 consecutive queries, inside [0, Spad)
-                    d4v[qd] = *(const f32x4*)(dlt + qt0 + 8 * qd + 4 * hi);
-                }
-                f32x16 st = zero16(), dp = zero16();
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    st = MFMA(T::row_frag(qimg, offs, qt2, ks), HOIST ? kf[HOIST ? ks : 0] : *(const bf16x8*)(Kp + ks * 16), st);
-                    dp = MFMA(T::row_frag(doimg, offs, qt2, ks), HOIST ? vf[HOIST ? ks : 0] : *(const bf16x8*)(Vp + ks * 16), dp);
-                }
-                bf16x8 pb[2], dsb[2];
-                const bool need_mask = (key0 + 32 > kv_len) || (qt0 + 32 > p.S) || (p.causal && key0 + 31 > qt0);
-                if (need_mask) {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const int qq0 = qt0 + 8 * qd + 4 * hi;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * qd + e;
-                            const int qq = qq0 + e;
-                            const bool dead = key_dead || (qq >= p.S) || (p.causal && key > qq);
-                            const float pv = dead ? 0.f : __builtin_amdgcn_exp2f(st[r] * c2 - l4v[qd][e]);
-                            pb[r >> 3][r & 7] = (bf16)pv;
-                            dsb[r >> 3][r & 7] = (bf16)(dead ? 0.f : pv * (dp[r] - d4v[qd][e]));
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int r = 4 * qd + e;
-                            const float pv = __builtin_amdgcn_exp2f(st[r] * c2 - l4v[qd][e]);
-                            pb[r >> 3][r & 7] = (bf16)pv;
-                            dsb[r >> 3][r & 7] = (bf16)(pv * (dp[r] - d4v[qd][e]));
-                        }
-                }
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        dvacc[dt] = MFMA(T::tr_frag(doimg, offs, dt, 2 * qt2 + s2), pb[s2], dvacc[dt]);
-                        dkacc[dt] = MFMA(T::tr_frag(qimg, offs, dt, 2 * qt2 + s2), dsb[s2], dkacc[dt]);
-                    }
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            st[0] = MFMA(T::row_frag(qimg, offs, 0, ks), kf[ks], st[0]);
+            st[1] = MFMA(T::row_frag(qimg, offs, 1, ks), kf[ks], st[1]);
+            dp[0] = MFMA(T::row_frag(doimg, offs, 0, ks), vf[ks], dp[0]);
+            dp[1] = MFMA(T::row_frag(doimg, offs, 1, ks), vf[ks], dp[1]);
         }
-        __syncthreads();
+        // transposed fragments: group 2*dt = dO^T d-tile dt (-> dV), group 2*dt+1 = Q^T d-tile dt (-> dK); group 0 in flight during the
+        // VALU block, the rest through the two-deep ring
+        bf16x8 fa[4], fb[4];
+        auto issue = [&](auto g_, bf16x8(&dst)[4]) {
+            constexpr int g = decltype(g_)::value, dt = g >> 1;
+            constexpr int IMG = (g & 1) ? 0 : T::BYTES;
+            const uint32_t a0 = qtr[dt][0] + boff, a1 = qtr[dt][1] + boff;
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<IMG + s4 * 16 * T::RS>(a0, a1); });
+        };
+        issue(std::integral_constant<int, 0>{}, fa);
+        const f32x2 c2v = {c2, c2};
+        bf16x8 pb[4], dsb[4];
+#pragma unroll
+        for (int qt2 = 0; qt2 < 2; ++qt2)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int r = 4 * qd + e;
+                    const f32x2 s2 = {st[qt2][r], st[qt2][r + 1]};
+                    const f32x2 l2 = *(const f32x2*)(stats + qt2 * 32 + 8 * qd + e);
+                    const f32x2 dl2 = *(const f32x2*)(stats + 64 + qt2 * 32 + 8 * qd + e);
+                    const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, -l2);
+                    f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                    const f32x2 d2 = {dp[qt2][r], dp[qt2][r + 1]};
+                    if (MASKED) {
+                        const int qq = qt * 64 + qt2 * 32 + 8 * qd + 4 * hi + e;
+                        if (key_dead || (qq >= p.S) || (p.causal && key > qq)) p2[0] = 0.f;
+                        if (key_dead || (qq + 1 >= p.S) || (p.causal && key > qq + 1)) p2[1] = 0.f;
+                    }
+                    const f32x2 ds2 = p2 * (d2 - dl2);
+                    pb[2 * qt2 + (r >> 3)][r & 7] = (bf16)p2[0];
+                    pb[2 * qt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
+                    dsb[2 * qt2 + (r >> 3)][r & 7] = (bf16)ds2[0];
+                    dsb[2 * qt2 + (r >> 3)][(r & 7) + 1] = (bf16)ds2[1];
+                }
+        afk_frag_ring<2 * DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
+            constexpr int g = decltype(g_)::value, dt = g >> 1;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                if (g & 1) dkacc[dt] = MFMA(f[s4], dsb[s4], dkacc[dt]);
+                else dvacc[dt] = MFMA(f[s4], pb[s4], dvacc[dt]);
+            }
+        }, fa, fb);
+    };
+
+    if (ntiles > 0) stage(0);
+    AFK_ATTN_BARRIER();
+    int t = 0;
+    for (int gi = 0; gi < g_count; ++gi) {
+        const int h = hk * group + g_begin + gi;
+        for (int qt = qt_begin; qt < qt_end; ++qt, ++t) {
+            stage(t + 1);  // clamped to the last tile (a redundant re-stage lands in the other buffer and is never read)
+            if (qt >= qt_int0 && qt < qt_int1) {
+                body(t, qt, std::false_type{});
+            } else if (wave_live && !(p.causal && qt * 64 + 63 < key0)) {  // wave-uniform: causal tiles entirely before this wave's keys contribute nothing
+                body(t, qt, std::true_type{});
+            }
+            AFK_ATTN_BARRIER();
+        }
     }
     if (key < p.S) {
         bf16* dKp = p.dK + b * p.dk_bs + hy * p.dk_hs + (int64_t)key * p.dk_rs;
@@ -640,16 +799,16 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)(split ? Hq : Hkv), (unsigned)B);
     dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
     if (D == 128) {
-        constexpr int L = 4 * Tile<128>::BYTES;
-        static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, L) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
+        constexpr int L = 4 * Tile<128>::BYTES, LKV = L + 2048;  // dK/dV sweep: + one lse/delta strip per buffer
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), L, st, pk);
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), LKV, st, pk);
         hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
     } else {
-        constexpr int L = 4 * Tile<64>::BYTES;
-        static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, L) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
+        constexpr int L = 4 * Tile<64>::BYTES, LKV = L + 2048;
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
         (void)once;
-        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), L, st, pk);
+        hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
         hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
     }
     if (split) {

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <type_traits>
+#include <utility>
 
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -35,6 +37,73 @@ int afk_set_error(int code, const char* fmt, ...);
     } while (0)
 
 static inline int64_t afk_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------- compile-time loops (immediates for inline asm)
+template <typename F, int... I>
+__device__ __forceinline__ void afk_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void afk_static_for(F&& f) {
+    afk_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------- ds_read_b64_tr_b16 as OPAQUE inline asm
+// The compiler's waitcnt pass treats the builtin form (__builtin_amdgcn_ds_read_tr16_b64_*) as "may alias an LDS-DMA
+// (global_load_lds) destination" and plants an s_waitcnt vmcnt(0) in front of it - which drains every prefetch in flight and
+// serialises a double-buffered pipeline (plain ds_read_b128 loads do not get that wait).  Issued as asm the read is invisible
+// to that pass; the price is that the CALLER owns the data hazard: call afk_lds_wait0(frag...) (s_waitcnt lgkmcnt(0) tied to
+// the registers) before the first use, and order the read against the DMA that filled the image with a counted vmcnt +
+// barrier.  LDS returns in order, so the compiler's own counted lgkmcnt waits stay safe (they can only over-wait).
+__device__ __forceinline__ uint32_t afk_lds_addr(const void* generic_ptr_into_lds) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)generic_ptr_into_lds;
+}
+template <int OFF>
+__device__ __forceinline__ bf16x4 afk_lds_tr16_b64(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// two tr-reads -> one MFMA k-operand (8 consecutive k)
+template <int OFF>
+__device__ __forceinline__ bf16x8 afk_lds_tr_frag(uint32_t addr0, uint32_t addr1) {
+    const bf16x4 a = afk_lds_tr16_b64<OFF>(addr0);
+    const bf16x4 b = afk_lds_tr16_b64<OFF>(addr1);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void afk_lds_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <typename T0, typename... Ts>
+__device__ __forceinline__ void afk_lds_tie(T0& a, Ts&... rest) {
+    asm volatile("" : "+v"(a));  // every later use of `a` is ordered after this point (and so after the wait before it)
+    if constexpr (sizeof...(rest) > 0) afk_lds_tie(rest...);
+}
+template <typename... Ts>
+__device__ __forceinline__ void afk_lds_wait0(Ts&... frags) {
+    afk_lds_wait0();
+    afk_lds_tie(frags...);
+}
+// Two-deep ring of fragment groups (4 fragments = 8 tr-reads per group) read with the opaque asm form: while the MFMAs of group g
+// run, the reads of group g+1 are in flight.  issue(integral_constant<g>, dst[4]) emits the 8 reads of group g; use(integral_constant<g>,
+// frags[4]) consumes them.  Group 0 must already have been issued into `fa` by the caller (typically ahead of a VALU block, so
+// that its latency hides there).  lgkmcnt counts at most 15, hence one group of 8 in flight behind the one being waited for; LDS
+// returns in order, so lgkmcnt(8) right after issuing group g+1 means group g has landed.
+template <int NG, typename Issue, typename Use>
+__device__ __forceinline__ void afk_frag_ring(Issue&& issue, Use&& use, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) {
+    afk_static_for<NG>([&](auto g_) {
+        constexpr int g = decltype(g_)::value;
+        bf16x8(&cur)[4] = (g & 1) ? fb : fa;
+        bf16x8(&nxt)[4] = (g & 1) ? fa : fb;
+        if constexpr (g + 1 < NG) {
+            issue(std::integral_constant<int, g + 1>{}, nxt);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        } else {
+            afk_lds_wait0();
+        }
+        afk_lds_tie(cur[0], cur[1], cur[2], cur[3]);
+        use(g_, cur);
+    });
+}
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }

@@ -58,13 +58,11 @@ __device__ __forceinline__ int tr_off(int tile32, int pc, int lane) {
     const int r = 8 * hi + (i >> 2) + 4 * pc;  // + 16*s
     return r * TROW + ((chunk ^ tswz(r)) << 4) + 8 * (i & 1);
 }
-__device__ __forceinline__ bf16x8 tr_frag(const char* img, int off0, int off1, int s) {
-    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off0 + s * 16 * TROW));
-    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off1 + s * 16 * TROW));
-    bf16x8 v;
-    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    return v;
+// opaque-asm reads (common.h: the builtin form drags an s_waitcnt vmcnt(0) into the loop); every MEM segment ends with
+// AFK_LGKMCNT0 + a scheduling barrier before the first MFMA, which is the wait these reads need
+template <int S>
+__device__ __forceinline__ bf16x8 tr_frag(uint32_t buf, int off0, int off1) {
+    return afk_lds_tr_frag<S * 16 * TROW>(buf + off0, buf + off1);
 }
 
 // per-lane source of one LDS-DMA piece (1 KiB = 2 k-rows x 512 B) of a transposed image
@@ -185,16 +183,17 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
     if (wm == 1) AFK_BARRIER();
 
     bf16x8 bf[2][4], af[AT ? 4 : 2][AT ? 2 : 4];
+    const uint32_t lds0 = afk_lds_addr(smem);
     for (int t = 0; t < T; ++t) {
         const char* buf = smem + (t & 1) * BUF_BYTES;
+        const uint32_t lbuf = lds0 + (t & 1) * BUF_BYTES;
         const int t1 = min(t + 1, T - 1), t2 = min(t + 2, T - 1);
         const int e1 = (t + 1) & 1, e2 = t & 1;
         if (!AT) {
             // ================= NN  MEM_a: Bt fragments (whole tile) + A rows 0..63
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) bf[j][s] = tr_frag(buf, tob[j][0], tob[j][1], s);
+                afk_static_for<4>([&](auto s_) { constexpr int s = decltype(s_)::value; bf[j][s] = tr_frag<s>(lbuf, tob[j][0], tob[j][1]); });
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -243,13 +242,20 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 // ================= TN  MEM: fragments of k-steps {2ph, 2ph+1} of both images
+                afk_static_for<2>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value;
+                    if (ph == 0) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
+                        for (int j = 0; j < 2; ++j) bf[j][s] = tr_frag<s>(lbuf, tob[j][0], tob[j][1]);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[j][s] = tr_frag(buf, tob[j][0], tob[j][1], 2 * ph + s);
+                        for (int i = 0; i < 4; ++i) af[i][s] = tr_frag<s>(lbuf, toa[i][0], toa[i][1]);
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i][s] = tr_frag(buf, toa[i][0], toa[i][1], 2 * ph + s);
-                }
+                        for (int j = 0; j < 2; ++j) bf[j][s] = tr_frag<2 + s>(lbuf, tob[j][0], tob[j][1]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i][s] = tr_frag<2 + s>(lbuf, toa[i][0], toa[i][1]);
+                    }
+                });
                 AFK_LGKMCNT0();
                 if (kvalid < BK) {  // block-uniform, last tile only: zero the A contribution of k >= K
 #pragma unroll

@@ -13,6 +13,8 @@ Backward GEMM forms (all on the one NT kernel, csrc/gemm.hip):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -35,6 +37,17 @@ def _wgrad(arena: Arena, blk: Block, dyt, xt, Mvalid, *, bias_blk=None, bias_sli
         arena.grad_written(bias_blk)
 
 
+# "nt": every backward GEMM on the NT kernel (operand transposes + W^T shadows); "direct": dgrad on the NN kernel and wgrad on the TN
+# kernel (operands as they lie) wherever the output has at least DIRECT_MIN_TILES 256x256 tiles (the transposed-operand kernels have no
+# small-tile variant)
+BWD_FORM = os.environ.get("AFK_BWD_FORM", "nt")
+DIRECT_MIN_TILES = 192
+
+
+def _tiles256(m, n):
+    return ((m + 255) // 256) * ((n + 255) // 256)
+
+
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True):
     """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena.
     The weight-gradient branch (two operand transposes + wgrad GEMM + bias row-sum) is independent of the data-gradient
@@ -42,8 +55,19 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
     M = dy.shape[0]
     blk = arena[wkey]
     side = arena.wgrad_stream
+    N, K = dy.shape[1], x.shape[1]
+    direct = BWD_FORM == "direct"
 
     def wgrad_branch():
+        if direct and _tiles256(N, K) >= DIRECT_MIN_TILES:
+            ops.gemm(dy, x, out=blk.grad.reshape(blk.shape[0], -1), trans_a=True, trans_b=True, accumulate=not blk.fresh)
+            arena.grad_written(blk)
+            if bkey:
+                bb = arena[bkey]
+                for (s, e) in (bias_slices or [(0, N)]):
+                    ops.colsum(dy[:, s:e], bb.grad[s:e], accumulate=not bb.fresh)
+                arena.grad_written(bb)
+            return
         dyt = ops.transpose(dy)  # [N, Mp]
         xt = ops.transpose(x)    # [K, Mp]
         _wgrad(arena, blk, dyt, xt, M, bias_blk=arena[bkey] if bkey else None, bias_slices=bias_slices)
@@ -64,6 +88,8 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
         x.record_stream(side)
     if not need_dx:
         return None
+    if direct and _tiles256(M, K) >= DIRECT_MIN_TILES:
+        return ops.gemm(dy, blk.data.reshape(blk.shape[0], -1), trans_b=True)  # dX = dY . W, W as stored
     wt = arena.shadow(wkey)  # [K, pad64(N)]
     return ops.gemm_nt(dy, wt, K=dy.shape[1])
 
@@ -365,7 +391,8 @@ class LMHeadLossFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_grad else None
         chunk = min(LMHeadLossFn.CHUNK, M)
         buf = torch.empty((chunk, V), device=dev, dtype=torch.bfloat16)
-        wt = arena.shadow(wkey) if need_grad else None
+        direct = BWD_FORM == "direct"
+        wt = arena.shadow(wkey) if need_grad and not direct else None
         if need_grad:
             # unscaled lm_head gradient goes to a private buffer when it must be accumulated into existing grads
             gw_tmp = blk.grad if blk.fresh else torch.empty_like(blk.grad)
@@ -376,7 +403,11 @@ class LMHeadLossFn(torch.autograd.Function):
             logits = buf[:n]
             ops.gemm_nt(x[s:e], blk.data, out=logits)
             ops.ce_fwd_bwd_(logits, shift_labels[s:e], row_loss[s:e], denom, upstream=1.0, write_grad=need_grad)
-            if need_grad:
+            if need_grad and direct:
+                ops.gemm(logits, blk.data, out=dx[s:e], trans_b=True)                               # dX = dlogits . W
+                ops.gemm(logits, x[s:e], out=gw_tmp, trans_a=True, trans_b=True, accumulate=not first)  # dW += dlogits^T . X
+                first = False
+            elif need_grad:
                 ops.gemm_nt(logits, wt, out=dx[s:e], K=V)
                 dlt = ops.transpose(logits)      # [V, pad64(n)]
                 xt = ops.transpose(x[s:e])       # [H, pad64(n)]

@@ -190,6 +190,8 @@ def main():
         engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
         engine.broadcast_parameters(0)
         opt.master.copy_(model.arena.params)
+    from audio_flamingo_amd import functional as F_
+    model.arena.lazy_T_shadows = F_.BWD_FORM == "direct"
     model.arena.refresh_shadows(force=True)
     model.arena.enable_wgrad_stream(not args.no_wgrad_stream)
     model.arena.thin_blocks = int(os.environ.get("AFK_THIN_TRANSPOSE", "0"))

@@ -399,6 +399,51 @@ def test_attention_online_softmax_spike(dev):
     _cmp("attn spike", o, _attn_ref(qkv, B, S, H, H, D, D ** -0.5, False, None), 2e-2, 2e-2)
 
 
+@pytest.mark.parametrize("name,B,S,Hq,Hkv,D,causal", [("encoder", 8, 1500, 20, 20, 64, False), ("decoder", 8, 1024, 28, 4, 128, True),
+                                                     ("long", 1, 3000, 28, 4, 128, True)])
+def test_attention_full_size_bit_deterministic(dev, name, B, S, Hq, Hkv, D, causal):
+    """the AF3-7B attention shapes with the chip full (thousands of co-resident blocks): three runs must agree bit for bit (a missed
+    LDS / MFMA hazard shows up as run-to-run noise only at this scale), and a sample of rows must match the fp32 reference"""
+    ops = _ops()
+    qkv = _rand((B * S, (Hq + 2 * Hkv) * D), dev, 1.0, 5).to(BF)
+    do = _rand((B * S, Hq * D), dev, 1.0, 6).to(BF)
+    scale = D ** -0.5
+    outs = []
+    for _ in range(3):
+        o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=causal)
+        dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=causal)
+        outs.append((o.clone(), lse.clone(), dqkv.clone()))
+    torch.cuda.synchronize()
+    for o, lse, dqkv in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(lse, outs[0][1]), f"{name}: forward not deterministic"
+        assert torch.equal(dqkv, outs[0][2]), f"{name}: backward not deterministic"
+    # fp32 reference on batch 0, first 2 query heads / their kv head (keeps the reference small)
+    g = Hq // Hkv
+    hq = min(2, g) if g > 1 else 2
+    q = qkv[:S, : hq * D]
+    k = qkv[:S, Hq * D: Hq * D + (D if g > 1 else hq * D)]
+    v = qkv[:S, (Hq + Hkv) * D: (Hq + Hkv) * D + (D if g > 1 else hq * D)]
+    sub = torch.cat([q, k, v], 1).contiguous()
+    ref = _attn_ref(sub, 1, S, hq, 1 if g > 1 else hq, D, scale, causal, None)
+    _cmp(f"{name} fwd sample", outs[0][0][:S, : hq * D], ref, atol=2e-2, rtol=2e-2)
+
+
+def test_attention_lazy_rescale_ramp(dev):
+    """scores that keep growing along the key axis, by small steps (below the rescale threshold) and by jumps (above it): the stale
+    running max of the lazy-rescale forward must stay exact"""
+    ops = _ops()
+    B, S, H, D = 1, 1024, 2, 64
+    qkv = _rand((B * S, 3 * H * D), dev, 0.05, 7).to(BF)
+    ramp = torch.linspace(0.0, 6.0, S, device=dev)
+    ramp[700:] += 8.0
+    qkv[:, :D] = 1.0                                     # head 0 queries: all ones
+    qkv[:, H * D: H * D + D] = (ramp[:, None] * torch.ones(D, device=dev)).to(BF)  # head 0 keys: k_j = ramp_j -> s_ij = D * ramp_j * scale
+    o, lse = ops.attn_fwd(qkv, B, S, H, H, D, scale=D ** -0.5, causal=False)
+    _cmp("ramp fwd", o, _attn_ref(qkv, B, S, H, H, D, D ** -0.5, False, None), 2e-2, 2e-2)
+    oc, _ = ops.attn_fwd(qkv, B, S, H, H, D, scale=D ** -0.5, causal=True)
+    _cmp("ramp fwd causal", oc, _attn_ref(qkv, B, S, H, H, D, D ** -0.5, True, None), 2e-2, 2e-2)
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()
