@@ -866,6 +866,38 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
     return AFK_OK;
 }
 
+namespace {
+// KV-cache append (decode path): rows r = b*n + i of the fused projection output hold the new token's K (already rotated) and V;
+// K goes to Kc[b][start+i][:] (row-major), V to Vt[b][h][d][start+i] (stored transposed: the layout the interval attention kernels
+// read).  `start` comes from device memory when start_dev != null, so a captured HIP graph of one decode step can be replayed
+// while the position advances on the device.
+__global__ __launch_bounds__(256) void kv_append_kernel(const bf16* __restrict__ qkv, int64_t ld, int k_col0, bf16* __restrict__ Kc,
+                                                        int64_t kc_bs, bf16* __restrict__ Vt, int64_t vt_bs, int spad,
+                                                        const int* __restrict__ start_dev, int start_host, int B, int n, int Hkv, int D) {
+    const int nk = Hkv * D;
+    const int start = start_dev ? *start_dev : start_host;
+    const int64_t total = (int64_t)B * n * nk;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % nk);
+        const int64_t r = t / nk;
+        const int i = (int)(r % n), b = (int)(r / n);
+        const bf16* row = qkv + r * ld + k_col0;
+        Kc[b * kc_bs + (int64_t)(start + i) * nk + c] = row[c];
+        Vt[b * vt_bs + (int64_t)c * spad + start + i] = row[nk + c];  // c = h*D + d
+    }
+}
+}  // namespace
+
+extern "C" int afk_kv_cache_append(const void* qkv, int64_t ld, int k_col0, void* kcache, int64_t kc_bs, void* vtcache, int64_t vt_bs,
+                                   int spad, const int* start_dev, int start_host, int B, int n, int Hkv, int D, void* stream) {
+    AFK_REQUIRE(qkv && kcache && vtcache && B > 0 && n > 0 && Hkv > 0 && D > 0 && spad > 0, "afk_kv_cache_append: bad args");
+    const int64_t total = (int64_t)B * n * Hkv * D;
+    hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, ST, (const bf16*)qkv, ld, k_col0, (bf16*)kcache, kc_bs,
+                       (bf16*)vtcache, vt_bs, spad, start_dev, start_host, B, n, Hkv, D);
+    AFK_LAUNCH_CHECK("afk_kv_cache_append");
+    return AFK_OK;
+}
+
 extern "C" int afk_relu_fwd(const void* x, void* y, int64_t n, void* stream) {
     AFK_REQUIRE(x && y && n % 8 == 0, "afk_relu_fwd: n must be a multiple of 8");
     hipLaunchKernelGGL(relu_fwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, n / 8);

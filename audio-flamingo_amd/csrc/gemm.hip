@@ -89,10 +89,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nkt = p.K / BK;
-    stage(0, 0);
+    int kt0 = 0, nkt = p.K / BK;
+    if (p.splits > 1) {  // split-K: this block reduces K-tiles [kt0, nkt) of the tile
+        const int all = nkt, sp = blockIdx.y;
+        kt0 = (int)((int64_t)all * sp / p.splits);
+        nkt = (int)((int64_t)all * (sp + 1) / p.splits);
+    }
+    if (kt0 < nkt) stage(kt0 & 1, kt0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = kt0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
         const char* sa = smem + cur * STAGE_BYTES;
@@ -127,9 +132,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                gemm_epilogue_store4(p, m, n, v);
+                if (p.splits > 1) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.ws + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = o;
+                } else {
+                    gemm_epilogue_store4(p, m, n, v);
+                }
             }
         }
+    }
+}
+
+// split-K second pass: fixed-order sum of the partials (bit-deterministic), then the same fused epilogue as the one-pass kernels
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
+    const int n4 = p.N >> 2;
+    const int64_t total = (int64_t)p.M * n4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(t / n4), n = (int)(t % n4) * 4;
+        const float* src = p.ws + (int64_t)m * p.N + n;
+        f32x4 acc = *(const f32x4*)src;
+        for (int sp = 1; sp < p.splits; ++sp) {
+            const f32x4 x = *(const f32x4*)(src + (int64_t)sp * p.M * p.N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += x[e];
+        }
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        gemm_epilogue_store4(p, m, n, v);
     }
 }
 
@@ -202,7 +230,8 @@ extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* 
 
 static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
-                     int res_mod, void* preact_out, float alpha, int flags, void* stream) {
+                     int res_mod, void* preact_out, float alpha, int flags, void* stream, int splits = 1, void* workspace = nullptr) {
+    AFK_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || (workspace && !trans_b)), "afk_gemm_nt_bf16_splitk: 1..64 splits, workspace required, NT form only");
     AFK_REQUIRE(A && B && C, "afk_gemm_nt_bf16: null operand");
     AFK_REQUIRE(M > 0 && N > 0 && K > 0, "afk_gemm_nt_bf16: bad shape %d %d %d", M, N, K);
     AFK_REQUIRE(!trans_a || trans_b, "afk_gemm_bf16: A^T with k-contiguous B is not implemented (NT, NN, TN are)");
@@ -232,9 +261,11 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.res_mod = res_mod;
     p.alpha = alpha;
     p.gm = g_gm;
+    p.splits = splits;
+    p.ws = (float*)workspace;
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = trans_b || g_variant == 2 || (g_variant == 0 && tiles256 >= 192);
+    const bool use256 = splits == 1 && (trans_b || g_variant == 2 || (g_variant == 0 && tiles256 >= 192));
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -264,7 +295,12 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     } else if (use256) {
         if (int e = afk_launch_gemm256(p, st)) return e;
     } else {
-        hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg), dim3(256), NSTAGE * STAGE_BYTES, st, p);
+        hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg, (unsigned)splits), dim3(256), NSTAGE * STAGE_BYTES, st, p);
+        if (splits > 1) {
+            int g = (int)afk_cdiv((int64_t)M * (N / 4), 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
+        }
     }
     if (prof) hipEventRecord(e1, st);
     AFK_LAUNCH_CHECK("afk_gemm_nt_bf16");
@@ -275,6 +311,12 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
                                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                                 int res_mod, void* preact_out, float alpha, int flags, void* stream) {
     return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream);
+}
+
+extern "C" int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                                       const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
+                                       int flags, int splits, void* workspace, void* stream) {
+    return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream, splits, workspace);
 }
 
 extern "C" int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,

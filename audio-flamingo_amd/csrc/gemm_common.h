@@ -17,6 +17,8 @@ struct GemmArgs {
     int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
     float alpha;
     int gm;  // M-tiles per rasterization group (L2 locality)
+    int splits;  // split-K (128x128 kernel only): blockIdx.y = split, raw fp32 partial sums go to ws[split][M][N]
+    float* ws;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;

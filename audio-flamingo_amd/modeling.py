@@ -22,7 +22,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import AfkError
 from .arena import Arena
 from . import functional as F_
@@ -346,16 +346,137 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             logits = lg.reshape(B, -1, self.V)
         return AF3Output(loss=loss, logits=logits, audio_hidden_states=audio_hidden)
 
-    # ------------------------------------------------------------------ generate (greedy, prefix recompute)
+    # ------------------------------------------------------------------ generate (greedy; KV cache - SURVEY.md 8(f)-4)
+    def _merged_embeddings(self, ids, input_features, input_features_mask):
+        """embed_tokens(ids) with the <sound> rows replaced by the projected audio rows (forward() stages a9-a10) -> [B*S, H]"""
+        a, lm = self.arena, self._lm
+        ids_flat = ids.reshape(-1).contiguous()
+        audio, src = None, None
+        if input_features is not None:
+            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask)
+            src, _ = ops.placeholder_scan(ids_flat, self.audio_token_id)
+            if n_tok is not None:
+                T3 = audio.shape[0] // input_features.shape[0]
+                csum = torch.cumsum(n_tok, 0)
+                r = src.clamp_min(0).to(torch.int64)
+                win = torch.searchsorted(csum, r, right=True).clamp_max(n_tok.numel() - 1)
+                row = win * T3 + (r - (csum - n_tok)[win])
+                src = torch.where(src >= 0, row.to(torch.int32), src).contiguous()
+        return ops.embed_scatter_fwd(ids_flat, src, a[lm + "embed_tokens.weight"].data, audio)
+
+    def _decode_layers(self, x, B, n, start, cache, pos_rows, krange, fast_prefill, start_dev=None):
+        """all decoder layers on n new positions per sample (rows [B*n, H]) at cache offset `start` (or *start_dev: graph replay).
+        cache = (K [L, B, Smax, Hkv*D] post-RoPE keys, Vt [L, B, Hkv, D, Smaxpad] values stored transposed: the layout the interval
+        attention kernels read directly).  Attention: prefill without padding on the LDS-staged causal kernel; everything else
+        (decode steps, padded batches) on the interval kernel: query row i of sample b sees keys [krange[b,i,0], krange[b,i,1]);
+        with start_dev the kernel is given the whole cache length and the interval alone bounds what is visible."""
+        a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
+        Kc, Vt = cache
+        Smax, Spad = Kc.shape[2], Vt.shape[4]
+        nq, nk = Hq * D, Hkv * D
+        cos, sin = self._rope_tables(int(self.config.text_config.max_position_embeddings))
+        Sk = Smax if start_dev is not None else start + n
+        for i in range(self.dec_layers):
+            A = lambda k: a[f"{lm}layers.{i}.{k}"]
+            h, _ = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, self.rms_eps)
+            qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
+            ops.rope_(qkv, cos, sin, S=n, nheads=Hq + Hkv, D=D, pos=pos_rows)
+            ld = qkv.stride(0)
+            _lib.call("afk_kv_cache_append", qkv.data_ptr(), ld, nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                      ops._p(start_dev), int(start or 0), B, n, Hkv, D, ops._stream())
+            if fast_prefill:
+                o, _ = ops.attn_fwd(qkv, B, n, Hq, Hkv, D, scale=D ** -0.5, causal=True)
+            else:
+                o = torch.empty((B * n, nq), device=x.device, dtype=torch.bfloat16)
+                lse = torch.empty((B, Hq, n), device=x.device, dtype=torch.float32)
+                _lib.call("afk_xattn_fwd", qkv.data_ptr(), n * ld, D, ld, Kc[i].data_ptr(), Smax * nk, D, nk, Vt[i].data_ptr(),
+                          o.data_ptr(), n * nq, D, nq, lse.data_ptr(), 0, krange.data_ptr(), B, Hq, Hkv, n, Sk, ops.pad64(n), Spad, D,
+                          float(D ** -0.5), ops._stream())
+            x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
+            h2, _ = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, self.rms_eps)
+            gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
+            x = ops.gemm_nt(ops.silu_mul_fwd(gu), A("mlp.down_proj.weight").data, residual=x2)
+        y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
+        return y
+
+    def _decode_step(self, st):
+        """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
+        B = st["nxt"].shape[0]
+        x = st["emb"].index_select(0, st["nxt"])
+        pos1 = (st["cur"] - st["lo"]).contiguous()
+        kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
+        y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])
+        st["nxt"].copy_(ops.gemm_nt(y, st["head"]).float().argmax(-1))
+        st["cur"].add_(1)
+
     @torch.no_grad()
     def generate(self, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20,
-                 do_sample=False, eos_token_id=None, **kwargs):
+                 do_sample=False, eos_token_id=None, pad_token_id=None, use_cache=True, use_graph=None, **kwargs):
+        """Greedy decoding (GenerationMixin.generate with do_sample=False, transformers/generation/utils.py; cache handling as
+        Qwen2Attention.forward modeling_qwen2.py:213-214).  Prefill runs the prompt once and fills a per-layer KV cache; every new
+        token then costs one pass over the weights and one Q=1 attention over the cache.  Batches may be LEFT padded
+        (attention_mask, as the processor pads): positions count real tokens only and padded keys are never visible.
+        The decode step is launch-bound in eager mode (~370 small launches per token), so it is captured once into a HIP graph and
+        replayed (use_graph=None: whenever more than 3 tokens are requested)."""
         if do_sample:
             raise AfkError("only greedy decoding (do_sample=False) is implemented")
+        self._require_hip()
         ids = input_ids.to(self.device_)
+        if not use_cache:
+            return self._generate_recompute(ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id)
+        B, S0 = ids.shape
+        dev = self.device_
+        lo = torch.zeros(B, device=dev, dtype=torch.int32)
+        padded = False
+        if attention_mask is not None:
+            am = attention_mask.to(dev)
+            if not bool(am.all()):
+                padded = True
+                lens = am.sum(-1)
+                if not bool((am.flip(-1).cumsum(-1) == torch.minimum(torch.arange(1, S0 + 1, device=dev)[None], lens[:, None])).all()):
+                    raise AfkError("generate(): only LEFT-padded attention_mask is supported (pad the prompt on the left)")
+                lo = (S0 - lens).to(torch.int32)
+        Smax = S0 + max_new_tokens
+        L, nk = self.dec_layers, self.Hkv * self.D
+        Kc = torch.zeros((L, B, Smax, nk), device=dev, dtype=torch.bfloat16)
+        Vt = torch.zeros((L, B, self.Hkv, self.D, ops.pad64(Smax)), device=dev, dtype=torch.bfloat16)
+        ar = torch.arange(S0, device=dev, dtype=torch.int32)
+        pos_rows = (ar[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()          # position_ids = cumsum(mask) - 1
+        krange = torch.stack([lo[:, None].expand(B, S0), torch.maximum(ar[None, :] + 1, lo[:, None])], -1).contiguous()  # [lo, i+1)
+        x = self._merged_embeddings(ids, input_features, input_features_mask)
+        fast = (not padded) and self.D in (64, 128) and ops.ATTN_IMPL == "lds"
+        y = self._decode_layers(x, B, S0, 0, (Kc, Vt), pos_rows, krange, fast)
+        last = y.reshape(B, S0, -1)[:, -1, :].contiguous()
+        st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
+              "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "nxt": ops.gemm_nt(last, self.arena["lm_head.weight"].data).float().argmax(-1)}
+        toks = [st["nxt"].clone()]
+        if use_graph is None:
+            use_graph = max_new_tokens > 3
+        graph = None
+        for t in range(1, max_new_tokens):
+            if eos_token_id is not None and t % 8 == 0 and bool((torch.stack(toks, 1) == eos_token_id).any(1).all()):
+                break
+            if use_graph and t == 2:  # step 1 ran eagerly (lazy one-time initialisation inside the library happens outside the capture)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    self._decode_step(st)
+            elif graph is not None:
+                graph.replay()
+            else:
+                self._decode_step(st)
+            toks.append(st["nxt"].clone())
+        new = torch.stack(toks, 1)
+        if eos_token_id is not None:  # everything after a row's first EOS becomes padding (GenerationMixin semantics)
+            after = (new == eos_token_id).cumsum(1) - (new == eos_token_id).long() > 0
+            new = torch.where(after, torch.full_like(new, pad_token_id if pad_token_id is not None else eos_token_id), new)
+        return torch.cat([ids, new], dim=1)
+
+    @torch.no_grad()
+    def _generate_recompute(self, ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id):
+        """reference path without a cache (every step re-runs the whole prefix through forward()): used by the tests to pin the cache path"""
         if ids.shape[0] != 1 and attention_mask is not None and not bool(attention_mask.all()):
-            raise AfkError("batched generate with padding is not supported")
-        audio_cache = None
+            raise AfkError("the recompute path does not support padded batches")
         for _ in range(max_new_tokens):
             out = self.forward(input_ids=ids, input_features=input_features, input_features_mask=input_features_mask,
                                logits_to_keep=1)

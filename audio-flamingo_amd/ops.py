@@ -6,6 +6,8 @@ No function has a CPU / eager fallback: inputs must live on a HIP device (AfkErr
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -65,10 +67,32 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
         flags |= GEMM_ACCUM
     if preact_out is not None:
         assert preact_out.stride(0) == out.stride(0) and preact_out.dtype == BF16
+    splits = splitk_plan(M, N, K)
+    if splits > 1:
+        ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
+        _lib.call("afk_gemm_nt_bf16_splitk", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                  M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
+                  _p(preact_out), float(alpha), flags, splits, ws.data_ptr(), _stream())
+        return out
     _lib.call("afk_gemm_nt_bf16", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
               M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
               _p(preact_out), float(alpha), flags, _stream())
     return out
+
+
+SPLITK = os.environ.get("AFK_SPLITK", "1") != "0"
+
+
+def splitk_plan(M, N, K):
+    """number of K splits for an NT GEMM: > 1 only when the output has too few 128x128 tiles to fill the chip (2 x 256 workgroup
+    slots) and the reduction is long enough to share - decode-time Linears (M = batch) and weight gradients of narrow layers"""
+    if not SPLITK or K < 1024:
+        return 1
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if t256 >= 192 or t128 > 300:
+        return 1
+    return max(1, min(16, K // 256, (512 + t128 - 1) // t128))
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None,

@@ -135,6 +135,43 @@ def cpu_baseline(seconds_budget=30.0):
     }
 
 
+def settle_hbm(dev, quiet_s=8.0, timeout_s=60.0):
+    """The amdgpu driver releases and scrubs a dead process's VRAM asynchronously (measured here: `mem_info_vram_used` falls from 215 GB
+    to 0.3 GB over ~7 s after a 185 GB replica exits).  A replica that starts allocating inside or right behind that window gets
+    fragmented small-page mappings and runs 30-60 % slower for its whole life (measured: 5 back-to-back bench processes -> runs 4, 5 at
+    680-740 ms/step instead of 450; with 15 s between the processes all five at 457-460).  So before building the model, wait (untimed)
+    until this GPU's VRAM has been empty and unchanged for `quiet_s` seconds."""
+    import glob
+
+    path = None
+    try:
+        bus = torch.cuda.get_device_properties(dev).pci_bus_id  # HIP: int; sysfs: 0000:BB:00.0
+        for c in glob.glob("/sys/class/drm/card*/device"):
+            real = os.path.realpath(c)
+            if isinstance(bus, int) and real.split(":")[-2:-1] == [f"{bus:02x}"] and os.path.exists(c + "/mem_info_vram_used"):
+                path = c + "/mem_info_vram_used"
+    except Exception:
+        path = None
+    t0 = time.time()
+    quiet_since, last = None, None
+    while time.time() - t0 < timeout_s:
+        if path is not None:
+            used = int(open(path).read())
+        else:
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            used = total_b - free_b
+        now = time.time()
+        if used < (2 << 30) and (last is None or abs(used - last) < (64 << 20)):
+            quiet_since = quiet_since or now
+            if now - quiet_since >= quiet_s:
+                break
+        else:
+            quiet_since = None
+        last = used
+        time.sleep(0.5)
+    return round(time.time() - t0, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +208,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    waited = settle_hbm(dev)
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -236,6 +274,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside): << dt means the GPU is never starved
     fence()
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
@@ -293,7 +332,8 @@ def main():
                        "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": s_tok, "audio_tokens": n_audio_tok,
                        "windows_per_sample": windows, "activation_checkpointing": ckpt,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
-            "loss": final_loss, "peak_mem_gib": round(peak_mem, 1),
+            "loss": final_loss, "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
+            "waited_for_free_hbm_s": waited,
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
             "hardware_tflops_per_gpu": hw_tf,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",

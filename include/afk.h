@@ -57,6 +57,14 @@ int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, voi
 int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                   int64_t ldc, int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                   int res_mod, void* preact_out, float alpha, int flags, void* stream);
+/* Split-K form of afk_gemm_nt_bf16 for outputs with few tiles and a long reduction (decode-time Linear layers with a handful of rows,
+ * weight gradients of narrow layers): `splits` workgroups per 128x128 output tile each reduce a K range into fp32 partials
+ * workspace[splits][M][N] (splits*M*N*4 bytes, caller-owned), a second kernel sums them in fixed order (bit-deterministic) and applies
+ * the same fused epilogue (bias / GELU / residual / accumulate).  Same oracle lines as afk_gemm_nt_bf16. */
+int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                            const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
+                            int flags, int splits, void* workspace, void* stream);
+
 
 /* ---- normalisation ------------------------------------------------------------------------------------
  * LayerNorm: nn.LayerNorm(eps=1e-5) at modeling_audioflamingo3.py:207,212 (per layer) and :335,403 (final).
@@ -174,6 +182,13 @@ int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
                   int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream);
 /* gqa_scratch: NULL, or 2*B*S*Hq*D bf16 - enables the one-block-per-query-head dK/dV sweep + group reduce (GQA) */
+
+/* KV cache of the decode path (Qwen2Attention.forward modeling_qwen2.py:213-214 `past_key_values.update`): rows b*n+i of the fused
+ * projection output (K at column k_col0, V right behind it) are appended at cache position start+i; K row-major
+ * kcache[b][pos][Hkv*D] (batch stride kc_bs), V transposed vtcache[b][h][d][pos] with pitch spad (batch stride vt_bs) - the Vt operand
+ * of afk_xattn_fwd.  start = *start_dev if start_dev != NULL (graph-replayable), else start_host. */
+int afk_kv_cache_append(const void* qkv, int64_t ld, int k_col0, void* kcache, int64_t kc_bs, void* vtcache, int64_t vt_bs,
+                        int spad, const int* start_dev, int start_host, int B, int n, int Hkv, int D, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

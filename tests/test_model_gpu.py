@@ -187,6 +187,32 @@ def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
             assert torch.equal(ma.arena.shadow(k), mb.arena.shadow(k)), f"stale W^T shadow for {k}"
 
 
+def test_generate_kv_cache_matches_prefix_recompute(dev):
+    """the KV-cache decode path (prefill + Q=1 steps over the cache) against re-running the whole prefix through forward() each step"""
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=12)
+    a = m.generate(g["ids"][:1].to(dev), use_cache=True, **kw)
+    b = m.generate(g["ids"][:1].to(dev), use_cache=False, **kw)
+    assert a.shape == b.shape and torch.equal(a, b), (a[:, -12:], b[:, -12:])
+
+
+def test_generate_left_padded_batch_matches_single(dev):
+    """two prompts of different length, LEFT padded into one batch (processor convention): each row must decode exactly as it does alone"""
+    torch.manual_seed(3)
+    m = _model(dev)
+    p0 = torch.randint(0, 1000, (1, 40))
+    p1 = torch.randint(0, 1000, (1, 23))
+    alone = [m.generate(p.to(dev), max_new_tokens=8).cpu() for p in (p0, p1)]
+    pad = 40 - 23
+    ids = torch.cat([p0, torch.cat([torch.zeros(1, pad, dtype=torch.long), p1], 1)], 0)
+    att = torch.ones(2, 40, dtype=torch.long)
+    att[1, :pad] = 0
+    both = m.generate(ids.to(dev), attention_mask=att.to(dev), max_new_tokens=8).cpu()
+    assert both[0, 40:].tolist() == alone[0][0, 40:].tolist()
+    assert both[1, 40:].tolist() == alone[1][0, 23:].tolist()
+
+
 def test_gradient_checkpointing_matches(dev):
     """per-layer recompute (oracle row a19) must not change loss or gradients"""
     g = torch.load(os.path.join(G, "tiny64_caseB.pt"))

@@ -341,6 +341,32 @@ def test_embed_scatter(dev):
     _cmp("d_embed", d_embed, ref_de, atol=0.25, rtol=3e-2)  # bf16 running sums over ~40 duplicates
 
 
+def test_gemm_splitk(dev):
+    """few output tiles + long reduction -> split-K path (fp32 partials + fixed-order reduce with the fused epilogue): values against
+    fp32 torch, bit-determinism, and agreement with the one-pass kernel"""
+    ops = _ops()
+    for (M, N, K) in [(1, 3584, 18944), (8, 4608, 3584), (1280, 1280, 12032), (130, 260, 2048)]:
+        assert ops.splitk_plan(M, N, K) > 1, (M, N, K)
+        a = _rand((M, K), dev, 1.0, 1).to(BF)
+        b = _rand((N, K), dev, 1.0, 2).to(BF)
+        bias = _rand((N,), dev, 1.0, 3).to(BF)
+        res = _rand((M, N), dev, 1.0, 4).to(BF)
+        c = ops.gemm_nt(a, b, bias=bias, residual=res)
+        ref = (a.float() @ b.float().T + bias.float()).to(BF).float() + res.float()
+        _cmp(f"splitk {M}x{N}x{K}", c, ref, atol=K ** 0.5 * 2e-2, rtol=2e-2)
+        for _ in range(2):
+            assert torch.equal(ops.gemm_nt(a, b, bias=bias, residual=res), c), "split-K GEMM not deterministic"
+        ops.SPLITK = False
+        try:
+            c1 = ops.gemm_nt(a, b, bias=bias, residual=res)
+        finally:
+            ops.SPLITK = True
+        _cmp("splitk vs one-pass", c, c1.float(), atol=K ** 0.5 * 1e-2, rtol=2e-2)
+        acc = c.clone()
+        ops.gemm_nt(a, b, out=acc, accumulate=True)
+        _cmp("splitk accumulate", acc, c.float() + (a.float() @ b.float().T), atol=K ** 0.5 * 3e-2, rtol=3e-2)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, B, S, Hq, Hkv, D, scale, causal, kv_len):
     q = qkv[:, : Hq * D].float().reshape(B, S, Hq, D).transpose(1, 2)
