@@ -867,6 +867,45 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
 }
 
 namespace {
+// Music Flamingo rotary time embedding (apply_rotary_time_emb, modeling_musicflamingo.py:187-204): interleaved-pair rotation of the
+// first R features of every encoder output row by per-(row, feature) angles; the other E-R features pass through.  The reference
+// does the arithmetic in fp64 on fp32 cos/sin tables and rounds to the activation dtype; fp32 here (the bf16 rounding of the result
+// is 2^-9, fp32 products are exact to 2^-24).  backward = the transposed rotation applied to the gradient.
+__global__ __launch_bounds__(256) void rotary_time_kernel(const bf16* __restrict__ x, const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          bf16* __restrict__ y, int64_t rows, int E, int R, int backward) {
+    const int half = E >> 1;
+    const int64_t total = rows * half;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / half;
+        const int c = (int)(t % half) * 2;
+        const bf16x2 v = *(const bf16x2*)(x + r * E + c);
+        bf16x2 o = v;
+        if (c < R) {
+            const float x0 = (float)v[0], x1 = (float)v[1];
+            const float c0 = cs[r * R + c], c1 = cs[r * R + c + 1], s0 = sn[r * R + c], s1 = sn[r * R + c + 1];
+            if (!backward) {
+                o[0] = (bf16)(x0 * c0 - x1 * s0);
+                o[1] = (bf16)(x1 * c1 + x0 * s1);
+            } else {
+                o[0] = (bf16)(x0 * c0 + x1 * s1);
+                o[1] = (bf16)(x1 * c1 - x0 * s0);
+            }
+        }
+        *(bf16x2*)(y + r * E + c) = o;
+    }
+}
+}  // namespace
+
+extern "C" int afk_rotary_time(const void* x, const float* cos_t, const float* sin_t, void* y, int64_t rows, int E, int R, int backward,
+                               void* stream) {
+    AFK_REQUIRE(x && cos_t && sin_t && y && rows > 0 && E > 0 && E % 2 == 0 && R >= 0 && R <= E && R % 2 == 0, "afk_rotary_time: bad args");
+    hipLaunchKernelGGL(rotary_time_kernel, dim3(ew_grid(rows * (E / 2), 256)), dim3(256), 0, ST, (const bf16*)x, cos_t, sin_t, (bf16*)y, rows,
+                       E, R, backward);
+    AFK_LAUNCH_CHECK("afk_rotary_time");
+    return AFK_OK;
+}
+
+namespace {
 // KV-cache append (decode path): rows r = b*n + i of the fused projection output hold the new token's K (already rotated) and V;
 // K goes to Kc[b][start+i][:] (row-major), V to Vt[b][h][d][start+i] (stored transposed: the layout the interval attention kernels
 // read).  `start` comes from device memory when start_dev != null, so a captured HIP graph of one decode step can be replayed

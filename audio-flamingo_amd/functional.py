@@ -230,6 +230,20 @@ class PoolNormFn(torch.autograd.Function):
         return ops.avgpool2_bwd(dp, out_rows, E), None, None, None, None, None
 
 
+class RotaryTimeFn(torch.autograd.Function):
+    """Music Flamingo: rotary time embedding on the encoder output rows (apply_rotary_time_emb, modeling_musicflamingo.py:187-204)"""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        return ops.rotary_time(x, cos, sin)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos, sin = ctx.saved_tensors
+        return ops.rotary_time(dy.contiguous(), cos, sin, backward=True), None, None
+
+
 # ---------------------------------------------------------------------------------------------- projector (a8)
 class ProjectorFn(torch.autograd.Function):
     """Linear -> GELU -> Linear (AudioFlamingo3MultiModalProjector.forward, :435-439)"""

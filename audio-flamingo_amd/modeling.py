@@ -249,7 +249,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return self._prm[key]
 
     # ------------------------------------------------------------------ audio tower + projector (a2-a9)
-    def get_audio_features(self, input_features, input_features_mask=None):
+    def _post_encoder(self, x, W, T3, n_tok, input_ids):
+        """hook between the audio tower and the projector (identity for AF3; Music Flamingo rotates by time here)"""
+        return x
+
+    def get_audio_features(self, input_features, input_features_mask=None, input_ids=None):
         """-> (audio_rows [W*T3, H] (all rows, padded windows included), tokens_per_window int64[W] or None)"""
         self._require_hip()
         a, at = self.arena, self._at
@@ -276,6 +280,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             x = self._layer(F_.EncoderLayerFn.apply, x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len)
         T3 = T2 // 2
         x = F_.PoolNormFn.apply(x, self._anchor(at + "layer_norm.weight"), a, at + "layer_norm.weight", at + "layer_norm.bias", W * T3)
+        x = self._post_encoder(x, W, T3, n_tok, input_ids)
         x = F_.ProjectorFn.apply(x, self._anchor(self._pj + "linear_1.weight"), a, self._pj)
         return x, n_tok
 
@@ -292,7 +297,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         ids_flat = ids.reshape(-1).contiguous()
         audio, src = None, None
         if input_features is not None:
-            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask)
+            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask, input_ids=ids)
             src, cnt = ops.placeholder_scan(ids_flat, self.audio_token_id)
             T3 = audio.shape[0] // input_features.shape[0]
             if n_tok is not None:
@@ -353,7 +358,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         ids_flat = ids.reshape(-1).contiguous()
         audio, src = None, None
         if input_features is not None:
-            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask)
+            audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask, input_ids=ids)
             src, _ = ops.placeholder_scan(ids_flat, self.audio_token_id)
             if n_tok is not None:
                 T3 = audio.shape[0] // input_features.shape[0]

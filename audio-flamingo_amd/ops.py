@@ -251,6 +251,17 @@ def rope_(buf, cos, sin, *, S, nheads, D, pos=None, backward=False):
     return buf
 
 
+def rotary_time(x, cos, sin, *, backward=False):
+    """Music Flamingo rotary time embedding on encoder rows: x [rows, E] bf16, cos / sin [rows, R] fp32 (R <= E, even)"""
+    _chk(x, BF16, "rotary_time x"), _chk(cos, torch.float32, "rotary_time cos"), _chk(sin, torch.float32, "rotary_time sin")
+    rows, E = x.shape
+    R = cos.shape[-1]
+    assert x.is_contiguous() and cos.is_contiguous() and sin.is_contiguous() and cos.numel() == rows * R == sin.numel()
+    y = torch.empty_like(x)
+    _lib.call("afk_rotary_time", x.data_ptr(), cos.data_ptr(), sin.data_ptr(), y.data_ptr(), rows, E, R, int(backward), _stream())
+    return y
+
+
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     _lib.call("afk_add_bf16", a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())

@@ -183,6 +183,12 @@ int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream);
 /* gqa_scratch: NULL, or 2*B*S*Hq*D bf16 - enables the one-block-per-query-head dK/dV sweep + group reduce (GQA) */
 
+/* Music Flamingo rotary time embedding on the encoder output (apply_rotary_time_emb, transformers/models/musicflamingo/
+ * modeling_musicflamingo.py:187-204; angles :97-118): y[r, 2i..2i+1] = rotation of x[r, 2i..2i+1] by the angle whose cos / sin are
+ * cos_t / sin_t [rows, R] (fp32) for 2i < R, y = x elsewhere.  backward != 0 applies the transposed rotation (gradient). */
+int afk_rotary_time(const void* x, const float* cos_t, const float* sin_t, void* y, int64_t rows, int E, int R, int backward,
+                    void* stream);
+
 /* KV cache of the decode path (Qwen2Attention.forward modeling_qwen2.py:213-214 `past_key_values.update`): rows b*n+i of the fused
  * projection output (K at column k_col0, V right behind it) are appended at cache position start+i; K row-major
  * kcache[b][pos][Hkv*D] (batch stride kc_bs), V transposed vtcache[b][h][d][pos] with pitch spad (batch stride vt_bs) - the Vt operand

@@ -290,3 +290,31 @@ def test_on_device_audio_preprocessing_matches_reference_processor(dev):
     o = m(input_ids=ids.to(dev), input_features=out["input_features"].to(torch.bfloat16), input_features_mask=out["input_features_mask"],
           attention_mask=att.to(dev))
     assert o.logits.shape == (2, 1752, 1024) and torch.isfinite(o.logits.float()[1]).all() and n == 1875
+
+
+def test_music_flamingo_vs_reference_golden(dev):
+    """Music Flamingo: AF3 path + rotary time embedding kernel, forward and backward, against the live reference's golden
+    vectors; same tolerances as the AF3 cases"""
+    from transformers import MusicFlamingoConfig
+
+    from audio_flamingo_amd.musicflamingo import MusicFlamingoForConditionalGeneration as Mine
+    from tests.test_host_cpu import TINY
+
+    T = {k: (dict(v, model_type="audioflamingo3_encoder") if k == "audio_config" else v) for k, v in TINY.items()}
+    m = Mine(MusicFlamingoConfig(**T), device=dev)
+    m.load_state_dict(torch.load(os.path.join(G, "tiny64_music_state_bf16.pt")))
+    g = torch.load(os.path.join(G, "tiny64_music_case.pt"))
+    m.zero_grad()
+    out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+            attention_mask=g["att"].to(dev), labels=g["labels"].to(dev), return_logits=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(out.loss.detach()) - float(g["loss"])) <= 1e-2
+    sel = g["labels"] != -100
+    assert float((out.logits.float().cpu()[sel] - g["logits_bf16"].float()).abs().max()) <= LOGIT_TOL
+    n_tok = [750, 250, 125]
+    rows = torch.cat([out.audio_hidden_states.float().cpu()[w * 750: w * 750 + n] for w, n in enumerate(n_tok)])
+    assert _rel(rows, g["audio_bf16"]) <= 2e-2
+    params = dict(m.named_parameters())
+    bad = {k: _rel(params[k].grad, v) for k, v in g["grads"].items() if _rel(params[k].grad, v) > 6e-2}
+    assert not bad, bad

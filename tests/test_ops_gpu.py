@@ -470,6 +470,30 @@ def test_attention_lazy_rescale_ramp(dev):
     _cmp("ramp fwd causal", oc, _attn_ref(qkv, B, S, H, H, D, D ** -0.5, True, None), 2e-2, 2e-2)
 
 
+def test_rotary_time(dev):
+    """Music Flamingo rotary time embedding kernel: forward vs the fp64 formula, backward = transposed rotation (checked through autograd)"""
+    ops = _ops()
+    rows, E, R = 300, 128, 52
+    x = _rand((rows, E), dev, 1.0, 1).to(BF)
+    ang = _rand((rows, R), dev, 3.0, 2)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+
+    def ref(xx):
+        xx = xx.double()
+        rot, rest = xx[:, :R], xx[:, R:]
+        pr = rot.reshape(rows, -1, 2)
+        half = torch.stack((-pr[..., 1], pr[..., 0]), -1).flatten(-2)
+        return torch.cat((rot * cos.double() + half * sin.double(), rest), -1)
+
+    y = ops.rotary_time(x, cos, sin)
+    _cmp("rotary_time fwd", y, ref(x).float(), atol=1e-2, rtol=1e-2)
+    assert torch.equal(y[:, R:], x[:, R:])
+    xr = x.float().requires_grad_(True)
+    dy = _rand((rows, E), dev, 1.0, 3).to(BF)
+    ref(xr).backward(dy.double())
+    _cmp("rotary_time bwd", ops.rotary_time(dy, cos, sin, backward=True), xr.grad, atol=1e-2, rtol=1e-2)
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()

@@ -98,3 +98,30 @@ def test_flamingo_oracle_matches_structural_stand_in():
         ref = layer(x, image_hidden_states=media, image_attention_mask=add_mask, cross_attention_gate=gate)
         got = FO.gated_cross_attention(dict(layer.state_dict()), x, media, keep, gate, 4, cfg.rms_norm_eps)
     assert (ref - got).abs().max() < 1e-5
+
+
+def test_music_flamingo_oracle_matches_reference_golden():
+    """Music Flamingo delta (rotary time embedding between encoder and projector): the restatement against the golden vectors of the
+    live reference (oracle/make_golden_music.py): two windows of one sample + a short third window"""
+    import os
+
+    import torch
+
+    from oracle import af3_oracle as O
+
+    G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    g = torch.load(os.path.join(G, "tiny64_music_case.pt"))
+    sd = {k: v.float() for k, v in torch.load(os.path.join(G, "tiny64_music_state_bf16.pt")).items()}
+    cfg = dict(enc_heads=4, heads=4, kv_heads=2, eps=1e-6, theta=10000.0, audio_token_id=1023, music=dict(audio_token_id=1023))
+    with torch.no_grad():
+        out = O.forward(sd, cfg, g["ids"], g["feats"].float(), g["fmask"].long(), labels=g["labels"], attention_mask=g["att"])
+    assert abs(float(out["loss"]) - float(g["loss"])) < 1e-4
+    keep = g["labels"] != -100
+    assert float((out["logits"][keep] - g["logits_bf16"].float()).abs().max()) < 2e-2      # golden logits are stored in bf16
+    assert float((out["audio"] - g["audio_bf16"].float()).abs().max()) < 2e-2
+    # the rotation must matter: without it the audio rows differ visibly
+    cfg0 = dict(cfg)
+    cfg0.pop("music")
+    with torch.no_grad():
+        plain = O.audio_features(sd, g["feats"].float(), g["fmask"].long(), 4)
+    assert float((plain - g["audio_bf16"].float()).abs().max()) > 0.05
