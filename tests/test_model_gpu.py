@@ -318,3 +318,34 @@ def test_music_flamingo_vs_reference_golden(dev):
     params = dict(m.named_parameters())
     bad = {k: _rel(params[k].grad, v) for k, v in g["grads"].items() if _rel(params[k].grad, v) > 6e-2}
     assert not bad, bad
+
+
+def test_hf_trainer_runs_unchanged_script(dev, tmp_path):
+    """a stock transformers.Trainer loop (AfkTrainer subclass: fused arena optimizer behind torch.optim.Optimizer, LR
+    scheduler, gradient clipping, gradient accumulation) fine-tunes the HIP model; optimizer state round-trips through state_dict"""
+    from transformers import TrainingArguments
+
+    from audio_flamingo_amd.trainer import AfkAdamW, AfkTrainer
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    rows = [dict(input_ids=g["ids"][i % 2], input_features=g["feats"][i % 2], input_features_mask=g["fmask"][i % 2], labels=g["labels"][i % 2])
+            for i in range(16)]
+    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, gradient_accumulation_steps=2, max_steps=4,
+                             learning_rate=2e-3, lr_scheduler_type="linear", warmup_steps=1, logging_steps=1, save_strategy="no",
+                             report_to=[], remove_unused_columns=False, dataloader_pin_memory=False, max_grad_norm=1.0, seed=0)
+    tr = AfkTrainer(model=m, args=args, train_dataset=rows)
+    out = tr.train()
+    opt = getattr(tr.optimizer, "optimizer", tr.optimizer)  # accelerate wraps it in AcceleratedOptimizer
+    assert isinstance(opt, AfkAdamW) and opt.fused.t == 4
+    losses = [h["loss"] for h in tr.state.log_history if "loss" in h]
+    assert len(losses) == 4 and losses[-1] < losses[0] - 0.05, losses
+    # checkpoint / resume of the optimizer: state_dict round trip reproduces the next step bit for bit
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict()["state"].items()}
+    pg = opt.state_dict()["param_groups"]
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    m.zero_grad(); m(**kw).loss.backward(); opt.step()
+    after = m.arena.params.clone()
+    opt.load_state_dict({"state": sd, "param_groups": pg})
+    m.zero_grad(); m(**kw).loss.backward(); opt.step()
+    assert torch.equal(m.arena.params, after)
