@@ -350,10 +350,23 @@ def main():
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the measured line down
                 res["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
-        print(json.dumps(res))
+        line = json.dumps(res)
+    else:
+        line = None
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner through C stdio (fully buffered on a pipe -> it would surface at exit, AFTER the result):
+        # drain both layers first so that the JSON line is the last line of output
+        sys.stdout.flush()
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
