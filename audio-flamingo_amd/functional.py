@@ -6,10 +6,11 @@ gradients never travel through autograd: the wgrad GEMMs write (or accumulate) d
 (arena.py) and the Functions return ``None`` for their parameter inputs.  The single ``anchor`` tensor each
 Function takes is a parameter view that only serves to make the output require grad.
 
-Backward GEMM forms (all on the one NT kernel, csrc/gemm.hip):
-    dgrad  dX[M,K] = dY[M,N] . Wt[K,N]^T          Wt = arena shadow (W^T, refreshed after every optimizer step)
-    wgrad  dW[N,K] = dYt[N,M] . Xt[K,M]^T          dYt, Xt = afk_transpose_bf16 (M zero-padded to a multiple of 64)
-    bias   db[N]   = rowsum(dYt)
+Backward GEMM forms (default "wgrad_direct", see BWD_FORM below):
+    dgrad  dX[M,K] = dY[M,N] . Wt[K,N]^T          NT kernel; Wt = arena shadow (W^T, refreshed after every optimizer step)
+    wgrad  dW[N,K] = dY[M,N]^T . X[M,K]           TN kernel (csrc/gemm256t.hip) on the operands as they lie; narrow outputs (< 192 tiles
+                                                  of 256x256) fall back to NT on afk_transpose_bf16 copies (dYt . Xt^T)
+    bias   db[N]   = colsum(dY)  (rowsum(dYt) on the fallback)
 """
 from __future__ import annotations
 
@@ -37,10 +38,12 @@ def _wgrad(arena: Arena, blk: Block, dyt, xt, Mvalid, *, bias_blk=None, bias_sli
         arena.grad_written(bias_blk)
 
 
-# "nt": every backward GEMM on the NT kernel (operand transposes + W^T shadows); "direct": dgrad on the NN kernel and wgrad on the TN
-# kernel (operands as they lie) wherever the output has at least DIRECT_MIN_TILES 256x256 tiles (the transposed-operand kernels have no
-# small-tile variant)
-BWD_FORM = os.environ.get("AFK_BWD_FORM", "nt")
+# Backward GEMM forms (measured on the full AF3-7B step, same box, ms/step):
+#   "nt"            every backward GEMM on the NT kernel: dY^T / X^T operand transposes for wgrad + W^T shadows for dgrad        455-459
+#   "wgrad_direct"  wgrad on the TN kernel straight from dY and X (no activation transposes), dgrad on NT + shadows   (default)  442
+#   "direct"        also dgrad on the NN kernel (no W^T shadows: -15.6 GB of HBM), the NN kernel is ~6 % slower than NT           460
+# The transposed-operand kernels have no small-tile variant: outputs with fewer than DIRECT_MIN_TILES 256x256 tiles stay on "nt".
+BWD_FORM = os.environ.get("AFK_BWD_FORM", "wgrad_direct")
 DIRECT_MIN_TILES = 192
 
 
@@ -57,9 +60,10 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
     side = arena.wgrad_stream
     N, K = dy.shape[1], x.shape[1]
     direct = BWD_FORM == "direct"
+    wdirect = direct or BWD_FORM == "wgrad_direct"  # TN wgrad only: no activation transposes, dgrad stays on the NT kernel + W^T shadows
 
     def wgrad_branch():
-        if direct and _tiles256(N, K) >= DIRECT_MIN_TILES:
+        if wdirect and _tiles256(N, K) >= DIRECT_MIN_TILES:
             ops.gemm(dy, x, out=blk.grad.reshape(blk.shape[0], -1), trans_a=True, trans_b=True, accumulate=not blk.fresh)
             arena.grad_written(blk)
             if bkey:
@@ -406,6 +410,7 @@ class LMHeadLossFn(torch.autograd.Function):
         chunk = min(LMHeadLossFn.CHUNK, M)
         buf = torch.empty((chunk, V), device=dev, dtype=torch.bfloat16)
         direct = BWD_FORM == "direct"
+        wdirect = direct or BWD_FORM == "wgrad_direct"
         wt = arena.shadow(wkey) if need_grad and not direct else None
         if need_grad:
             # unscaled lm_head gradient goes to a private buffer when it must be accumulated into existing grads
@@ -417,16 +422,18 @@ class LMHeadLossFn(torch.autograd.Function):
             logits = buf[:n]
             ops.gemm_nt(x[s:e], blk.data, out=logits)
             ops.ce_fwd_bwd_(logits, shift_labels[s:e], row_loss[s:e], denom, upstream=1.0, write_grad=need_grad)
-            if need_grad and direct:
-                ops.gemm(logits, blk.data, out=dx[s:e], trans_b=True)                               # dX = dlogits . W
-                ops.gemm(logits, x[s:e], out=gw_tmp, trans_a=True, trans_b=True, accumulate=not first)  # dW += dlogits^T . X
-                first = False
-            elif need_grad:
-                ops.gemm_nt(logits, wt, out=dx[s:e], K=V)
-                dlt = ops.transpose(logits)      # [V, pad64(n)]
-                xt = ops.transpose(x[s:e])       # [H, pad64(n)]
-                ops.gemm_nt(dlt, xt, out=gw_tmp, accumulate=not first)
-                del dlt, xt
+            if need_grad:
+                if direct:
+                    ops.gemm(logits, blk.data, out=dx[s:e], trans_b=True)                               # dX = dlogits . W
+                else:
+                    ops.gemm_nt(logits, wt, out=dx[s:e], K=V)
+                if wdirect:
+                    ops.gemm(logits, x[s:e], out=gw_tmp, trans_a=True, trans_b=True, accumulate=not first)  # dW += dlogits^T . X
+                else:
+                    dlt = ops.transpose(logits)      # [V, pad64(n)]
+                    xt = ops.transpose(x[s:e])       # [H, pad64(n)]
+                    ops.gemm_nt(dlt, xt, out=gw_tmp, accumulate=not first)
+                    del dlt, xt
                 first = False
         loss = torch.empty((), device=dev, dtype=torch.float32)
         ops.loss_reduce(row_loss, denom, loss)
