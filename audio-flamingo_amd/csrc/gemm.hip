@@ -231,7 +231,8 @@ extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* 
 static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                      int res_mod, void* preact_out, float alpha, int flags, void* stream, int splits = 1, void* workspace = nullptr) {
-    AFK_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || (workspace && !trans_b)), "afk_gemm_nt_bf16_splitk: 1..64 splits, workspace required, NT form only");
+    AFK_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || workspace), "afk_gemm_*_splitk: 1..64 splits, workspace required");
+    AFK_REQUIRE(splits == 1 || splits <= (K + BK - 1) / BK, "afk_gemm_*_splitk: more splits than K tiles");
     AFK_REQUIRE(A && B && C, "afk_gemm_nt_bf16: null operand");
     AFK_REQUIRE(M > 0 && N > 0 && K > 0, "afk_gemm_nt_bf16: bad shape %d %d %d", M, N, K);
     AFK_REQUIRE(!trans_a || trans_b, "afk_gemm_bf16: A^T with k-contiguous B is not implemented (NT, NN, TN are)");
@@ -265,7 +266,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.ws = (float*)workspace;
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = splits == 1 && (trans_b || g_variant == 2 || (g_variant == 0 && tiles256 >= 192));
+    const bool use256 = trans_b || (splits == 1 && (g_variant == 2 || (g_variant == 0 && tiles256 >= 192)));
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -292,6 +293,11 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     if (prof) hipEventRecord(e0, st);
     if (trans_b) {
         if (int e = afk_launch_gemm256t(p, trans_a, st)) return e;
+        if (splits > 1) {
+            int g = (int)afk_cdiv((int64_t)M * (N / 4), 256);
+            if (g > 2048) g = 2048;
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
+        }
     } else if (use256) {
         if (int e = afk_launch_gemm256(p, st)) return e;
     } else {
@@ -317,6 +323,13 @@ extern "C" int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B
                                        const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
                                        int flags, int splits, void* workspace, void* stream) {
     return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream, splits, workspace);
+}
+
+extern "C" int afk_gemm_bf16_splitk(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                    int M, int N, int K, const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out,
+                                    float alpha, int flags, int splits, void* workspace, void* stream) {
+    return gemm_impl(trans_a, trans_b, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream, splits,
+                     workspace);
 }
 
 extern "C" int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,

@@ -93,7 +93,20 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
     int tm, tn;
     gemm_tile_of_block(p, tm, tn);
     const int m0 = tm * 256, n0 = tn * 256;
-    const int T = (p.K + BK - 1) / BK;
+    // split-K (blockIdx.y = split): this block reduces K-tiles [t0, t1) of its output tile; operands are re-based so that the body
+    // below runs unchanged on the local reduction length KL
+    int KL = p.K;
+    const bf16* Abase = p.A;
+    const bf16* Bbase = p.B;
+    if (p.splits > 1) {
+        const int tall = (p.K + BK - 1) / BK;
+        const int t0 = (int)((int64_t)tall * blockIdx.y / p.splits), t1 = (int)((int64_t)tall * (blockIdx.y + 1) / p.splits);
+        const int kbeg = t0 * BK;
+        KL = min(p.K, t1 * BK) - kbeg;
+        Abase += AT ? (int64_t)kbeg * p.lda : (int64_t)kbeg;
+        Bbase += (int64_t)kbeg * p.ldb;
+    }
+    const int T = (KL + BK - 1) / BK;
     constexpr int NX = AT ? 4 : 6, NY = AT ? 4 : 2;
 
     // ------------------------------------------------------------------ LDS-DMA piece table
@@ -114,12 +127,12 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
             // X: k-rows 0..31 (units 0..15) of A (jj<2) then B (jj>=2); Y: k-rows 32..63 (units 16..31) likewise
             const bool isA = jj < 2;
             const int unit = (isx ? 0 : 16) + wave + 8 * (jj & 1);
-            tr_src[j] = isA ? tsrc(p.A, unit, m0, p.M, lane) : tsrc(p.B, unit, n0, p.N, lane);
+            tr_src[j] = isA ? tsrc(Abase, unit, m0, p.M, lane) : tsrc(Bbase, unit, n0, p.N, lane);
             tr_ld[j] = isA ? p.lda : p.ldb;
             dst[j] = (isA ? 0 : OP_BYTES) + unit * 1024;
         } else if (isx && jj < 4) {
             const int unit = wave + 8 * jj;  // Bt image, 32 pieces
-            tr_src[j] = tsrc(p.B, unit, n0, p.N, lane);
+            tr_src[j] = tsrc(Bbase, unit, n0, p.N, lane);
             tr_ld[j] = p.ldb;
             dst[j] = OP_BYTES + unit * 1024;
         } else {
@@ -129,14 +142,14 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
             const int rl = unit * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((rl >> 1) & 7);
             const int r = min(m0 + rl, p.M - 1);
-            an_src[j] = p.A + (int64_t)r * p.lda + chunk * 8;
+            an_src[j] = Abase + (int64_t)r * p.lda + chunk * 8;
             dst[j] = unit * 1024;
         }
     }
     auto src_of = [&](int j, int t) -> const bf16* {
         const bool tr = AT || j < 4;  // compile-time after unrolling
         if (tr) {
-            const int row = min(t * BK + tr_src[j].krow, p.K - 1);
+            const int row = min(t * BK + tr_src[j].krow, KL - 1);
             return tr_src[j].base + (int64_t)row * tr_ld[j];
         }
         return an_src[j] + (int64_t)t * BK;
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
             AFK_VMCNT(8);
             AFK_BARRIER();
         } else {
-            const int kvalid = p.K - t * BK;  // < 64 only on a ragged last tile
+            const int kvalid = KL - t * BK;  // < 64 only on a ragged last tile
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
                 // ================= TN  MEM: fragments of k-steps {2ph, 2ph+1} of both images
@@ -307,7 +320,12 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                gemm_epilogue_store4(p, m, n, v);
+                if (p.splits > 1) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.ws + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = o;
+                } else {
+                    gemm_epilogue_store4(p, m, n, v);
+                }
             }
         }
     }
@@ -324,9 +342,10 @@ int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
         attr_set = true;
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
+    const unsigned ns = (unsigned)(p.splits > 1 ? p.splits : 1);
     if (trans_a)
-        hipLaunchKernelGGL(gemm_xt_bf16_k256<true>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+        hipLaunchKernelGGL(gemm_xt_bf16_k256<true>, dim3((unsigned)nwg, ns), dim3(512), LDS_BYTES, st, p);
     else
-        hipLaunchKernelGGL(gemm_xt_bf16_k256<false>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+        hipLaunchKernelGGL(gemm_xt_bf16_k256<false>, dim3((unsigned)nwg, ns), dim3(512), LDS_BYTES, st, p);
     return AFK_OK;
 }

@@ -63,7 +63,7 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
     wdirect = direct or BWD_FORM == "wgrad_direct"  # TN wgrad only: no activation transposes, dgrad stays on the NT kernel + W^T shadows
 
     def wgrad_branch():
-        if wdirect and _tiles256(N, K) >= DIRECT_MIN_TILES:
+        if wdirect and _tiles256(N, K) * ops.splitk_plan_256(N, K, M) >= DIRECT_MIN_TILES:  # narrow outputs: TN kernel with split-K
             ops.gemm(dy, x, out=blk.grad.reshape(blk.shape[0], -1), trans_a=True, trans_b=True, accumulate=not blk.fresh)
             arena.grad_written(blk)
             if bkey:

@@ -126,10 +126,27 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=No
         flags |= GEMM_OUT_F32
     if accumulate:
         flags |= GEMM_ACCUM
+    splits = splitk_plan_256(M, N, K) if trans_b else 1
+    if splits > 1:
+        ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
+        _lib.call("afk_gemm_bf16_splitk", int(trans_a), int(trans_b), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+                  out.stride(0), M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
+                  _p(preact_out), float(alpha), flags, splits, ws.data_ptr(), _stream())
+        return out
     _lib.call("afk_gemm_bf16", int(trans_a), int(trans_b), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
               out.stride(0), M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
               _p(preact_out), float(alpha), flags, _stream())
     return out
+
+
+def splitk_plan_256(M, N, K):
+    """K splits for the 256x256 transposed-operand kernels (one workgroup per CU): only for outputs with < 128 tiles and K >= 2048"""
+    if not SPLITK or K < 2048:
+        return 1
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    if t256 >= 128:
+        return 1
+    return max(1, min(16, K // 512, (256 + t256 - 1) // t256))
 
 
 def colsum(x, out, *, accumulate=False):

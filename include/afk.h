@@ -64,6 +64,10 @@ int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const vo
 int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                             const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
                             int flags, int splits, void* workspace, void* stream);
+/* the same for the general form (NN / TN on the 256x256 transposed-operand kernels; splits <= ceil(K / 64)) */
+int afk_gemm_bf16_splitk(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                         int M, int N, int K, const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out,
+                         float alpha, int flags, int splits, void* workspace, void* stream);
 
 
 /* ---- normalisation ------------------------------------------------------------------------------------

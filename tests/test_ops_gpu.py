@@ -367,6 +367,22 @@ def test_gemm_splitk(dev):
         _cmp("splitk accumulate", acc, c.float() + (a.float() @ b.float().T), atol=K ** 0.5 * 3e-2, rtol=3e-2)
 
 
+def test_gemm_tn_splitk(dev):
+    """narrow weight gradients (encoder: 1280 x 1280 from 12 000 rows) on the TN kernel with split-K: values, determinism, accumulate"""
+    ops = _ops()
+    for (M, N, K) in [(1280, 1280, 12000), (3840, 1280, 12000), (520, 264, 4100)]:
+        assert ops.splitk_plan_256(M, N, K) > 1
+        at = _rand((K, M), dev, 1.0, 1).to(BF)
+        bt = _rand((K, N), dev, 1.0, 2).to(BF)
+        c = ops.gemm(at, bt, trans_a=True, trans_b=True)
+        ref = at.float().T @ bt.float()
+        _cmp(f"tn splitk {M}x{N}x{K}", c, ref, atol=K ** 0.5 * 2e-2, rtol=2e-2)
+        assert torch.equal(ops.gemm(at, bt, trans_a=True, trans_b=True), c), "TN split-K not deterministic"
+        acc = c.clone()
+        ops.gemm(at, bt, out=acc, trans_a=True, trans_b=True, accumulate=True)
+        _cmp("tn splitk accumulate", acc, 2 * ref, atol=K ** 0.5 * 4e-2, rtol=3e-2)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, B, S, Hq, Hkv, D, scale, causal, kv_len):
     q = qkv[:, : Hq * D].float().reshape(B, S, Hq, D).transpose(1, 2)
