@@ -345,7 +345,7 @@ def main():
                          "note": ("HIP events around every GEMM launch on its launch stream; measured on one extra untimed step with the wgrad stream "
                                   "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the measured line down
