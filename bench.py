@@ -240,10 +240,10 @@ def main():
     if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
         overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
 
-    def step():
+    def step(serial=False):
         feats = frontend(waves, out_dtype=torch.bfloat16)
         model.arena.zero_grad()
-        if overlap is not None:
+        if overlap is not None and not serial:
             # per bucket, inside backward, on a side stream: [all-reduce] -> AdamW -> W^T shadow refresh
             overlap.begin_step()
             out = model(input_ids=ids, input_features=feats, labels=labels)
@@ -279,9 +279,10 @@ def main():
     dt = time.perf_counter() - t0
     ops.prof_enable(False)
     ov_ms, ov_flops, ov_launches = ops.prof_collect()
-    # Per-launch GEMM durations: with the wgrad branch on a second stream two GEMMs share the chip, so the HIP-event
-    # brackets of the timed region over-state each launch.  One extra UNTIMED step with the second stream off gives the
-    # same launches back to back on one stream; that is what `roofline.achieved` is computed from (both are reported).
+    # Per-launch GEMM durations: with the wgrad branch on a second stream and AdamW on a third, kernels share the chip and the
+    # HIP-event brackets of the timed region over-state each launch.  One extra UNTIMED step on the serial schedule (one stream,
+    # optimizer after backward) gives the same launches back to back; that is what `roofline.achieved` is computed from (both are
+    # reported; profiles/r01f_bench_kernel_stats_serial.md is the rocprofv3 view of the same schedule).
     had_side = model.arena.wgrad_stream is not None
     if had_side:
         model.arena.join_streams()
@@ -289,7 +290,7 @@ def main():
         fence()
         ops.prof_reset()
         ops.prof_enable(True)
-        step()
+        step(serial=True)
         fence()
         ops.prof_enable(False)
         gemm_ms, gemm_flops, gemm_launches = ops.prof_collect()
