@@ -149,6 +149,7 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 }
 
 // exact-erf GELU (oracle: transformers/activations.py GELUActivation -> F.gelu default)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));

@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ 
     }
 }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // h = bf16(bf16(silu(g)) * u)   gu = [rows, 2I] (gate | up), h = [rows, I]   (Qwen2MLP.forward, modeling_qwen2.py:46-48)
 __global__ __launch_bounds__(256) void silu_mul_fwd_kernel(const bf16* __restrict__ gu, bf16* __restrict__ h, int64_t rows,

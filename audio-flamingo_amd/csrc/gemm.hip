@@ -243,6 +243,8 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     AFK_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "afk_gemm_nt_bf16: leading dims must keep 16-B (A,B) / 8-B (C) alignment");
     AFK_REQUIRE(!(flags & AFK_GEMM_BIAS) || bias, "afk_gemm_nt_bf16: BIAS flag without bias");
     AFK_REQUIRE(!(flags & AFK_GEMM_RESIDUAL) || (residual && ldr % 4 == 0), "afk_gemm_nt_bf16: RESIDUAL flag without residual");
+    AFK_REQUIRE(!(flags & AFK_GEMM_SWIGLU_BWD) || (residual && ldr % 4 == 0 && ldc >= 2 * (int64_t)N && flags == AFK_GEMM_SWIGLU_BWD && splits == 1),
+                "afk_gemm: SWIGLU_BWD needs the gate|up tensor as `residual`, a [M, 2N] output and no other epilogue flag");
     AFK_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0), "afk_gemm_nt_bf16: misaligned pointer");
     GemmArgs p;
     p.A = (const bf16*)A;

@@ -63,6 +63,26 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
     }
+    if (flags & AFK_GEMM_SWIGLU_BWD) {
+        // v = d(silu(gate)*up) for columns n..n+3 of the SwiGLU output (this GEMM is the down-projection dgrad).  R = the saved
+        // [rows, 2N] gate|up pre-activations; the two gradients go to C[m, n] (gate) and C[m, N + n] (up): the [rows, N] intermediate
+        // never exists in HBM.  Same arithmetic as silu_mul_bwd_kernel on the bf16-rounded GEMM result (bit-identical to the
+        // two-kernel form).
+        const bf16x4 gv = *(const bf16x4*)(p.R + (int64_t)m * p.ldr + n);
+        const bf16x4 uv = *(const bf16x4*)(p.R + (int64_t)m * p.ldr + p.N + n);
+        bf16x4 og, ou;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gf = (float)gv[e], uf = (float)uv[e], df = rbf(v[e]);
+            const float s = sigmoid_f(gf);
+            og[e] = (bf16)(df * uf * (s * (1.f + gf * (1.f - s))));
+            ou[e] = (bf16)(df * (gf * s));
+        }
+        bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
+        *(bf16x4*)cp = og;
+        *(bf16x4*)(cp + p.N) = ou;
+        return;
+    }
     if (flags & AFK_GEMM_RESIDUAL) {
         const int rm = p.res_mod > 0 ? m % p.res_mod : m;
         const bf16x4 rv = *(const bf16x4*)(p.R + (int64_t)rm * p.ldr + n);

@@ -51,7 +51,13 @@ def _tiles256(m, n):
     return ((m + 255) // 256) * ((n + 255) // 256)
 
 
-def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True):
+# SwiGLU backward inside the down-projection dgrad epilogue (AFK_GEMM_SWIGLU_BWD): bit-identical and saves 620 MB of HBM traffic per
+# layer, but MEASURED SLOWER on the full step (446-450 vs 435 ms): the epilogue's per-lane row-strided 8-byte gate|up loads cost more
+# than the separate 5.3 TB/s elementwise pass.  Kept as an ABI feature (tests/test_ops_gpu.py), off in the model.
+FUSE_SWIGLU_BWD = os.environ.get("AFK_FUSE_SWIGLU", "0") == "1"
+
+
+def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
     """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena.
     The weight-gradient branch (two operand transposes + wgrad GEMM + bias row-sum) is independent of the data-gradient
     GEMM; with ``arena.wgrad_stream`` set it is enqueued on that stream so the two GEMMs fill each other's tile tails."""
@@ -95,6 +101,8 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
     if direct and _tiles256(M, K) >= DIRECT_MIN_TILES:
         return ops.gemm(dy, blk.data.reshape(blk.shape[0], -1), trans_b=True)  # dX = dY . W, W as stored
     wt = arena.shadow(wkey)  # [K, pad64(N)]
+    if swiglu_gu is not None:  # down-projection dgrad with the SwiGLU backward in its epilogue: returns d(gate|up) directly
+        return ops.gemm_nt(dy, wt, K=dy.shape[1], swiglu_bwd=swiglu_gu)
     return ops.gemm_nt(dy, wt, K=dy.shape[1])
 
 
@@ -328,10 +336,14 @@ class DecoderLayerFn(torch.autograd.Function):
         arena, pfx, B, S, Hq, Hkv, D = ctx.meta
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
-        da = linear_bwd(arena, dx3, a, pfx + "mlp.down_proj.weight")
-        del a
-        dgu = ops.silu_mul_bwd(gu, da)
-        del da
+        if FUSE_SWIGLU_BWD and BWD_FORM != "direct":
+            dgu = linear_bwd(arena, dx3, a, pfx + "mlp.down_proj.weight", swiglu_gu=gu)
+            del a
+        else:
+            da = linear_bwd(arena, dx3, a, pfx + "mlp.down_proj.weight")
+            del a
+            dgu = ops.silu_mul_bwd(gu, da)
+            del da
         dh2 = linear_bwd(arena, dgu, h2, pfx + "mlp.gate_up.weight")
         del dgu
         nw = A("post_attention_layernorm.weight")

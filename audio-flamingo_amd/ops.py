@@ -15,7 +15,7 @@ from ._lib import AfkError
 
 BF16 = torch.bfloat16
 
-GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ACCUM = 1, 2, 4, 8, 16
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ACCUM, GEMM_SWIGLU_BWD = 1, 2, 4, 8, 16, 32
 
 
 def _stream() -> int:
@@ -40,7 +40,7 @@ def pad64(n: int) -> int:
 
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None, out_f32=False,
-            accumulate=False, alpha=1.0, M=None, N=None, K=None):
+            accumulate=False, alpha=1.0, M=None, N=None, K=None, swiglu_bwd=None):
     """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b: 2-D bf16 with unit inner stride (row stride free)."""
     _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b")
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -48,6 +48,15 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
     N = b.shape[0] if N is None else N
     K = a.shape[1] if K is None else K
     assert K <= a.shape[1] and K <= b.shape[1]
+    if swiglu_bwd is not None:
+        # fused SwiGLU backward epilogue: out [M, 2N] = (dgate | dup), swiglu_bwd = saved gate|up [M, 2N]
+        assert bias is None and residual is None and not gelu and not accumulate and not out_f32 and swiglu_bwd.shape[1] == 2 * N
+        _chk(swiglu_bwd, BF16, "gemm swiglu_bwd")
+        if out is None:
+            out = torch.empty((M, 2 * N), device=a.device, dtype=BF16)
+        _lib.call("afk_gemm_nt_bf16", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K, 0,
+                  swiglu_bwd.data_ptr(), swiglu_bwd.stride(0), 0, 0, float(alpha), GEMM_SWIGLU_BWD, _stream())
+        return out
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= N

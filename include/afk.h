@@ -47,6 +47,7 @@ int afk_gemm_set_variant(int variant);
 #define AFK_GEMM_RESIDUAL 4
 #define AFK_GEMM_OUT_F32 8
 #define AFK_GEMM_ACCUM 16
+#define AFK_GEMM_SWIGLU_BWD 32 /* C is [M, 2N]: (dgate | dup) = SwiGLU backward of the product, `residual` = saved gate|up [M, 2N] (Qwen2MLP, modeling_qwen2.py:46-48) */
 int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                      int res_mod, void* preact_out, float alpha, int flags, void* stream);

@@ -367,6 +367,19 @@ def test_gemm_splitk(dev):
         _cmp("splitk accumulate", acc, c.float() + (a.float() @ b.float().T), atol=K ** 0.5 * 3e-2, rtol=3e-2)
 
 
+def test_gemm_swiglu_bwd_epilogue(dev):
+    """down-projection dgrad with the SwiGLU backward fused into its epilogue == dgrad GEMM followed by silu_mul_bwd, bit for bit"""
+    ops = _ops()
+    M, I, H = 700, 1024, 512
+    dy = _rand((M, H), dev, 1.0, 1).to(BF)
+    wt = _rand((I, H), dev, 0.1, 2).to(BF)       # W_down^T shadow: [I, H]
+    gu = _rand((M, 2 * I), dev, 1.5, 3).to(BF)
+    da = ops.gemm_nt(dy, wt)
+    ref = ops.silu_mul_bwd(gu, da)
+    got = ops.gemm_nt(dy, wt, swiglu_bwd=gu)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
 def test_gemm_tn_splitk(dev):
     """narrow weight gradients (encoder: 1280 x 1280 from 12 000 rows) on the TN kernel with split-K: values, determinism, accumulate"""
     ops = _ops()
