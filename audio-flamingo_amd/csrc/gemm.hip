@@ -143,6 +143,78 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------ skinny-M (decode) first pass: HBM-bound weight streaming
+// y[M <= 16, N] = x[M,K] . W[N,K]^T: every weight byte is read exactly once, fully coalesced (one wave-instruction = 1 KiB of ONE weight
+// row), and meets the M activation rows in registers through v_dot2c_f32_bf16; no MFMA (a 128-row tile would waste 127/128 of it and,
+// worse, leave most CUs without a tile).  A wave owns R consecutive weight rows over the K range of its split and keeps R x MB fp32
+// partial sums per lane; the cross-lane reduction happens once at the end.  Output = fp32 partials ws[split][M][N] for the common
+// split-K reduce / epilogue kernel below.  Algorithmic bytes per launch: 2*N*K (+ 2*M*K activations, L1/L2-resident).
+// measured on the AF3-7B decode step: M = 1 5.1 ms/token (MFMA split-K tiles: 6.5), M = 8 7.6 (MFMA split-K: 6.8) - the VALU dot
+// products stop paying above a handful of rows, so the path is taken for M <= 4 only
+#define AFK_GEMV_MAX_M 4
+template <int MB, int R>
+__global__ __launch_bounds__(256) void gemv_nt_bf16_kernel(GemmArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * R;
+    if (n0 >= p.N) return;
+    const int kb_all = (p.K + 511) >> 9;
+    const int kb0 = (int)((int64_t)kb_all * blockIdx.y / p.splits), kb1 = (int)((int64_t)kb_all * (blockIdx.y + 1) / p.splits);
+    float acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[r][m] = 0.f;
+    const bf16* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = p.B + (int64_t)min(n0 + r, p.N - 1) * p.ldb;
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int k = (kb << 9) + lane * 8;
+        if (k < p.K) {  // K % 8 == 0: a lane's 8 elements are all in or all out
+            bf16x8 wv[R], xv[MB];
+#pragma unroll
+            for (int r = 0; r < R; ++r) wv[r] = __builtin_nontemporal_load((const bf16x8*)(wrow[r] + k));  // streamed once: keep L2 for x
+#pragma unroll
+            for (int m = 0; m < MB; ++m) xv[m] = *(const bf16x8*)(p.A + (int64_t)min(m, p.M - 1) * p.lda + k);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bf16x2 a = {wv[r][2 * e], wv[r][2 * e + 1]}, b = {xv[m][2 * e], xv[m][2 * e + 1]};
+                        acc[r][m] = __builtin_amdgcn_fdot2_f32_bf16(a, b, acc[r][m], false);
+                    }
+        }
+    }
+    // cross-lane reduction of the V = R*MB per-lane partial sums as a reduce-scatter: at stride s a lane hands the half it does not
+    // keep to lane^s (V-1 exchanges instead of 6V); after log2(V) halvings lane l holds the complete sum number l >> (6 - log2 V)
+    constexpr int V = R * MB;
+    static_assert((V & (V - 1)) == 0 && V <= 64, "R*MB must be a power of two <= 64");
+    float* v = &acc[0][0];
+    int n = V;
+#pragma unroll
+    for (int sft = 5; sft >= 0; --sft) {
+        const int st = 1 << sft;
+        const bool up = (lane >> sft) & 1;
+        if (n > 1) {
+            const int h = n >> 1;
+#pragma unroll
+            for (int i = 0; i < V / 2; ++i)
+                if (i < h) {
+                    const float lo = v[i], hi_ = v[i + h];
+                    v[i] = (up ? hi_ : lo) + __shfl_xor(up ? lo : hi_, st, 64);
+                }
+            n = h;
+        } else {
+            v[0] += __shfl_xor(v[0], st, 64);
+        }
+    }
+    constexpr int LOGV = V == 64 ? 6 : V == 32 ? 5 : V == 16 ? 4 : V == 8 ? 3 : V == 4 ? 2 : V == 2 ? 1 : 0;
+    const int idx = lane >> (6 - LOGV);
+    const int r = idx / MB, m = idx % MB;
+    if ((lane & ((64 >> LOGV) - 1)) == 0 && n0 + r < p.N && m < p.M) p.ws[((int64_t)blockIdx.y * p.M + m) * p.N + n0 + r] = v[0];
+}
+
 // split-K second pass: fixed-order sum of the partials (bit-deterministic), then the same fused epilogue as the one-pass kernels
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs p) {
     const int n4 = p.N >> 2;
@@ -233,6 +305,8 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
                      int res_mod, void* preact_out, float alpha, int flags, void* stream, int splits = 1, void* workspace = nullptr) {
     AFK_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || workspace), "afk_gemm_*_splitk: 1..64 splits, workspace required");
     AFK_REQUIRE(splits == 1 || splits <= (K + BK - 1) / BK, "afk_gemm_*_splitk: more splits than K tiles");
+    const bool gemv = workspace != nullptr && M <= AFK_GEMV_MAX_M && !trans_a && !trans_b;  // skinny-M weight streaming (decode)
+    AFK_REQUIRE(!gemv || splits <= (K + 511) / 512, "afk_gemm_nt_bf16_splitk: M <= 16 streams K in blocks of 512: at most ceil(K/512) splits");
     AFK_REQUIRE(A && B && C, "afk_gemm_nt_bf16: null operand");
     AFK_REQUIRE(M > 0 && N > 0 && K > 0, "afk_gemm_nt_bf16: bad shape %d %d %d", M, N, K);
     AFK_REQUIRE(!trans_a || trans_b, "afk_gemm_bf16: A^T with k-contiguous B is not implemented (NT, NN, TN are)");
@@ -268,7 +342,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.ws = (float*)workspace;
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = trans_b || (splits == 1 && (g_variant == 2 || (g_variant == 0 && tiles256 >= 192)));
+    const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant == 2 || (g_variant == 0 && tiles256 >= 192))));
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -293,7 +367,17 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
         }
     }
     if (prof) hipEventRecord(e0, st);
-    if (trans_b) {
+    if (gemv) {
+        const dim3 grid((unsigned)afk_cdiv(N, 32), (unsigned)splits);
+#define AFK_GEMV(MB_, R_) hipLaunchKernelGGL((gemv_nt_bf16_kernel<MB_, R_>), grid, dim3(256), 0, st, p)
+        if (M == 1) AFK_GEMV(1, 8);
+        else if (M == 2) AFK_GEMV(2, 8);
+        else AFK_GEMV(4, 8);
+#undef AFK_GEMV
+        int g = (int)afk_cdiv((int64_t)M * (N / 4), 256);
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
+    } else if (trans_b) {
         if (int e = afk_launch_gemm256t(p, trans_a, st)) return e;
         if (splits > 1) {
             int g = (int)afk_cdiv((int64_t)M * (N / 4), 256);

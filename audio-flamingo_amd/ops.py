@@ -77,7 +77,7 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
     if preact_out is not None:
         assert preact_out.stride(0) == out.stride(0) and preact_out.dtype == BF16
     splits = splitk_plan(M, N, K)
-    if splits > 1:
+    if splits > 1 or M <= GEMV_MAX_M:
         ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
         _lib.call("afk_gemm_nt_bf16_splitk", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
                   M, N, K, _p(bias), _p(residual), residual.stride(0) if residual is not None else 0, res_mod,
@@ -89,12 +89,16 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
     return out
 
 
+GEMV_MAX_M = 4  # AFK_GEMV_MAX_M in csrc/gemm.hip
 SPLITK = os.environ.get("AFK_SPLITK", "1") != "0"
 
 
 def splitk_plan(M, N, K):
     """number of K splits for an NT GEMM: > 1 only when the output has too few 128x128 tiles to fill the chip (2 x 256 workgroup
     slots) and the reduction is long enough to share - decode-time Linears (M = batch) and weight gradients of narrow layers"""
+    if M <= GEMV_MAX_M and SPLITK:  # decode: weight-streaming kernel (csrc/gemm.hip gemv_nt_bf16_kernel), 32 weight rows per workgroup
+        blocks = (N + 31) // 32
+        return max(1, min(16, (K + 511) // 512, (1536 + blocks - 1) // blocks))
     if not SPLITK or K < 1024:
         return 1
     t256 = ((M + 255) // 256) * ((N + 255) // 256)

@@ -61,7 +61,9 @@ int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const vo
 /* Split-K form of afk_gemm_nt_bf16 for outputs with few tiles and a long reduction (decode-time Linear layers with a handful of rows,
  * weight gradients of narrow layers): `splits` workgroups per 128x128 output tile each reduce a K range into fp32 partials
  * workspace[splits][M][N] (splits*M*N*4 bytes, caller-owned), a second kernel sums them in fixed order (bit-deterministic) and applies
- * the same fused epilogue (bias / GELU / residual / accumulate).  Same oracle lines as afk_gemm_nt_bf16. */
+ * the same fused epilogue (bias / GELU / residual / accumulate).  Same oracle lines as afk_gemm_nt_bf16.
+ * M <= 4 (decode) takes a weight-streaming first pass instead of MFMA tiles: every weight row is read once, coalesced, against the M
+ * activation rows held in registers (HBM-bound: 2*N*K bytes per launch); there `splits` <= ceil(K / 512) and may be 1. */
 int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                             const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
                             int flags, int splits, void* workspace, void* stream);

@@ -367,6 +367,21 @@ def test_gemm_splitk(dev):
         _cmp("splitk accumulate", acc, c.float() + (a.float() @ b.float().T), atol=K ** 0.5 * 3e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 16])
+def test_gemv_decode_shapes(dev, M):
+    """skinny-M weight-streaming path (decode-time Linear layers): values vs fp32, bias + residual epilogue, ragged N / K, determinism"""
+    ops = _ops()
+    for (N, K) in [(3584, 3584), (4608, 3584), (1000, 1280), (3584, 18944), (72, 256)]:
+        a = _rand((M, K), dev, 1.0, 1).to(BF)
+        b = _rand((N, K), dev, 1.0, 2).to(BF)
+        bias = _rand((N,), dev, 1.0, 3).to(BF)
+        res = _rand((M, N), dev, 1.0, 4).to(BF)
+        c = ops.gemm_nt(a, b, bias=bias, residual=res)
+        ref = (a.float() @ b.float().T + bias.float()).to(BF).float() + res.float()
+        _cmp(f"gemv {M}x{N}x{K}", c, ref, atol=K ** 0.5 * 2e-2, rtol=2e-2)
+        assert torch.equal(ops.gemm_nt(a, b, bias=bias, residual=res), c)
+
+
 def test_gemm_swiglu_bwd_epilogue(dev):
     """down-projection dgrad with the SwiGLU backward fused into its epilogue == dgrad GEMM followed by silu_mul_bwd, bit for bit"""
     ops = _ops()
