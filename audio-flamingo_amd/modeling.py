@@ -391,6 +391,14 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                       ops._p(start_dev), int(start or 0), B, n, Hkv, D, ops._stream())
             if fast_prefill:
                 o, _ = ops.attn_fwd(qkv, B, n, Hq, Hkv, D, scale=D ** -0.5, causal=True)
+            elif n == 1 and D in (64, 128) and self.decode_splits > 0:
+                # one query row per sample: split-KV kernel (the cache is read once, nsplit blocks per head)
+                o = torch.empty((B, nq), device=x.device, dtype=torch.bfloat16)
+                ns = self.decode_splits
+                ws = torch.empty(_lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns), device=x.device, dtype=torch.float32)
+                _lib.call("afk_attn_decode", qkv.data_ptr(), qkv.stride(0), D, Kc[i].data_ptr(), Smax * nk, nk, D, Vt[i].data_ptr(),
+                          Hkv * D * Spad, Spad, o.data_ptr(), nq, D, krange.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns,
+                          ws.data_ptr(), ops._stream())
             else:
                 o = torch.empty((B * n, nq), device=x.device, dtype=torch.bfloat16)
                 lse = torch.empty((B, Hq, n), device=x.device, dtype=torch.float32)
@@ -403,6 +411,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             x = ops.gemm_nt(ops.silu_mul_fwd(gu), A("mlp.down_proj.weight").data, residual=x2)
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
+
+    decode_splits = 8  # key-range splits of the Q = 1 attention (0: use the interval MFMA kernel instead)
 
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""

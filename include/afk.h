@@ -203,6 +203,15 @@ int afk_rotary_time(const void* x, const float* cos_t, const float* sin_t, void*
 int afk_kv_cache_append(const void* qkv, int64_t ld, int k_col0, void* kcache, int64_t kc_bs, void* vtcache, int64_t vt_bs,
                         int spad, const int* start_dev, int start_host, int B, int n, int Hkv, int D, void* stream);
 
+/* Decode-time attention over the KV cache, one query row per sample (Qwen2Attention.forward with past_key_values, modeling_qwen2.py:
+ * 195-234): split-KV.  Q [B][Hq][D] (strides q_bs, q_hs), K cache [B][pos][Hkv][D] (k_bs, k_rs, k_hs), V^T cache [B][Hkv][D][spad]
+ * (vt_bs) as written by afk_kv_cache_append, O like Q.  krange[B][2] = visible key interval [lo, hi) per sample, read on the device.
+ * workspace: afk_attn_decode_workspace_floats(B, Hq, D, nsplit) floats.  head_dim 64 / 128. */
+int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit);
+int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                    const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
+                    int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
+
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;
  * denom = device scalar (number of valid labels, or num_items_in_batch). */

@@ -538,6 +538,36 @@ def test_rotary_time(dev):
     _cmp("rotary_time bwd", ops.rotary_time(dy, cos, sin, backward=True), xr.grad, atol=1e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (64, 4, 4)])
+def test_attn_decode_split_kv(dev, D, Hq, Hkv):
+    """Q = 1 attention over a KV cache (split-KV kernel) against fp32 softmax attention; ragged visible intervals [lo, hi) per sample"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    B, Smax = 3, 1000
+    spad = ops.pad64(Smax)
+    nk, nq = Hkv * D, Hq * D
+    q = _rand((B, nq), dev, 1.0, 1).to(BF)
+    kc = _rand((B, Smax, nk), dev, 1.0, 2).to(BF)
+    v = _rand((B, Smax, nk), dev, 1.0, 3).to(BF)
+    vt = torch.zeros((B, Hkv, D, spad), device=dev, dtype=BF)
+    vt[..., :Smax] = v.reshape(B, Smax, Hkv, D).permute(0, 2, 3, 1)
+    kr = torch.tensor([[0, 1000], [37, 801], [5, 6]], device=dev, dtype=torch.int32)
+    for ns in (1, 8, 13):
+        o = torch.empty((B, nq), device=dev, dtype=BF)
+        ws = torch.empty(_lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns), device=dev, dtype=torch.float32)
+        _lib.call("afk_attn_decode", q.data_ptr(), nq, D, kc.data_ptr(), Smax * nk, nk, D, vt.data_ptr(), Hkv * D * spad, spad, o.data_ptr(), nq, D,
+                  kr.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, ws.data_ptr(), ops._stream())
+        g = Hq // Hkv
+        for b in range(B):
+            lo, hi = int(kr[b, 0]), int(kr[b, 1])
+            qq = q[b].float().reshape(Hq, D)
+            kk = kc[b, lo:hi].float().reshape(hi - lo, Hkv, D).repeat_interleave(g, 1)
+            vv = v[b, lo:hi].float().reshape(hi - lo, Hkv, D).repeat_interleave(g, 1)
+            p = torch.softmax(torch.einsum("hd,shd->hs", qq, kk) * D ** -0.5, -1)
+            ref = torch.einsum("hs,shd->hd", p, vv).reshape(-1)
+            _cmp(f"attn_decode ns={ns} b={b}", o[b], ref, atol=2e-2, rtol=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()
