@@ -118,37 +118,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue. lane holds m = ..+l31 and n = ..+8q+4hi+{0..3} for q = 0..3 (regs 4q..4q+3)
+    // ---- epilogue (gemm_common.h): every lane takes part in the lane-half exchange of the wide form, so no early exit per lane
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + l31;
-        if (m >= p.M) continue;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (p.splits > 1) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.ws + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = o;
-                } else {
-                    gemm_epilogue_store4(p, m, n, v);
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 64 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
-// ------------------------------------------------------------------ skinny-M (decode) first pass: HBM-bound weight streaming
-// y[M <= 16, N] = x[M,K] . W[N,K]^T: every weight byte is read exactly once, fully coalesced (one wave-instruction = 1 KiB of ONE weight
-// row), and meets the M activation rows in registers through v_dot2c_f32_bf16; no MFMA (a 128-row tile would waste 127/128 of it and,
-// worse, leave most CUs without a tile).  A wave owns R consecutive weight rows over the K range of its split and keeps R x MB fp32
-// partial sums per lane; the cross-lane reduction happens once at the end.  Output = fp32 partials ws[split][M][N] for the common
-// split-K reduce / epilogue kernel below.  Algorithmic bytes per launch: 2*N*K (+ 2*M*K activations, L1/L2-resident).
 // measured on the AF3-7B decode step: M = 1 5.1 ms/token (MFMA split-K tiles: 6.5), M = 8 7.6 (MFMA split-K: 6.8) - the VALU dot
 // products stop paying above a handful of rows, so the path is taken for M <= 4 only
 #define AFK_GEMV_MAX_M 4
@@ -247,6 +223,7 @@ struct ProfState {
 ProfState g_prof;
 int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256
 int g_gm = 0;       // rasterization group height override (0 = default 8)
+int g_wide = 1;     // 16-byte epilogue form allowed (afk_gemm_set_variant bit 4 clears it: A/B experiments)
 
 hipEvent_t prof_next_event() {
     if (g_prof.used == g_prof.pool.size()) {
@@ -262,6 +239,7 @@ hipEvent_t prof_next_event() {
 extern "C" int afk_gemm_set_variant(int v) {
     // v = base + 256*gm : the rasterization group height is a tuning knob of tools/exp_gemm.py
     g_gm = (v >> 8) & 255;
+    g_wide = (v & 16) ? 0 : 1;
     v &= 15;
     AFK_REQUIRE(v >= 0 && v <= 2, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
     g_variant = v;
@@ -340,6 +318,14 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.gm = g_gm;
     p.splits = splits;
     p.ws = (float*)workspace;
+    {
+        const bool f32 = (flags & AFK_GEMM_OUT_F32) != 0;
+        bool w = N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)C % (f32 ? 32 : 16) == 0;
+        if (flags & AFK_GEMM_BIAS) w = w && (uintptr_t)bias % 16 == 0;
+        if (flags & (AFK_GEMM_RESIDUAL | AFK_GEMM_SWIGLU_BWD)) w = w && ldr % 8 == 0 && (uintptr_t)residual % 16 == 0;
+        if (preact_out) w = w && (uintptr_t)preact_out % 16 == 0;
+        p.wide = w && g_wide ? 1 : 0;
+    }
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
     const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant == 2 || (g_variant == 0 && tiles256 >= 192))));

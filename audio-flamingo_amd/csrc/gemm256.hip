@@ -214,22 +214,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + i * 32 + l31;
-        if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                gemm_epilogue_store4(p, m, n, v);
-            }
-        }
-    }
+        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
 }  // namespace

@@ -308,27 +308,9 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
     if (wm == 0) AFK_BARRIER();
 
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 128 + i * 32 + l31;
-        if (m >= p.M) continue;
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (p.splits > 1) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.ws + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = o;
-                } else {
-                    gemm_epilogue_store4(p, m, n, v);
-                }
-            }
-        }
-    }
+        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
 }  // namespace

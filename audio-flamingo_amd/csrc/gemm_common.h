@@ -17,8 +17,9 @@ struct GemmArgs {
     int res_mod;  // residual row = m % res_mod when > 0 (broadcast table, e.g. embed_positions)
     float alpha;
     int gm;  // M-tiles per rasterization group (L2 locality)
-    int splits;  // split-K (128x128 kernel only): blockIdx.y = split, raw fp32 partial sums go to ws[split][M][N]
+    int splits;  // split-K: blockIdx.y = split, raw fp32 partial sums go to ws[split][M][N]
     float* ws;
+    int wide;    // 16-byte epilogue accesses are legal (N % 8 == 0 and every epilogue pointer / leading dimension 16-byte aligned)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -39,79 +40,123 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, i
     tn = rem / gsz;
 }
 
-// epilogue for 4 consecutive n of one row m (values already hold the fp32 accumulators)
+// epilogue for W (4 or 8) consecutive n of one row m (values already hold the fp32 accumulators)
 // order: *alpha, +bias[n] -> (round bf16, write preact, GELU-erf) -> (round bf16, +residual) -> (+C if ACCUM) -> store
-__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, int n, float v[4]) {
+template <int W>
+__device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& p, int m, int n, float* v) {
+    typedef __attribute__((ext_vector_type(W))) __bf16 bvec;
+    typedef __attribute__((ext_vector_type(W))) float fvec;
     const int flags = p.flags;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+    for (int e = 0; e < W; ++e) v[e] *= p.alpha;
     if (flags & AFK_GEMM_BIAS) {
-        const bf16x4 bv = *(const bf16x4*)(p.bias + n);
+        const bvec bv = *(const bvec*)(p.bias + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)bv[e];
+        for (int e = 0; e < W; ++e) v[e] += (float)bv[e];
     }
     if (flags & AFK_GEMM_GELU) {
         // oracle applies GELU to the bf16-rounded Linear output
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]);
+        for (int e = 0; e < W; ++e) v[e] = rbf(v[e]);
         if (p.C2) {
-            bf16x4 pre;
+            bvec pre;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pre[e] = (bf16)v[e];
-            *(bf16x4*)((bf16*)p.C2 + (int64_t)m * p.ldc + n) = pre;
+            for (int e = 0; e < W; ++e) pre[e] = (bf16)v[e];
+            *(bvec*)((bf16*)p.C2 + (int64_t)m * p.ldc + n) = pre;
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < W; ++e) v[e] = gelu_f(v[e]);
     }
     if (flags & AFK_GEMM_SWIGLU_BWD) {
-        // v = d(silu(gate)*up) for columns n..n+3 of the SwiGLU output (this GEMM is the down-projection dgrad).  R = the saved
+        // v = d(silu(gate)*up) for columns n.. of the SwiGLU output (this GEMM is the down-projection dgrad).  R = the saved
         // [rows, 2N] gate|up pre-activations; the two gradients go to C[m, n] (gate) and C[m, N + n] (up): the [rows, N] intermediate
         // never exists in HBM.  Same arithmetic as silu_mul_bwd_kernel on the bf16-rounded GEMM result (bit-identical to the
         // two-kernel form).
-        const bf16x4 gv = *(const bf16x4*)(p.R + (int64_t)m * p.ldr + n);
-        const bf16x4 uv = *(const bf16x4*)(p.R + (int64_t)m * p.ldr + p.N + n);
-        bf16x4 og, ou;
+        const bvec gv = *(const bvec*)(p.R + (int64_t)m * p.ldr + n);
+        const bvec uv = *(const bvec*)(p.R + (int64_t)m * p.ldr + p.N + n);
+        bvec og, ou;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < W; ++e) {
             const float gf = (float)gv[e], uf = (float)uv[e], df = rbf(v[e]);
             const float s = sigmoid_f(gf);
             og[e] = (bf16)(df * uf * (s * (1.f + gf * (1.f - s))));
             ou[e] = (bf16)(df * (gf * s));
         }
         bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
-        *(bf16x4*)cp = og;
-        *(bf16x4*)(cp + p.N) = ou;
+        *(bvec*)cp = og;
+        *(bvec*)(cp + p.N) = ou;
         return;
     }
     if (flags & AFK_GEMM_RESIDUAL) {
         const int rm = p.res_mod > 0 ? m % p.res_mod : m;
-        const bf16x4 rv = *(const bf16x4*)(p.R + (int64_t)rm * p.ldr + n);
+        const bvec rv = *(const bvec*)(p.R + (int64_t)rm * p.ldr + n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = rbf(v[e]) + (float)rv[e];
+        for (int e = 0; e < W; ++e) v[e] = rbf(v[e]) + (float)rv[e];
     }
     if (flags & AFK_GEMM_OUT_F32) {
         float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-        f32x4 o;
+        fvec o;
         if (flags & AFK_GEMM_ACCUM) {
-            o = *(const f32x4*)cp;
+            o = *(const fvec*)cp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += v[e];
+            for (int e = 0; e < W; ++e) o[e] += v[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = v[e];
+            for (int e = 0; e < W; ++e) o[e] = v[e];
         }
-        *(f32x4*)cp = o;
+        *(fvec*)cp = o;
     } else {
         bf16* cp = (bf16*)p.C + (int64_t)m * p.ldc + n;
         if (flags & AFK_GEMM_ACCUM) {
-            const bf16x4 old = *(const bf16x4*)cp;
+            const bvec old = *(const bvec*)cp;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)old[e];
+            for (int e = 0; e < W; ++e) v[e] += (float)old[e];
         }
-        bf16x4 o;
+        bvec o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-        *(bf16x4*)cp = o;
+        for (int e = 0; e < W; ++e) o[e] = (bf16)v[e];
+        *(bvec*)cp = o;
+    }
+}
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, int n, float v[4]) { gemm_epilogue_store<4>(p, m, n, v); }
+
+// One 32 (m) x 32 (n) MFMA result block of a wave: lane (l31, hi) holds row m and, in accumulator registers 4q..4q+3, the columns
+// nb + 8q + 4hi + {0..3}.  Wide form (p.wide: every pointer / leading dimension of the epilogue keeps 16-byte alignment): the two lane
+// halves trade registers through v_permlane32_swap so that each lane owns 8 CONSECUTIVE columns (nb + 16t + 8hi + 0..7) - 16-byte stores
+// and 16-byte bias / residual loads, half as many memory instructions as the 8-byte form.  Split-K partials keep the 4-wide form.
+__device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc) {
+    if (m >= p.M) return;
+    if (p.splits > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = nb + 8 * q + 4 * hi;
+            if (n >= p.N) continue;
+            const f32x4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *(f32x4*)(p.ws + ((int64_t)blockIdx.y * p.M + m) * p.N + n) = o;
+        }
+        return;
+    }
+    if (p.wide) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * t + e]), __float_as_uint(acc[8 * t + 4 + e]), false, false);
+                v[e] = __uint_as_float(r[0]);      // lo lanes: own q=2t ; hi lanes: partner's q=2t+1
+                v[4 + e] = __uint_as_float(r[1]);  // lo lanes: partner's q=2t ; hi lanes: own q=2t+1
+            }
+            const int n = nb + 16 * t + 8 * hi;
+            if (n < p.N) gemm_epilogue_store<8>(p, m, n, v);
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = nb + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        gemm_epilogue_store<4>(p, m, n, v);
     }
 }
 

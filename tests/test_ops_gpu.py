@@ -382,6 +382,31 @@ def test_gemv_decode_shapes(dev, M):
         assert torch.equal(ops.gemm_nt(a, b, bias=bias, residual=res), c)
 
 
+def test_gemm_wide_epilogue_matches_narrow(dev):
+    """16-byte epilogue (lane halves trade registers, 8 consecutive columns per lane) == the 8-byte form, bit for bit, for every fused
+    epilogue; shapes with N % 8 != 0 or misaligned operands silently take the narrow form"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    for (M, N, K) in [(300, 520, 256), (8192, 3584, 512), (1000, 1028, 128)]:
+        a = _rand((M, K), dev, 1.0, 1).to(BF)
+        b = _rand((N, K), dev, 1.0, 2).to(BF)
+        bias = _rand((N,), dev, 1.0, 3).to(BF)
+        res = _rand((M, N), dev, 1.0, 4).to(BF)
+        outs = []
+        for narrow in (0, 16):
+            _lib.call("afk_gemm_set_variant", narrow)
+            pre = torch.empty((M, N), device=dev, dtype=BF)
+            y1 = ops.gemm_nt(a, b, bias=bias, gelu=True, preact_out=pre, residual=res)
+            y2 = ops.gemm_nt(a, b, out_f32=True)
+            y3 = res.clone()
+            ops.gemm_nt(a, b, out=y3, accumulate=True)
+            y4 = ops.gemm(a.t().contiguous(), b.t().contiguous(), trans_a=True, trans_b=True) if M % 8 == 0 and N % 8 == 0 else None
+            outs.append((y1, pre, y2, y3, y4))
+        _lib.call("afk_gemm_set_variant", 0)
+        for x, y in zip(*outs):
+            assert (x is None and y is None) or torch.equal(x, y)
+
+
 def test_gemm_swiglu_bwd_epilogue(dev):
     """down-projection dgrad with the SwiGLU backward fused into its epilogue == dgrad GEMM followed by silu_mul_bwd, bit for bit"""
     ops = _ops()
