@@ -1,7 +1,7 @@
 // LayerNorm / RMSNorm forward + backward for gfx950 (HBM-bound row kernels).
 //
-// One 64-lane wave owns one row; the row lives in registers as VPL bf16x4 vectors per lane (8-byte
-// coalesced loads, 512 B per wave-instruction), statistics in fp32 with wave shuffles only - no LDS, no
+// One 64-lane wave owns one row; the row lives in registers as VPL vectors of VW = 8 bf16 per lane (16-byte
+// coalesced loads, 1 KiB per wave-instruction; VW = 4 when D % 8 != 0), statistics in fp32 with wave shuffles only - no LDS, no
 // barriers - 4 rows per 256-thread block, grid-stride over rows.  Algorithmic traffic: read x + write y
 // (fwd), read x,dy + write dx (bwd) - SURVEY.md §8(d).
 //
@@ -19,32 +19,34 @@ namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;
 
-template <int VPL, bool RMS>
+// VW = elements per lane-vector: 8 (16-byte accesses, 1 KiB per wave-instruction) whenever D % 8 == 0, else 4
+template <int VPL, bool RMS, int VW>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                        const bf16* __restrict__ b, bf16* __restrict__ y,
                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                        int64_t rows, int D, float eps) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nvec = D >> 2;
+    typedef __attribute__((ext_vector_type(VW))) __bf16 bvec;
+    const int nvec = D / VW;
     const float invD = 1.f / (float)D;
     for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
         const bf16* xr = x + row * D;
-        float v[VPL][4];
+        float v[VPL][VW];
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                const bf16x4 t = *(const bf16x4*)(xr + 4 * vi);
+                const bvec t = *(const bvec*)(xr + VW * vi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < VW; ++e) {
                     v[i][e] = (float)t[e];
                     s += v[i][e];
                     ss += v[i][e] * v[i][e];
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+                for (int e = 0; e < VW; ++e) v[i][e] = 0.f;
             }
         }
         float mean = 0.f, rstd;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16* __restrict__ 
                 const int vi = lane + 64 * i;
                 if (vi < nvec) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < VW; ++e) {
                         const float d = v[i][e] - mean;
                         q += d * d;
                     }
@@ -79,17 +81,17 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16* __restrict__ 
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                const bf16x4 wv4 = *(const bf16x4*)(w + 4 * vi);
-                bf16x4 o;
+                const bvec wv4 = *(const bvec*)(w + VW * vi);
+                bvec o;
                 if (RMS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((float)wv4[e] * rbf(v[i][e] * rstd));
+                    for (int e = 0; e < VW; ++e) o[e] = (bf16)((float)wv4[e] * rbf(v[i][e] * rstd));
                 } else {
-                    const bf16x4 bv4 = *(const bf16x4*)(b + 4 * vi);
+                    const bvec bv4 = *(const bvec*)(b + VW * vi);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd * (float)wv4[e] + (float)bv4[e]);
+                    for (int e = 0; e < VW; ++e) o[e] = (bf16)((v[i][e] - mean) * rstd * (float)wv4[e] + (float)bv4[e]);
                 }
-                *(bf16x4*)(yr + 4 * vi) = o;
+                *(bvec*)(yr + VW * vi) = o;
             }
         }
     }
@@ -98,22 +100,24 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16* __restrict__ 
 // backward.  dx for one row; per-block fp32 partial sums of dw (and db) over the rows this block visits.
 //   LN : xh=(x-mean)*rstd; g=dy*w;  dx = rstd*(g - mean(g) - xh*mean(g*xh));  dw+=dy*xh; db+=dy
 //   RMS: xh=x*rstd;        g=dy*w;  dx = rstd*(g - xh*mean(g*xh));            dw+=dy*bf16(xh)
-template <int VPL, bool RMS>
+template <int VPL, bool RMS, int VW>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                        const bf16* __restrict__ dy, const float* __restrict__ mean_in,
                                                        const float* __restrict__ rstd_in, bf16* __restrict__ dx,
                                                        const bf16* __restrict__ dx_add, float* __restrict__ partials,
                                                        int64_t rows, int D) {
-    __shared__ float red[2][VPL * 256];  // cross-wave fold of the column partials
+    typedef __attribute__((ext_vector_type(VW))) __bf16 bvec;
+    typedef __attribute__((ext_vector_type(VW / 2))) unsigned packed_t;
+    __shared__ float red[2][VPL * 64 * VW];  // cross-wave fold of the column partials
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nvec = D >> 2;
+    const int nvec = D / VW;
     const float invD = 1.f / (float)D;
-    float pw[VPL][4], pb[VPL][4];
+    float pw[VPL][VW], pb[VPL][VW];
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pw[i][e] = pb[i][e] = 0.f;
-    for (int c = threadIdx.x; c < VPL * 256; c += 256) red[0][c] = red[1][c] = 0.f;
+        for (int e = 0; e < VW; ++e) pw[i][e] = pb[i][e] = 0.f;
+    for (int c = threadIdx.x; c < VPL * 64 * VW; c += 256) red[0][c] = red[1][c] = 0.f;
     for (int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wv; row < rows; row += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
         const bf16* xr = x + row * D;
         const bf16* dyr = dy + row * D;
@@ -121,26 +125,26 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
         const float rstd = rstd_in[row];
         // the row stays in registers as PACKED bf16 (2 VGPRs per 4 elements): 56 instead of 112 VGPRs at D=3584, which
         // is what lets 3 waves/SIMD be resident and keep enough loads in flight for an HBM-bound kernel
-        bf16x4 xv[VPL], dv[VPL];
+        bvec xv[VPL], dv[VPL];
         float sg = 0.f, sgx = 0.f;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                xv[i] = *(const bf16x4*)(xr + 4 * vi);
-                dv[i] = *(const bf16x4*)(dyr + 4 * vi);
+                xv[i] = *(const bvec*)(xr + VW * vi);
+                dv[i] = *(const bvec*)(dyr + VW * vi);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[i][e] = dv[i][e] = (bf16)0.f;
+                for (int e = 0; e < VW; ++e) xv[i][e] = dv[i][e] = (bf16)0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                const bf16x4 wt = *(const bf16x4*)(w + 4 * vi);
+                const bvec wt = *(const bvec*)(w + VW * vi);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < VW; ++e) {
                     const float d = (float)dv[i][e];
                     const float xh = ((float)xv[i][e] - mean) * rstd;
                     const float g = d * (float)wt[e];
@@ -157,31 +161,31 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
         // first pass's fp32 values alive (that is what blew the register budget)
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
-            asm volatile("" : "+v"(*(uint2*)&xv[i]));
-            asm volatile("" : "+v"(*(uint2*)&dv[i]));
+            asm volatile("" : "+v"(*(packed_t*)&xv[i]));
+            asm volatile("" : "+v"(*(packed_t*)&dv[i]));
         }
         bf16* dxr = dx + row * D;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) {
             const int vi = lane + 64 * i;
             if (vi < nvec) {
-                const bf16x4 wt = *(const bf16x4*)(w + 4 * vi);
-                bf16x4 o;
-                float r[4];
+                const bvec wt = *(const bvec*)(w + VW * vi);
+                bvec o;
+                float r[VW];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < VW; ++e) {
                     const float xh = ((float)xv[i][e] - mean) * rstd;
                     const float g = (float)dv[i][e] * (float)wt[e];
                     r[e] = rstd * (g - sg - xh * sgx);
                 }
                 if (dx_add) {  // fused residual-gradient merge: dx = bf16(norm-branch) + skip-branch
-                    const bf16x4 a = *(const bf16x4*)(dx_add + row * D + 4 * vi);
+                    const bvec a = *(const bvec*)(dx_add + row * D + VW * vi);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] = rbf(r[e]) + (float)a[e];
+                    for (int e = 0; e < VW; ++e) r[e] = rbf(r[e]) + (float)a[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)r[e];
-                *(bf16x4*)(dxr + 4 * vi) = o;
+                for (int e = 0; e < VW; ++e) o[e] = (bf16)r[e];
+                *(bvec*)(dxr + VW * vi) = o;
             }
         }
     }
@@ -194,9 +198,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
 #pragma unroll
             for (int i = 0; i < VPL; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    red[0][(lane + 64 * i) * 4 + e] += pw[i][e];
-                    if (!RMS) red[1][(lane + 64 * i) * 4 + e] += pb[i][e];
+                for (int e = 0; e < VW; ++e) {
+                    red[0][(lane + 64 * i) * VW + e] += pw[i][e];
+                    if (!RMS) red[1][(lane + 64 * i) * VW + e] += pb[i][e];
                 }
         }
         __syncthreads();
@@ -238,13 +242,20 @@ template <bool RMS>
 int launch_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows, int D,
                float eps, hipStream_t st) {
     const int g = norm_grid(rows);
-#define AFK_NF(V)                                                                                                    \
-    hipLaunchKernelGGL((norm_fwd_kernel<V, RMS>), dim3(g), dim3(256), 0, st, (const bf16*)x, (const bf16*)w,       \
+#define AFK_NF(V, W)                                                                                                 \
+    hipLaunchKernelGGL((norm_fwd_kernel<V, RMS, W>), dim3(g), dim3(256), 0, st, (const bf16*)x, (const bf16*)w,    \
                        (const bf16*)b, (bf16*)y, mean, rstd, rows, D, eps)
-    if (D <= 512) AFK_NF(2);
-    else if (D <= 1280) AFK_NF(5);
-    else if (D <= 3584) AFK_NF(14);
-    else AFK_NF(32);
+    if (D % 8 == 0) {
+        if (D <= 512) AFK_NF(1, 8);
+        else if (D <= 1536) AFK_NF(3, 8);
+        else if (D <= 3584) AFK_NF(7, 8);
+        else AFK_NF(16, 8);
+    } else {
+        if (D <= 512) AFK_NF(2, 4);
+        else if (D <= 1280) AFK_NF(5, 4);
+        else if (D <= 3584) AFK_NF(14, 4);
+        else AFK_NF(32, 4);
+    }
 #undef AFK_NF
     return AFK_OK;
 }
@@ -252,12 +263,18 @@ int launch_fwd(const void* x, const void* w, const void* b, void* y, float* mean
 template <bool RMS>
 int launch_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
                const void* dx_add, float* partials, int nblocks, int64_t rows, int D, hipStream_t st) {
-#define AFK_NB(V)                                                                                                    \
-    hipLaunchKernelGGL((norm_bwd_kernel<V, RMS>), dim3(nblocks), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, \
+#define AFK_NB(V, W)                                                                                                 \
+    hipLaunchKernelGGL((norm_bwd_kernel<V, RMS, W>), dim3(nblocks), dim3(256), 0, st, (const bf16*)x, (const bf16*)w, \
                        (const bf16*)dy, mean, rstd, (bf16*)dx, (const bf16*)dx_add, partials, rows, D)
-    if (D <= 512) AFK_NB(2);
-    else if (D <= 1280) AFK_NB(5);
-    else AFK_NB(14);
+    if (D % 8 == 0) {
+        if (D <= 512) AFK_NB(1, 8);
+        else if (D <= 1536) AFK_NB(3, 8);
+        else AFK_NB(7, 8);
+    } else {
+        if (D <= 512) AFK_NB(2, 4);
+        else if (D <= 1280) AFK_NB(5, 4);
+        else AFK_NB(14, 4);
+    }
 #undef AFK_NB
     return AFK_OK;
 }
