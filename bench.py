@@ -311,13 +311,14 @@ def main():
         ms_per_step = 1000.0 * dt / args.steps
         samples_per_s = world * args.batch * args.steps / dt
         achieved_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_detail = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
         if os.path.exists(tpath):  # PMC passes cannot run inside bench.py; the committed rocprofv3 --pmc result is quoted
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                       "shape": tj["shape"], "source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+            traffic = tj["hbm_bytes_per_launch"]  # HBM bytes of ONE launch of the kernel on the shape below (largest GEMM of the step)
+            traffic_detail = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                              "shape": tj["shape"], "source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
         hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
         res = {
@@ -338,7 +339,7 @@ def main():
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
             "hardware_tflops_per_gpu": hw_tf,
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",
-                         "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic,
+                         "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic, "traffic_detail": traffic_detail,
                          "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
                          "gemm_ms_per_step": gemm_ms / prof_steps,
                          "timed_region_overlapped": {"achieved": (ov_flops / (ov_ms * 1e-3) / 1e12) if ov_ms > 0 else None, "launches": ov_launches,
