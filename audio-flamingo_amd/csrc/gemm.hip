@@ -125,9 +125,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
         for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 64 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
-// measured on the AF3-7B decode step: M = 1 5.1 ms/token (MFMA split-K tiles: 6.5), M = 8 7.6 (MFMA split-K: 6.8) - the VALU dot
-// products stop paying above a handful of rows, so the path is taken for M <= 4 only
-#define AFK_GEMV_MAX_M 4
+// measured on the AF3-7B decode step (ms/token): M = 1 3.85 (MFMA split-K tiles: 6.5); M = 2 6.3, M = 4 6.4, M = 8 7.6 against 5.3-5.7 on
+// MFMA split-K tiles (per launch 34 us at M = 2 vs 22 us at M = 1) - the path is taken for a single row only; the kernel keeps its
+// multi-row instantiations for the unit tests and for a later look at why the second row costs 55 %
+#define AFK_GEMV_MAX_M 1
 template <int MB, int R>
 __global__ __launch_bounds__(256) void gemv_nt_bf16_kernel(GemmArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -356,9 +357,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     if (gemv) {
         const dim3 grid((unsigned)afk_cdiv(N, 32), (unsigned)splits);
 #define AFK_GEMV(MB_, R_) hipLaunchKernelGGL((gemv_nt_bf16_kernel<MB_, R_>), grid, dim3(256), 0, st, p)
-        if (M == 1) AFK_GEMV(1, 8);
-        else if (M == 2) AFK_GEMV(2, 8);
-        else AFK_GEMV(4, 8);
+        AFK_GEMV(1, 8);
 #undef AFK_GEMV
         int g = (int)afk_cdiv((int64_t)M * (N / 4), 256);
         if (g > 2048) g = 2048;
@@ -395,6 +394,21 @@ extern "C" int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B
                                        const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
                                        int flags, int splits, void* workspace, void* stream) {
     return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream, splits, workspace);
+}
+
+// first pass only (decode glue, csrc/decode_glue.hip): fp32 partials ws[splits][M][N] of x[M,K] . W[N,K]^T, M <= AFK_GEMV_MAX_M
+extern "C" int afk_gemv_partials(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int splits, float* workspace,
+                                 void* stream) {
+    AFK_REQUIRE(A && B && workspace && M >= 1 && M <= AFK_GEMV_MAX_M && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+                "afk_gemv_partials: bad args (M <= %d, K %% 8 == 0)", AFK_GEMV_MAX_M);
+    AFK_REQUIRE(splits >= 1 && splits <= (K + 511) / 512 && splits <= 64, "afk_gemv_partials: 1 <= splits <= ceil(K / 512)");
+    GemmArgs p = {};
+    p.A = (const bf16*)A; p.B = (const bf16*)B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.splits = splits; p.ws = workspace;
+    const dim3 grid((unsigned)afk_cdiv(N, 32), (unsigned)splits);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((gemv_nt_bf16_kernel<1, 8>), grid, dim3(256), 0, st, p);
+    AFK_LAUNCH_CHECK("afk_gemv_partials");
+    return AFK_OK;
 }
 
 extern "C" int afk_gemm_bf16_splitk(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

@@ -413,6 +413,53 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return y
 
     decode_splits = 8  # key-range splits of the Q = 1 attention (0: use the interval MFMA kernel instead)
+    decode_fused_glue = True  # B <= 4: one glue kernel per Linear (csrc/decode_glue.hip) instead of reduce / bias / rope / append / norm / SwiGLU launches
+
+    def _decode_layers_fused(self, x, B, cache, pos_rows, krange, start_dev):
+        """one new position per sample, B <= ops.GEMV_MAX_M rows: every Linear = weight-streaming GEMV partials + ONE glue kernel"""
+        a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
+        Kc, Vt = cache
+        Smax, Spad = Kc.shape[2], Vt.shape[4]
+        nq, nk = Hq * D, Hkv * D
+        H = x.shape[1]
+        dev = x.device
+        cos, sin = self._rope_tables(int(self.config.text_config.max_position_embeddings))
+        st = ops._stream()
+        ns = self.decode_splits
+        aws = torch.empty(_lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns), device=dev, dtype=torch.float32)
+
+        def gemv(inp, w):
+            N, K = w.shape
+            sp = ops.splitk_plan(B, N, K)
+            ws = torch.empty(sp * B * N, device=dev, dtype=torch.float32)
+            _lib.call("afk_gemv_partials", inp.data_ptr(), inp.stride(0), w.data_ptr(), w.stride(0), B, N, K, sp, ws.data_ptr(), st)
+            return ws, sp
+
+        h, _ = ops.rmsnorm_fwd(x, a[f"{lm}layers.0.input_layernorm.weight"].data, self.rms_eps)
+        for i in range(self.dec_layers):
+            A = lambda k: a[f"{lm}layers.{i}.{k}"]
+            ws, sp = gemv(h, A("self_attn.qkv.weight").data)
+            q = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
+            _lib.call("afk_decode_qkv_finish", ws.data_ptr(), sp, B, A("self_attn.qkv.bias").data.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                      pos_rows.data_ptr(), q.data_ptr(), Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad, start_dev.data_ptr(),
+                      Hq, Hkv, D, st)
+            o = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
+            _lib.call("afk_attn_decode", q.data_ptr(), nq, D, Kc[i].data_ptr(), Smax * nk, nk, D, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                      o.data_ptr(), nq, D, krange.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, aws.data_ptr(), st)
+            ws, sp = gemv(o, A("self_attn.o_proj.weight").data)
+            x2, h2 = torch.empty_like(x), torch.empty_like(x)
+            _lib.call("afk_decode_residual_rmsnorm", ws.data_ptr(), sp, B, H, x.data_ptr(), A("post_attention_layernorm.weight").data.data_ptr(),
+                      float(self.rms_eps), x2.data_ptr(), h2.data_ptr(), st)
+            wgu = A("mlp.gate_up.weight").data
+            ws, sp = gemv(h2, wgu)
+            act = torch.empty((B, wgu.shape[0] // 2), device=dev, dtype=torch.bfloat16)
+            _lib.call("afk_decode_swiglu", ws.data_ptr(), sp, B, wgu.shape[0] // 2, act.data_ptr(), st)
+            ws, sp = gemv(act, A("mlp.down_proj.weight").data)
+            nxt = a[f"{lm}layers.{i + 1}.input_layernorm.weight"] if i + 1 < self.dec_layers else a[lm + "norm.weight"]
+            x, h = torch.empty_like(x2), torch.empty_like(x2)
+            _lib.call("afk_decode_residual_rmsnorm", ws.data_ptr(), sp, B, H, x2.data_ptr(), nxt.data.data_ptr(), float(self.rms_eps),
+                      x.data_ptr(), h.data_ptr(), st)
+        return h  # already through the final norm
 
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
@@ -420,7 +467,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         x = st["emb"].index_select(0, st["nxt"])
         pos1 = (st["cur"] - st["lo"]).contiguous()
         kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
-        y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])
+        if self.decode_fused_glue and B <= ops.GEMV_MAX_M and self.D in (64, 128) and self.decode_splits > 0 and ops.SPLITK:
+            y = self._decode_layers_fused(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"])
+        else:
+            y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])
         st["nxt"].copy_(ops.gemm_nt(y, st["head"]).float().argmax(-1))
         st["cur"].add_(1)
 

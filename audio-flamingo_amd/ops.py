@@ -89,7 +89,7 @@ def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, 
     return out
 
 
-GEMV_MAX_M = 4  # AFK_GEMV_MAX_M in csrc/gemm.hip
+GEMV_MAX_M = 1  # AFK_GEMV_MAX_M in csrc/gemm.hip
 if os.environ.get("AFK_GEMM_NARROW") == "1":  # A/B knob: 8-byte GEMM epilogue
     _lib.call("afk_gemm_set_variant", 16)
 SPLITK = os.environ.get("AFK_SPLITK", "1") != "0"

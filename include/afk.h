@@ -62,7 +62,7 @@ int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const vo
  * weight gradients of narrow layers): `splits` workgroups per 128x128 output tile each reduce a K range into fp32 partials
  * workspace[splits][M][N] (splits*M*N*4 bytes, caller-owned), a second kernel sums them in fixed order (bit-deterministic) and applies
  * the same fused epilogue (bias / GELU / residual / accumulate).  Same oracle lines as afk_gemm_nt_bf16.
- * M <= 4 (decode) takes a weight-streaming first pass instead of MFMA tiles: every weight row is read once, coalesced, against the M
+ * M == 1 (decode) takes a weight-streaming first pass instead of MFMA tiles: every weight row is read once, coalesced, against the M
  * activation rows held in registers (HBM-bound: 2*N*K bytes per launch); there `splits` <= ceil(K / 512) and may be 1. */
 int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                             const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
@@ -211,6 +211,18 @@ int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit);
 int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                     const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
                     int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
+
+/* Decode-step glue (csrc/decode_glue.hip): the weight-streaming first pass alone, and one kernel per Linear of a decoder layer that sums
+ * its fp32 partials ws[splits][M][N] and applies everything up to the next Linear's input (one live row per call today: M <= AFK_GEMV_MAX_M; same arithmetic and bf16
+ * rounding points as the stand-alone kernels; oracle lines: modeling_qwen2.py:46-48, 112-135, 213-214, 247-252, 284-297). */
+int afk_gemv_partials(const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int splits, float* workspace,
+                      void* stream);
+int afk_decode_qkv_finish(const float* ws, int splits, int M, const void* bias, const void* cos_t, const void* sin_t, const int* pos,
+                          void* q_out, void* kcache, int64_t kc_bs, void* vtcache, int64_t vt_bs, int spad, const int* start_dev,
+                          int Hq, int Hkv, int D, void* stream);
+int afk_decode_residual_rmsnorm(const float* ws, int splits, int M, int N, const void* residual, const void* w, float eps, void* x_out,
+                                void* h_out, void* stream);
+int afk_decode_swiglu(const float* ws, int splits, int M, int I, void* a_out, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

@@ -197,6 +197,19 @@ def test_generate_kv_cache_matches_prefix_recompute(dev):
     assert a.shape == b.shape and torch.equal(a, b), (a[:, -12:], b[:, -12:])
 
 
+def test_generate_fused_decode_glue_matches_unfused(dev):
+    """B <= 4 decode steps with one glue kernel per Linear (reduce + bias + RoPE + cache append / residual + RMSNorm / SwiGLU) produce the
+    same tokens as the unfused kernel sequence"""
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=12)
+    m.decode_fused_glue = True
+    a = m.generate(g["ids"][:1].to(dev), **kw)
+    m.decode_fused_glue = False
+    b = m.generate(g["ids"][:1].to(dev), **kw)
+    assert torch.equal(a, b), (a[:, -12:], b[:, -12:])
+
+
 def test_generate_left_padded_batch_matches_single(dev):
     """two prompts of different length, LEFT padded into one batch (processor convention): each row must decode exactly as it does alone"""
     torch.manual_seed(3)

@@ -367,7 +367,7 @@ def test_gemm_splitk(dev):
         _cmp("splitk accumulate", acc, c.float() + (a.float() @ b.float().T), atol=K ** 0.5 * 3e-2, rtol=3e-2)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("M", [1, 2, 8])
 def test_gemv_decode_shapes(dev, M):
     """skinny-M weight-streaming path (decode-time Linear layers): values vs fp32, bias + residual epilogue, ragged N / K, determinism"""
     ops = _ops()
