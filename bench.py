@@ -355,12 +355,9 @@ def main():
         line = json.dumps(res)
     else:
         line = None
-    if use_dp:
-        dist.barrier()
-        dist.destroy_process_group()
-    if line is not None:
-        # RCCL writes its version banner through C stdio (fully buffered on a pipe -> it would surface at exit, AFTER the result):
-        # drain both layers first so that the JSON line is the last line of output
+    def drain():
+        # RCCL writes its version banner through C stdio (fully buffered on a pipe -> it would surface at process exit, AFTER the
+        # result): every rank drains both layers
         sys.stdout.flush()
         try:
             import ctypes
@@ -368,6 +365,15 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+
+    drain()
+    if use_dp:
+        dist.barrier()
+        dist.destroy_process_group()
+        drain()
+    if line is not None:
+        if world > 1:
+            time.sleep(2.0)  # the other ranks have nothing left to print, let them leave: the JSON line stays the last line of output
         print(line, flush=True)
 
 
