@@ -11,3 +11,9 @@ Layout:
   frontend.py  log-mel frontend tables + wrapper
 """
 __version__ = "0.1.0"
+
+# multi-stream schedule (arena.enable_wgrad_stream, dp.BackwardOverlap) + RCCL's stream: more hardware queues than ROCm's default 4 keep
+# them from sharing a queue; only effective if the HIP runtime has not initialised yet (see bench.py)
+import os as _os
+
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
