@@ -170,3 +170,40 @@ def test_hf_attention_plugin_registers_and_refuses_cpu():
         hf_plugin._intervals(m)
     kr = hf_plugin._intervals(torch.ones(4, 4, dtype=torch.bool).tril()[None, None])
     assert kr.tolist() == [[[0, 1], [0, 2], [0, 3], [0, 4]]]
+
+
+def test_music_flamingo_time_tables_match_oracle():
+    """host-side index / angle arithmetic of the Music Flamingo delta (which window of its sample every encoder window is, cos / sin of the
+    rotary time angles) against the oracle restatement, on CPU - the rotation kernel itself is covered by the GPU tests"""
+    import torch
+    from transformers import MusicFlamingoConfig
+
+    from audio_flamingo_amd.musicflamingo import MusicFlamingoForConditionalGeneration as Mine
+    from oracle import af3_oracle as O
+
+    T = {k: (dict(v, model_type="audioflamingo3_encoder") if k == "audio_config" else v) for k, v in TINY.items()}
+    m = Mine(MusicFlamingoConfig(**T), device="cpu")
+    S = 9 + 1000 + 9 + 12
+    ids = torch.randint(0, 1000, (2, S))
+    ids[0, 9:1009] = 1023          # sample 0: two windows (750 + 250 tokens)
+    ids[1, 9:134] = 1023           # sample 1: one window (125 tokens)
+    post = torch.tensor([750, 250, 125])
+    ts = m._audio_timestamps(ids, post, 750)
+    ref_ts = O.music_audio_timestamps(ids, post, 750, 1023)
+    assert torch.equal(ts, ref_ts)
+    assert float(ts[1, 0]) == 30.0 and float(ts[2, 0]) == 0.0   # second window of sample 0 starts at 30 s; sample 1 restarts at 0
+    cos, sin = m._tables(ts, 750)
+    rc, rs = O.rotary_time_tables(ref_ts, 750, 128)
+    assert cos.shape == rc.shape == (3, 750, 52)
+    assert float((cos - rc).abs().max()) < 1e-5 and float((sin - rs).abs().max()) < 1e-5
+
+
+def test_splitk_plans():
+    from audio_flamingo_amd import ops
+
+    assert ops.splitk_plan(8192, 3584, 3584) == 1          # enough 256x256 tiles: one pass
+    assert ops.splitk_plan(1280, 1280, 12032) > 1          # encoder wgrad on the NT kernel: 100 tiles of 128x128
+    assert ops.splitk_plan(1, 3584, 18944) > 1             # decode: down-projection
+    assert ops.splitk_plan(1, 3584, 18944) <= (18944 + 511) // 512
+    assert ops.splitk_plan(8, 3584, 256) == 1              # short reduction: nothing to share
+    assert ops.splitk_plan_256(1280, 1280, 12000) > 1 and ops.splitk_plan_256(5120, 18944, 8192) == 1
