@@ -64,6 +64,9 @@ class Arena:
         # W^T shadows on demand only: set when dgrad runs on the NN kernel (functional.BWD_FORM == "direct"), where most of them
         # are never read; the eager per-bucket refresh after the optimizer then skips them and arena.shadow() rebuilds a stale one
         self.lazy_T_shadows = False
+        # replica state that lives OUTSIDE the trainable buffer (frozen tensors: the encoder's embed_positions table): the data-parallel
+        # engine broadcasts it together with the parameters so that replicas start identical (DDP broadcasts buffers too)
+        self.extra_state: List[torch.Tensor] = []
 
     # ------------------------------------------------------------------ layout
     def new_bucket(self, name: str) -> int:
@@ -97,7 +100,8 @@ class Arena:
             b.data = self.params[b.offset: b.offset + b.numel].view(b.shape)
             b.grad = self.grads[b.offset: b.offset + b.numel].view(b.shape)
         self._bucket_ranges = [(starts[i] or 0, ends[i]) for i in range(nb)]
-        self._bucket_sizes = [sum(1 for b in self.order if b.bucket == i) for i in range(nb)]
+        self._bucket_blocks = [[b for b in self.order if b.bucket == i] for i in range(nb)]
+        self._bucket_sizes = [len(bl) for bl in self._bucket_blocks]
         self._bucket_pending = list(self._bucket_sizes)
 
     def __getitem__(self, key: str) -> Block:
@@ -109,6 +113,25 @@ class Arena:
     def bucket_grads(self, i: int) -> torch.Tensor:
         s, e = self._bucket_ranges[i]
         return self.grads[s:e]
+
+    def bucket_blocks(self, i: int) -> List[Block]:
+        return self._bucket_blocks[i]
+
+    def bucket_touched(self, i: int) -> bool:
+        """has any block of bucket i received a gradient since the last zero_grad()?  (a text-only batch never runs the audio tower:
+        those buckets stay untouched and - as torch does for ``grad is None`` - must not be fed to the optimizer with stale contents)"""
+        return any(not b.fresh for b in self._bucket_blocks[i])
+
+    def zero_unwritten(self, i: int) -> int:
+        """clear the gradient slices of bucket i that no kernel has written since zero_grad() (zero_grad only flips the `fresh`
+        flags, the buffer still holds the previous step's values); -> number of blocks cleared.  Used before a bucket is handed
+        to a collective / optimizer launch that covers the whole slice."""
+        n = 0
+        for b in self._bucket_blocks[i]:
+            if b.fresh:
+                b.grad.zero_()
+                n += 1
+        return n
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self, memset: bool = False):
@@ -209,6 +232,11 @@ class FusedAdamW:
         self.m = torch.zeros_like(self.master)
         self.v = torch.zeros_like(self.master)
         self.t = 0
+        self._synced = (arena.params._version, arena.step_counter)
+        # step-dependent scalars (lr, bias corrections) live on the device: every AdamW launch reads them there, so a captured HIP graph
+        # of the whole training step replays correctly after advance() has refreshed them
+        self.hyper = torch.zeros(4, device=arena.device, dtype=torch.float32) if arena.device.type == "cuda" else None
+        self._in_capture = False  # graphs.GraphedTrainStep: the capture pass records launches only
         # contiguous segments sharing a decay setting
         self.segments = []
         for b in arena.order:
@@ -230,33 +258,88 @@ class FusedAdamW:
             else:
                 segs.append([blk.offset, end, wd])
 
-    def _launch(self, s, e, wd, grad_scale, max_blocks=0):
+    def _launch(self, s, e, wd, grad_scale, max_blocks=0, gate=None):
         a = self.arena
         ops.adamw_step(self.master[s:e], self.m[s:e], self.v[s:e], a.grads[s:e], a.params[s:e], lr=self.lr,
                        beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t,
-                       grad_scale=grad_scale, max_blocks=max_blocks)
+                       grad_scale=grad_scale, max_blocks=max_blocks, gate=gate, hyper=self.hyper)
+
+    def advance(self):
+        """t += 1 and publish (lr, 1 - beta1^t, sqrt(1 - beta2^t)) to the device.  Called by begin_step() / step(); a HIP-graph replay of
+        the step calls it directly (the captured AdamW launches read the device copy)."""
+        if self._in_capture:
+            return
+        self.t += 1
+        if self.hyper is not None:
+            ops.set_f32(self.hyper, [self.lr, 1.0 - self.betas[0] ** self.t, (1.0 - self.betas[1] ** self.t) ** 0.5])
+
+    # ------------------------------------------------------------------ master <-> working copy
+    def sync_master(self):
+        """re-read the fp32 master from the bf16 parameters (call after anything that rewrote them: load_state_dict, broadcast)"""
+        self.master.copy_(self.arena.params)
+        self._mark_synced()
+
+    def _mark_synced(self):
+        self._synced = (self.arena.params._version, self.arena.step_counter)
+
+    def _check_master(self):
+        """parameters rewritten behind the optimizer's back (model.load_state_dict, a broadcast, an in-place init) would be overwritten
+        by `old master + update` on the next step: detect it (tensor version / arena step counter) and re-read the master first."""
+        if self._synced != (self.arena.params._version, self.arena.step_counter):
+            self.sync_master()
+
+    def _runs(self, blocks):
+        runs = []
+        for b in blocks:
+            end = b.offset + (b.numel + ALIGN - 1) // ALIGN * ALIGN
+            wd = self.weight_decay if b.decay else 0.0
+            if runs and runs[-1][2] == wd and runs[-1][1] == b.offset:
+                runs[-1][1] = end
+            else:
+                runs.append([b.offset, end, wd])
+        return runs
 
     def begin_step(self):
         """overlapped mode: advance the step count once, then step_bucket() per bucket as its gradients complete"""
-        self.t += 1
+        self._check_master()
+        self.advance()
 
-    def step_bucket(self, i: int, grad_scale: float = 1.0, max_blocks: int = 0):
-        for s, e, wd in self.bucket_segments[i]:
-            self._launch(s, e, wd, grad_scale, max_blocks)
+    def step_bucket(self, i: int, grad_scale: float = 1.0, max_blocks: int = 0, gate=None, written_only: bool = False):
+        """AdamW on bucket i.  gate: device int32 - the launches do nothing when it reads 0 (data parallel: "did ANY rank touch this
+        bucket", known only on the device).  written_only: cover just the blocks written since zero_grad() (torch skips ``grad is None``)."""
+        if written_only:
+            segs = self._runs([b for b in self.arena.bucket_blocks(i) if not b.fresh])
+        else:
+            segs = self.bucket_segments[i]
+        for s, e, wd in segs:
+            self._launch(s, e, wd, grad_scale, max_blocks, gate)
 
     def end_step(self):
         self.arena.step_counter += 1
+        self._mark_synced()
         for b in self.arena.order:  # shadows were refreshed bucket by bucket (lazy W^T shadows stay stale until used)
             if b.shadow_kind is not None and not (self.arena.lazy_T_shadows and b.shadow_kind == "T"):
                 b.shadow_version = self.arena._version_of(b)
 
-    def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True):
-        self.t += 1
+    def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True, gates=None):
+        """one optimizer step over every block that received a gradient since zero_grad() (blocks whose backward did not run this
+        step - e.g. the audio tower on a text-only batch - are skipped, as torch.optim skips ``grad is None``).
+        gates (data parallel, from DataParallelEngine.finish()): device int32 [n_buckets], 1 where any rank touched the bucket -
+        every rank then launches every bucket and the device decides."""
+        self._check_master()
+        self.advance()
         a = self.arena
         a.join_streams()
-        for s, e, wd in self.segments:
-            self._launch(s, e, wd, grad_scale)
+        if gates is not None:
+            for i in range(len(a.bucket_names)):
+                for s, e, wd in self.bucket_segments[i]:
+                    self._launch(s, e, wd, grad_scale, gate=gates[i:i + 1])
+        else:
+            segs = self.segments if all(not b.fresh for b in a.order) else self._runs([b for b in a.order if not b.fresh])
+            for s, e, wd in segs:
+                self._launch(s, e, wd, grad_scale)
         a.step_counter += 1
+        self._mark_synced()
         if refresh_shadows:
             a.refresh_shadows(force=True)
 

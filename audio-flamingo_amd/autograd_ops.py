@@ -165,13 +165,7 @@ class _XAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, krange, B, Sq, Sk, H, D, scale, Hkv=None):
         Hkv = Hkv or H
-        sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
-        vt = ops.transpose_heads(v, B, Sk, Hkv, D, v.stride(0), skp)
-        o = torch.empty((B * Sq, H * D), device=q.device, dtype=BF16)
-        lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
-        _lib.call("afk_xattn_fwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
-                  vt.data_ptr(), o.data_ptr(), Sq * H * D, D, H * D, lse.data_ptr(), 0, _p(krange), B, H, Hkv, Sq, Sk, sqp, skp, D,
-                  float(scale), _stream())
+        o, lse = ops.xattn_fwd(q, k, v, krange, B, Sq, Sk, H, Hkv, D, scale)
         ctx.save_for_backward(q, k, v, o, lse, krange)
         ctx.meta = (B, Sq, Sk, H, D, scale, Hkv)
         return o
@@ -182,20 +176,11 @@ class _XAttn(torch.autograd.Function):
         B, Sq, Sk, H, D, scale, Hkv = ctx.meta
         do = do.contiguous()
         dev = q.device
-        sqp, skp = ops.pad64(Sq), ops.pad64(Sk)
         ldo, ldk = H * D, Hkv * D
-        delta = torch.empty((B, H, Sq), device=dev, dtype=torch.float32)
-        _lib.call("afk_attn_delta", o.data_ptr(), Sq * ldo, D, ldo, do.data_ptr(), Sq * ldo, D, ldo, delta.data_ptr(), B, H, Sq, D, _stream())
-        qt = ops.transpose_heads(q, B, Sq, H, D, q.stride(0), sqp)
-        kt = ops.transpose_heads(k, B, Sk, Hkv, D, k.stride(0), skp)
-        dot = ops.transpose_heads(do, B, Sq, H, D, ldo, sqp)
         dq = torch.empty((B * Sq, ldo), device=dev, dtype=BF16)
         dk = torch.empty((B * Sk, ldk), device=dev, dtype=BF16)
         dv = torch.empty((B * Sk, ldk), device=dev, dtype=BF16)
-        _lib.call("afk_xattn_bwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
-                  v.data_ptr(), Sk * v.stride(0), D, v.stride(0), do.data_ptr(), Sq * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(),
-                  dot.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Sq * ldo, D, ldo, dk.data_ptr(), Sk * ldk, D, ldk,
-                  dv.data_ptr(), Sk * ldk, D, ldk, 0, _p(krange), B, H, Hkv, Sq, Sk, sqp, skp, D, float(scale), _stream())
+        ops.xattn_bwd(q, k, v, o, do, lse, krange, B, Sq, Sk, H, Hkv, D, scale, dq, dk, dv)
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 

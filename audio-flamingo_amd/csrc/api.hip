@@ -13,4 +13,20 @@ int afk_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* afk_last_error(void) { return g_err; }
+
+// launch counters per kernel family (tests assert WHICH kernel served a shape: include/afk.h AFK_CNT_*)
+#include <atomic>
+static std::atomic<int64_t> g_counts[AFK_CNT_MAX];
+void afk_count(int id) {
+    if (id >= 0 && id < AFK_CNT_MAX) g_counts[id].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int afk_kernel_counts(int64_t* host_out, int n) {
+    AFK_REQUIRE(host_out && n > 0, "afk_kernel_counts: bad args");
+    for (int i = 0; i < n; ++i) host_out[i] = i < AFK_CNT_MAX ? g_counts[i].load(std::memory_order_relaxed) : 0;
+    return AFK_OK;
+}
+extern "C" int afk_kernel_counts_reset(void) {
+    for (int i = 0; i < AFK_CNT_MAX; ++i) g_counts[i].store(0, std::memory_order_relaxed);
+    return AFK_OK;
+}
 extern "C" int afk_version(void) { return 1; }

@@ -365,6 +365,7 @@ extern "C" int afk_attn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
                             const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale, int causal,
                             void* stream) {
     AFK_REQUIRE(Q && K && Vt && O, "afk_attn_fwd: null pointer");
+    afk_count(AFK_CNT_ATTN1_FWD);
     if (int e = check_common("afk_attn_fwd", B, Hq, Hkv, S, Spad, D)) return e;
     AFK_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 && o_rs % 4 == 0 && o_hs % 4 == 0,
                 "afk_attn_fwd: strides must keep 16-byte alignment");
@@ -407,6 +408,7 @@ extern "C" int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
                             int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad, int D, float scale,
                             int causal, void* stream) {
     AFK_REQUIRE(Q && K && V && dO && Qt && Kt && dOt && LSE && delta && dQ && dK && dV, "afk_attn_bwd: null pointer");
+    afk_count(AFK_CNT_ATTN1_BWD);
     if (int e = check_common("afk_attn_bwd", B, Hq, Hkv, S, Spad, D)) return e;
     AttnArgs p = {};
     p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
@@ -443,6 +445,7 @@ extern "C" int afk_xattn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
                              const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk, int Sqpad, int Skpad,
                              int D, float scale, void* stream) {
     AFK_REQUIRE(Q && K && Vt && O && LSE, "afk_xattn_fwd: null pointer");
+    afk_count(AFK_CNT_XATTN_FWD);
     if (int e = check_common("afk_xattn_fwd", B, Hq, Hkv, Sq, Sqpad, D)) return e;
     if (int e = check_common("afk_xattn_fwd", B, Hq, Hkv, Sk, Skpad, D)) return e;
     AttnArgs p = {};
@@ -469,6 +472,7 @@ extern "C" int afk_xattn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
                              int64_t dv_rs, const int* kv_len, const int* krange, int B, int Hq, int Hkv, int Sq, int Sk,
                              int Sqpad, int Skpad, int D, float scale, void* stream) {
     AFK_REQUIRE(Q && K && V && dO && Qt && Kt && dOt && LSE && delta && dQ && dK && dV, "afk_xattn_bwd: null pointer");
+    afk_count(AFK_CNT_XATTN_BWD);
     if (int e = check_common("afk_xattn_bwd", B, Hq, Hkv, Sq, Sqpad, D)) return e;
     if (int e = check_common("afk_xattn_bwd", B, Hq, Hkv, Sk, Skpad, D)) return e;
     AttnArgs p = {};

@@ -730,6 +730,7 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     dim3 grid((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
+    afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
     if (D == 128) {
         constexpr int L = 4 * Tile<128>::BYTES;
         static int once = set_lds(attn_fwd_lds_kernel<128>, L);
@@ -796,6 +797,8 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
         pk.dk_hs = pk.dv_hs = D;
         pk.dk_rs = pk.dv_rs = (int64_t)Hq * D;
     }
+    afk_count(D == 128 ? AFK_CNT_ATTN2_BWD_D128 : AFK_CNT_ATTN2_BWD_D64);
+    if (split) afk_count(AFK_CNT_GQA_REDUCE);
     dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)(split ? Hq : Hkv), (unsigned)B);
     dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
     if (D == 128) {

@@ -23,6 +23,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // error string storage (thread-local, read back through afk_last_error())
 int afk_set_error(int code, const char* fmt, ...);
+// launch counter of a kernel family (AFK_CNT_* in include/afk.h), read back through afk_kernel_counts()
+void afk_count(int id);
 
 #define AFK_REQUIRE(cond, ...)                                   \
     do {                                                         \

@@ -450,38 +450,42 @@ __global__ __launch_bounds__(256) void embed_scatter_fwd_kernel(const int64_t* _
     }
 }
 
-__device__ __forceinline__ void atomic_add_bf16x2(bf16* addr, float a, float b) {
-    unsigned int* w = (unsigned int*)addr;
-    unsigned int old = *w, assumed;
-    do {
-        assumed = old;
-        bf16x2 cur = *(bf16x2*)&assumed;
-        bf16x2 nv;
-        nv[0] = (bf16)((float)cur[0] + a);
-        nv[1] = (bf16)((float)cur[1] + b);
-        old = atomicCAS(w, assumed, *(unsigned int*)&nv);
-    } while (old != assumed);
-}
-
-// backward: text rows scatter-add into d_embed (token ids may repeat -> CAS adds on bf16 pairs);
-// placeholder rows are gathered into d_audio[src].
+// backward: placeholder rows are gathered into d_audio[src]; text rows are summed into d_embed[token id].
+// Token ids repeat, so this is a segmented reduction: `perm` lists the rows sorted (stably) by token id (integer index plumbing done by
+// the caller); the thread that sits on the FIRST row of an id's run sums the whole run in fp32, in row order, and rounds once into
+// d_embed (+= what is already there: the caller clears the slice at the first backward of a step).  Fixed order, one rounding:
+// bit-deterministic, and as accurate as torch's fp32-accumulating embedding backward (no atomics).
 __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const int64_t* __restrict__ ids, const int* __restrict__ src,
                                                                 const bf16* __restrict__ dout, bf16* __restrict__ d_embed,
-                                                                bf16* __restrict__ d_audio, int64_t n, int H) {
+                                                                bf16* __restrict__ d_audio, const int* __restrict__ perm, int64_t n, int H) {
     const int vpr = H >> 3;
     const int64_t total = n * vpr;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int v = (int)(i % vpr);
-        const int64_t r = i / vpr;
+        const int64_t j = i / vpr;
+        const int64_t r = perm ? perm[j] : j;
         const int s = src ? src[r] : -1;
-        const bf16x8 d = *(const bf16x8*)(dout + r * H + 8 * v);
         if (s >= 0) {
-            if (d_audio) *(bf16x8*)(d_audio + (int64_t)s * H + 8 * v) = d;
-        } else if (d_embed) {
-            bf16* p = d_embed + ids[r] * H + 8 * v;
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) atomic_add_bf16x2(p + e, (float)d[e], (float)d[e + 1]);
+            if (d_audio) *(bf16x8*)(d_audio + (int64_t)s * H + 8 * v) = *(const bf16x8*)(dout + r * H + 8 * v);
+            continue;
         }
+        if (!d_embed) continue;
+        const int64_t id = ids[r];
+        if (j > 0 && ids[perm[j - 1]] == id) continue;  // not the head of this id's run
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t k = j; k < n; ++k) {
+            const int64_t rk = perm[k];
+            if (ids[rk] != id) break;
+            const bf16x8 d = *(const bf16x8*)(dout + rk * H + 8 * v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+        }
+        bf16* p = d_embed + id * H + 8 * v;
+        const bf16x8 old = *(const bf16x8*)p;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)old[e] + acc[e]);
+        *(bf16x8*)p = o;
     }
 }
 
@@ -491,7 +495,13 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const int64_t* _
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const bf16* __restrict__ g, bf16* __restrict__ p, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    float grad_scale) {
+                                                    float grad_scale, const int* __restrict__ gate, const float* __restrict__ hyper) {
+    if (gate != nullptr && *gate == 0) return;  // data parallel: no rank produced a gradient for this bucket this step
+    if (hyper != nullptr) {  // step-dependent scalars from device memory: a captured HIP graph replays with fresh values
+        lr = hyper[0];
+        bc1 = hyper[1];
+        bc2_sqrt = hyper[2];
+    }
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         f32x4 w = *(const f32x4*)(master + 4 * i), mm = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
@@ -838,16 +848,18 @@ extern "C" int afk_embed_scatter_fwd(const int64_t* ids, const int* src, const v
 }
 
 extern "C" int afk_embed_scatter_bwd(const int64_t* ids, const int* src, const void* dout, void* d_embed, void* d_audio,
-                                     int64_t n, int H, void* stream) {
+                                     const int* perm, int64_t n, int H, void* stream) {
     AFK_REQUIRE(ids && dout && n > 0 && H % 8 == 0, "afk_embed_scatter_bwd: bad args");
+    AFK_REQUIRE(perm || !d_embed, "afk_embed_scatter_bwd: d_embed needs perm (rows sorted by token id)");
     hipLaunchKernelGGL(embed_scatter_bwd_kernel, dim3(ew_grid(n * (H / 8), 256)), dim3(256), 0, ST, ids, src,
-                       (const bf16*)dout, (bf16*)d_embed, (bf16*)d_audio, n, H);
+                       (const bf16*)dout, (bf16*)d_embed, (bf16*)d_audio, perm, n, H);
     AFK_LAUNCH_CHECK("afk_embed_scatter_bwd");
     return AFK_OK;
 }
 
 extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream) {
+                              float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, const int* gate,
+                              const float* hyper, void* stream) {
     AFK_REQUIRE(master && m && v && grad && param && n > 0 && step >= 1, "afk_adamw_step: bad args");
     AFK_REQUIRE(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) &&
                     ((uintptr_t)grad % 8 == 0) && ((uintptr_t)param % 8 == 0),
@@ -860,8 +872,24 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
     int grid = ew_grid(afk_cdiv(n, 4), 256);
     if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
-                       (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+                       (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gate, hyper);
     AFK_LAUNCH_CHECK("afk_adamw_step");
+    return AFK_OK;
+}
+
+namespace {
+__global__ void set_f32_kernel(float* dst, int n, float a, float b, float c, float d) {
+    const float v[4] = {a, b, c, d};
+    if (threadIdx.x < n) dst[threadIdx.x] = v[threadIdx.x];
+}
+}  // namespace
+
+// dst[0..n) = (a, b, c, d)[0..n): step-dependent scalars (learning rate, Adam bias corrections) written by a kernel whose arguments
+// travel with the launch - no pinned staging buffer the host could overwrite while an earlier copy is still queued
+extern "C" int afk_set_f32(float* dst, int n, float a, float b, float c, float d, void* stream) {
+    AFK_REQUIRE(dst && n >= 1 && n <= 4, "afk_set_f32: 1..4 values");
+    hipLaunchKernelGGL(set_f32_kernel, dim3(1), dim3(64), 0, ST, dst, n, a, b, c, d);
+    AFK_LAUNCH_CHECK("afk_set_f32");
     return AFK_OK;
 }
 

@@ -222,7 +222,8 @@ struct ProfState {
     std::vector<Rec> recs;
 };
 ProfState g_prof;
-int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256
+int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256 (8-wave ping-pong), 3 force 256x256 (4-wave, 128x128 per wave)
+int g_256_impl = 2; // which 256x256 NT kernel "auto" uses: 2 = 8-wave ping-pong (gemm256.hip), 3 = 4-wave (gemm256w4.hip); env AFK_GEMM256=w4|pp
 int g_gm = 0;       // rasterization group height override (0 = default 8)
 int g_wide = 1;     // 16-byte epilogue form allowed (afk_gemm_set_variant bit 4 clears it: A/B experiments)
 
@@ -242,7 +243,7 @@ extern "C" int afk_gemm_set_variant(int v) {
     g_gm = (v >> 8) & 255;
     g_wide = (v & 16) ? 0 : 1;
     v &= 15;
-    AFK_REQUIRE(v >= 0 && v <= 2, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel");
+    AFK_REQUIRE(v >= 0 && v <= 3, "afk_gemm_set_variant: 0 auto, 1 = 128x128 kernel, 2 = 256x256 8-wave kernel, 3 = 256x256 4-wave kernel");
     g_variant = v;
     return AFK_OK;
 }
@@ -329,7 +330,12 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     }
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant == 2 || (g_variant == 0 && tiles256 >= 192))));
+    const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
+    static const int env_impl = [] {
+        const char* e = getenv("AFK_GEMM256");
+        return (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : 0;
+    }();
+    const bool w4 = use256 && !trans_b && (g_variant == 3 || (g_variant == 0 && (env_impl ? env_impl : g_256_impl) == 3));
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -353,6 +359,8 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
             g_prof.recs.push_back({M, N, K, trans_b ? (trans_a ? 4 : 3) : (use256 ? 2 : 1)});
         }
     }
+    afk_count(gemv ? AFK_CNT_GEMV : trans_b ? (trans_a ? AFK_CNT_GEMM_TN256 : AFK_CNT_GEMM_NN256) : use256 ? AFK_CNT_GEMM_NT256 : AFK_CNT_GEMM_NT128);
+    if (splits > 1) afk_count(AFK_CNT_GEMM_SPLITK);
     if (prof) hipEventRecord(e0, st);
     if (gemv) {
         const dim3 grid((unsigned)afk_cdiv(N, 32), (unsigned)splits);
@@ -370,7 +378,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
         }
     } else if (use256) {
-        if (int e = afk_launch_gemm256(p, st)) return e;
+        if (int e = w4 ? afk_launch_gemm256w4(p, st) : afk_launch_gemm256(p, st)) return e;
     } else {
         hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg, (unsigned)splits), dim3(256), NSTAGE * STAGE_BYTES, st, p);
         if (splits > 1) {

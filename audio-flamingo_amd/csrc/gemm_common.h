@@ -162,5 +162,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
+// 256x256 four-wave kernel, 128x128 per wave, accumulators in AGPRs (gemm256w4.hip)
+int afk_launch_gemm256w4(const GemmArgs& p, hipStream_t st);
 // transposed-operand variants (gemm256t.hip): NN (trans_a = 0) and TN (trans_a = 1); B is reduction-major in both
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st);

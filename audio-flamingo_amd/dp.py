@@ -11,6 +11,15 @@ Backward keeps running on the compute stream, so the exchange of layer i overlap
 Buckets are whole layers (466 MB for a decoder layer) rather than 25 MiB: xGMI is a point-to-point mesh and large
 messages amortise RCCL's per-collective launch across all 7 links.  Averaging is folded into the
 optimizer (grad_scale = 1/world), so the reduction itself is a pure sum.
+
+Collective order is rank-independent by construction.  Backward completes the buckets in exactly reverse layout order
+(head, dec27 .. dec0, embed, enc_out, enc31 .. enc0, stem); a rank whose batch skipped part of the model (a text-only
+batch never runs the audio tower) has reduced a PREFIX of that sequence when backward ends, and ``finish()`` issues the
+rest in the same reverse order with the unwritten gradient slices cleared first - so every rank issues the same
+collectives in the same order with the same sizes (DDP raises for this case unless find_unused_parameters is set,
+TORCH/nn/parallel/distributed.py:1442 ff.).  One more tiny collective closes the step: a MAX over per-bucket "touched"
+flags; the optimizer launches are gated on it ON THE DEVICE, so a bucket that no rank touched keeps its parameters and
+moments exactly as torch.optim does for ``grad is None`` (DDP's find_unused_parameters bitmap, distributed.py:1533 ff.).
 """
 from __future__ import annotations
 
@@ -31,10 +40,16 @@ class DataParallelEngine:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.cuda = arena.grads.is_cuda
+        self.backend = dist.get_backend(process_group)
+        # device buffers over a host-side backend (gloo): stage through the host.  Only for correctness runs of the multi-rank path on a
+        # box without one GPU per rank (tests/test_dp_gpu.py: two ranks sharing one MI355X); the production backend is "nccl" = RCCL.
+        self.staged = self.cuda and self.backend != "nccl"
         self.overlap = overlap and self.cuda
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
         self._works: List = []
         self._done = [False] * len(arena.bucket_names)
+        self.issued: List[int] = []  # bucket indices in the order their collectives were issued this step (tests compare ranks)
+        self.bucket_gate: Optional[torch.Tensor] = None  # device int32 [n_buckets] after finish(): 1 where ANY rank touched the bucket
         self.enabled = True  # set False inside a no_sync() region (gradient accumulation micro-steps)
         arena.on_bucket_ready = self._on_bucket_ready
         self._native_bf16 = True
@@ -48,23 +63,47 @@ class DataParallelEngine:
 
     # ------------------------------------------------------------------ parameter broadcast (DDP ctor, distributed.py:1012)
     def broadcast_parameters(self, src: int = 0):
+        """rank `src`'s replica state to every rank: the parameter arena and the frozen tensors beside it (arena.extra_state)"""
         chunk = 1 << 28
-        p = self.arena.params
-        for s in range(0, p.numel(), chunk):
-            dist.broadcast(p[s: s + chunk], src=src, group=self.pg)
+        for p in [self.arena.params] + [t.view(-1) for t in self.arena.extra_state]:
+            for s in range(0, p.numel(), chunk):
+                if self.staged:
+                    h = p[s: s + chunk].float().cpu()
+                    dist.broadcast(h, src=src, group=self.pg)
+                    p[s: s + chunk].copy_(h.to(p.device))
+                else:
+                    dist.broadcast(p[s: s + chunk], src=src, group=self.pg)
         self.arena.step_counter += 1
 
     # ------------------------------------------------------------------ bucket exchange
     def begin_backward(self):
         self._done = [False] * len(self.arena.bucket_names)
         self._works = []
+        self.issued = []
+        self.bucket_gate = None
         self.arena.begin_backward()
+
+    def allreduce_sum_(self, buf: torch.Tensor):
+        """sum-all-reduce of a device slice, ordered on the CURRENT stream (RCCL), or staged through the host (gloo: synchronous)"""
+        if not self.staged:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            return
+        for ev in self.arena.ready_events():
+            ev.synchronize()
+        torch.cuda.current_stream().synchronize()
+        f = buf.float().cpu()
+        dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg)
+        buf.copy_(f.to(buf.device))
 
     def _reduce(self, i: int):
         buf = self.arena.bucket_grads(i)
         if buf.numel() == 0:
             return
-        if self.cuda:
+        self.arena.zero_unwritten(i)  # zero_grad() only flips flags: slices nobody wrote this step still hold the last step's values
+        self.issued.append(i)
+        if self.staged:
+            self.allreduce_sum_(buf)
+        elif self.cuda:
             evs = self.arena.ready_events()
             with torch.cuda.stream(self.comm_stream):
                 for ev in evs:
@@ -89,16 +128,36 @@ class DataParallelEngine:
         """after loss.backward(): exchange whatever is still pending, then order the compute stream after the comm stream"""
         if not self.enabled:
             return
-        for i in range(len(self._done)):
+        touched = [int(self.arena.bucket_touched(i)) for i in range(len(self._done))]
+        for i in reversed(range(len(self._done))):  # REVERSE layout order = the order backward would have produced them (see module doc)
             if not self._done[i] or (self.cuda and not self.overlap):
                 self._done[i] = True
                 self._reduce(i)
+        self.bucket_gate = self._exchange_touched(touched)
         for w in self._works:
             w.wait()  # on the nccl backend this makes the CURRENT stream wait; it does not block the host
         self._works = []
         self.arena.join_streams()
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        for b in self.arena.order:  # every slice now holds a reduced gradient (zeros where nobody contributed)
+            b.fresh = False
+
+    def _exchange_touched(self, touched) -> torch.Tensor:
+        """MAX over ranks of the per-bucket "a gradient was produced here" flags; always the LAST collective of a step"""
+        if self.staged:
+            t = torch.tensor(touched, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            t = t.to(self.arena.device)
+        elif self.cuda:
+            with torch.cuda.stream(self.comm_stream):
+                t = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
+                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+            t.record_stream(torch.cuda.current_stream())
+        else:
+            t = torch.tensor(touched, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+        return t
 
     @property
     def grad_scale(self) -> float:
@@ -139,27 +198,73 @@ class BackwardOverlap:
     def begin_step(self):
         self.opt.begin_step()
         self._done = [False] * len(self.arena.bucket_names)
+        if self.engine is not None:
+            self.engine.issued = []
         self.arena.begin_backward()
         self.arena.on_bucket_ready = self._ready
 
-    def _ready(self, i: int):
+    def _multi(self) -> bool:
+        return self.engine is not None and self.engine.world > 1
+
+    def _ready(self, i: int, gate=None, written_only: bool = False):
         if self._done[i]:
             return
         self._done[i] = True
+        if self._multi():
+            self.arena.zero_unwritten(i)  # on the compute stream, ahead of the events below
         evs = self.arena.ready_events()
         with torch.cuda.stream(self.side):
             for ev in evs:
                 self.side.wait_event(ev)
-            if self.engine is not None and self.engine.world > 1:
+            if self._multi():
                 buf = self.arena.bucket_grads(i)
                 if buf.numel():
-                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.engine.pg)  # ordered on the side stream
-            self.opt.step_bucket(i, self.grad_scale, self.thin_blocks)
+                    self.engine.issued.append(i)
+                    self.engine.allreduce_sum_(buf)  # ordered on the side stream
+            self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
             self.arena.refresh_bucket_shadows(i)
 
     def finish(self):
-        for i in range(len(self._done)):
-            self._ready(i)
+        """buckets backward never completed (their part of the model did not run this step, e.g. the audio tower on a text-only batch):
+        single process -> the optimizer skips what received no gradient (torch: grad is None); data parallel -> they are reduced in the
+        same reverse order every rank uses, and their AdamW launches are gated on the all-rank "touched" flags (dp.py module doc)."""
+        n = len(self._done)
+        pending = [i for i in reversed(range(n)) if not self._done[i]]
+        if self._multi():
+            eng = self.engine
+            touched = [int(self.arena.bucket_touched(i)) for i in range(n)]
+            deferred = []
+            for i in pending:  # reductions first (same order on every rank), flags after them, gated optimizer launches last
+                self._done[i] = True
+                self.arena.zero_unwritten(i)
+                evs = self.arena.ready_events()
+                with torch.cuda.stream(self.side):
+                    for ev in evs:
+                        self.side.wait_event(ev)
+                    buf = self.arena.bucket_grads(i)
+                    if buf.numel():
+                        eng.issued.append(i)
+                        eng.allreduce_sum_(buf)
+                deferred.append(i)
+            with torch.cuda.stream(self.side):
+                if eng.staged:
+                    gate = torch.tensor(touched, dtype=torch.int32)
+                    dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
+                    gate = gate.to(self.arena.device)
+                else:
+                    gate = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
+                    dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
+                for i in deferred:
+                    self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate[i:i + 1])
+                    self.arena.refresh_bucket_shadows(i)
+            gate.record_stream(torch.cuda.current_stream())
+            eng.bucket_gate = gate
+        else:
+            for i in pending:
+                if self.arena.bucket_touched(i):
+                    self._ready(i, written_only=True)
+                else:
+                    self._done[i] = True
         self.arena.join_streams()
         torch.cuda.current_stream().wait_stream(self.side)
         self.opt.end_step()

@@ -314,25 +314,28 @@ class DecoderLayerFn(torch.autograd.Function):
     """RMSNorm -> GQA causal attention (RoPE) -> +res ; RMSNorm -> SwiGLU -> +res  (Qwen2DecoderLayer.forward, :269-298)"""
 
     @staticmethod
-    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len):
+    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None):
         A = lambda k: arena[pfx + k]
         h, rstd1 = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
         qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
         ops.rope_(qkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos)
-        o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+        if krange is not None:  # left-padded rows (the reference processor's default): per-query key intervals [lo_b, min(i + 1, hi_b))
+            o, lse = ops.attn_interval_fwd(qkv, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
+        else:
+            o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
         x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
         h2, rstd2 = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
         gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
         a = ops.silu_mul_fwd(gu)
         x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
         # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
-        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a)
+        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange)
         ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)
         return x3
 
     @staticmethod
     def backward(ctx, dx3):
-        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a = ctx.saved_tensors
+        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange = ctx.saved_tensors
         arena, pfx, B, S, Hq, Hkv, D = ctx.meta
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
@@ -351,7 +354,10 @@ class DecoderLayerFn(torch.autograd.Function):
         arena.grad_written(nw)
         del dh2
         do = linear_bwd(arena, dx2, o, pfx + "self_attn.o_proj.weight")
-        dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+        if krange is not None:
+            dqkv = ops.attn_interval_bwd(qkv, o, do, lse, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
+        else:
+            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
         del do
         ops.rope_(dqkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos, backward=True)
         dh = linear_bwd(arena, dqkv, h, pfx + "self_attn.qkv.weight", bkey=pfx + "self_attn.qkv.bias")
@@ -359,7 +365,7 @@ class DecoderLayerFn(torch.autograd.Function):
         nw = A("input_layernorm.weight")
         dx = ops.rmsnorm_bwd(x, nw.data, dh, rstd1, nw.grad, dx_add=dx2, accumulate=not nw.fresh)
         arena.grad_written(nw)
-        return (dx,) + (None,) * 13
+        return (dx,) + (None,) * 14
 
 
 class RMSNormFn(torch.autograd.Function):
@@ -411,7 +417,15 @@ class LMHeadLossFn(torch.autograd.Function):
     CHUNK = 4096  # 16x14 = 224 tiles of 256x256 for the dgrad GEMM: enough to fill the chip with the fast kernel
 
     @staticmethod
-    def forward(ctx, x, anchor, arena, wkey, shift_labels, denom):
+    def forward(ctx, x, anchor, arena, wkey, shift_labels, denom, rows=None):
+        # rows (int64, ascending, on the device; None = every row): the positions whose shifted label is not -100.  Only they
+        # contribute to the loss and to any gradient (the CE gradient of an ignored row is exactly zero), so the lm_head GEMM, the CE
+        # kernel and both backward GEMMs run on the gathered rows alone: identical loss and gradients, 1/4 of the work on the
+        # 256-answer-token batches of the benchmark.  The reference computes all B*S rows (modeling_audioflamingo3.py:625-633).
+        M_all = x.shape[0]
+        if rows is not None:
+            x = ops.gather_rows(x, rows)
+            shift_labels = shift_labels.index_select(0, rows)
         M, H = x.shape
         blk = arena[wkey]
         V = blk.shape[0]
@@ -450,20 +464,22 @@ class LMHeadLossFn(torch.autograd.Function):
         loss = torch.empty((), device=dev, dtype=torch.float32)
         ops.loss_reduce(row_loss, denom, loss)
         if need_grad:
-            ctx.save_for_backward(dx, gw_tmp)
-            ctx.meta = (arena, wkey, gw_tmp is blk.grad)
+            ctx.save_for_backward(dx, gw_tmp, rows)
+            ctx.meta = (arena, wkey, gw_tmp is blk.grad, M_all)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        dx, gw_tmp = ctx.saved_tensors
-        arena, wkey, inplace = ctx.meta
+        dx, gw_tmp, rows = ctx.saved_tensors
+        arena, wkey, inplace, M_all = ctx.meta
         blk = arena[wkey]
         g32 = g.reshape(1).float()
         ops.scale_add_(dx, dx, g32, accumulate=False)
+        if rows is not None:
+            dx = ops.scatter_rows(dx, rows, M_all)
         if inplace:
             ops.scale_add_(blk.grad, blk.grad, g32, accumulate=False)
         else:
             ops.scale_add_(gw_tmp, blk.grad, g32, accumulate=True)
         arena.grad_written(blk)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None

@@ -15,12 +15,14 @@ one call:   audio_flamingo_amd.hf_plugin.register();  model.set_attn_implementat
   * everything else (bool mask - left/right padding, causal+padding -, Q != K decode steps, other head dims)
                                          -> interval kernels (afk_xattn_*): every query row attends a contiguous key interval
                                             [lo, hi); the mask is converted to those intervals on device and VERIFIED to be
-                                            interval-shaped (one host sync per distinct mask tensor, cached)
+                                            interval-shaped (one host sync per mask tensor OBJECT: the layers of one forward
+                                            share the object, a new forward builds a new one)
 GQA is native (no repeat_kv).  Dropout must be 0 (the AF3 configs: attention_dropout = 0.0).  bf16 only.  There is no fallback
 to torch SDPA: anything unsupported raises.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -28,16 +30,14 @@ import torch
 from . import autograd_ops as A
 
 NAME = "afk_mi355x"
-_mask_cache: dict = {}
+# (weakref to the mask tensor object, its _version, (B, Q, K), intervals).  The key is the tensor OBJECT, never its address: the caching
+# allocator hands the next forward's mask the same data_ptr, so an address key would serve a stale batch's intervals.
+_mask_cache: list = []
 calls = {"lds": 0, "interval": 0}  # which kernel family served the calls (tests assert the plugin really ran)
 
 
 def _intervals(mask: torch.Tensor) -> torch.Tensor:
     """bool [B,1,Q,K] (True = visible) -> int32 [B,Q,2] key interval per query row; raises if a row is not one interval"""
-    key = (mask.data_ptr(), mask._version, tuple(mask.shape))
-    hit = _mask_cache.get(key)
-    if hit is not None:
-        return hit
     m = mask[:, 0]
     K = m.shape[-1]
     cnt = m.sum(-1, dtype=torch.int32)
@@ -47,10 +47,18 @@ def _intervals(mask: torch.Tensor) -> torch.Tensor:
     if not bool(ok):
         raise NotImplementedError("afk attention plugin: attention_mask rows must each expose ONE contiguous key interval "
                                   "(causal, bidirectional, left/right padding); got a mask with holes")
-    kr = torch.stack([lo, lo + cnt], dim=-1).contiguous()
-    if len(_mask_cache) > 64:
-        _mask_cache.clear()
-    _mask_cache[key] = kr
+    return torch.stack([lo, lo + cnt], dim=-1).contiguous()
+
+
+def _intervals_of(attention_mask: torch.Tensor, B: int, Q: int, K: int) -> torch.Tensor:
+    """intervals of the mask tensor the model hands to every layer of ONE forward (same object, same version -> same contents)"""
+    shape = (B, Q, K)
+    for ref, ver, shp, kr in _mask_cache:
+        if ref() is attention_mask and ver == attention_mask._version and shp == shape:
+            return kr
+    kr = _intervals(attention_mask[..., :K].expand(B, 1, Q, K))
+    _mask_cache[:] = [e for e in _mask_cache if e[0]() is not None][-3:]
+    _mask_cache.append((weakref.ref(attention_mask), attention_mask._version, shape, kr))
     return kr
 
 
@@ -81,7 +89,7 @@ def afk_attention(module, query, key, value, attention_mask: Optional[torch.Tens
         if attention_mask is not None:
             if attention_mask.dtype != torch.bool:
                 raise NotImplementedError("afk attention plugin: only boolean masks (the sdpa mask interface) are supported")
-            krange = _intervals(attention_mask[..., :K].expand(B, 1, Q, K))
+            krange = _intervals_of(attention_mask, B, Q, K)
         elif causal:
             i = torch.arange(Q, device=query.device, dtype=torch.int32) + (K - Q)
             krange = torch.stack([torch.zeros_like(i), i + 1], -1).expand(B, Q, 2).contiguous()

@@ -9,9 +9,12 @@ fused arena blocks (q|k|v and gate|up are stored contiguously so that each is on
 ``load_state_dict`` from an oracle checkpoint and ``state_dict`` round-trip unchanged.
 
 Deviations from the oracle surface (documented, not silent):
-  * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``;
-  * ``generate`` is greedy (do_sample=False) and recomputes the prefix each step (KV-cache decode is a next-round row);
-  * decoder padding must be on the right (``attention_mask`` of the form 1..10..0); left padding raises.
+  * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``; lm_head and the
+    loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
+  * ``generate`` is greedy (do_sample=False): prefill fills a KV cache, each new token is one HIP-graph replay;
+  * ``attention_mask`` rows must be one contiguous run of ones (left padding - the reference processor's default -, right padding, or
+    both); masks with holes raise.  Hidden states of padded positions are zeros-attended garbage in both implementations and are
+    never compared.
 """
 from __future__ import annotations
 
@@ -148,6 +151,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         pos_prm = nn.Parameter(torch.zeros((self.max_pos, E), device=self.device_, dtype=torch.bfloat16), requires_grad=False)
         _attach(self, at + "embed_positions.weight", pos_prm)
         self._prm[at + "embed_positions.weight"] = pos_prm
+        a.extra_state.append(pos_prm.data)
         for i in range(self.enc_layers):
             p = f"{at}layers.{i}."
             P(p + "self_attn.q_proj.weight", p + "self_attn.qkv.weight", (0, E))
@@ -285,16 +289,65 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return x, n_tok
 
     # ------------------------------------------------------------------ forward (a10-a18)
+    @staticmethod
+    def _mask_intervals(attention_mask):
+        """attention_mask [B, S] of 0/1 -> (lo [B], hi [B]) of the single run of ones per row, or None when nothing is padded.
+        Computed on the mask's own device: a CPU mask (what a collator hands over) costs no device sync."""
+        am = attention_mask != 0
+        if bool(am.all()):
+            return None
+        S = am.shape[1]
+        n = am.sum(-1)
+        lo = am.to(torch.uint8).argmax(-1)
+        lo = torch.where(n > 0, lo, torch.zeros_like(lo))
+        hi = lo + n
+        ar = torch.arange(S, device=am.device)[None]
+        if not bool((am == ((ar >= lo[:, None]) & (ar < hi[:, None]))).all()):
+            raise AfkError("attention_mask rows must each be ONE contiguous run of ones (left and/or right padding); got a mask with holes")
+        return lo, hi
+
+    _rows_cache = None  # (weakref(labels tensor), version, rows) - see _valid_rows
+
+    def _valid_rows(self, labels):
+        """-> (shift_labels [B*S] on the device, rows) with rows = int64 indices (device) of the positions whose SHIFTED label is not -100,
+        or None when the lm_head should run on every row (all valid, or none).  The row count must be known on the host (it sizes the
+        GEMMs): labels that arrive on the CPU (a collator's output) are scanned there - no device sync; device labels are scanned on
+        the device (one sync) and the result is remembered for as long as the SAME tensor object (same version) comes back."""
+        import weakref
+
+        dev = self.device_
+        sh = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1)
+        if not labels.is_cuda:
+            rows = (sh != -100).nonzero().reshape(-1)
+            shift = sh.to(dev).contiguous()
+            rows = rows.to(dev) if 0 < rows.numel() < sh.numel() else None
+            return shift, rows
+        c = self._rows_cache
+        if c is not None and c[0]() is labels and c[1] == labels._version:
+            return sh.contiguous(), c[2]
+        rows = (sh != -100).nonzero().reshape(-1)  # host sync: the count sizes the GEMMs
+        rows = rows if 0 < rows.numel() < sh.numel() else None
+        self._rows_cache = (weakref.ref(labels), labels._version, rows)
+        return sh.contiguous(), rows
+
     def forward(self, input_ids=None, input_features=None, input_features_mask=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, logits_to_keep=0, return_logits=None,
                 num_items_in_batch=None, **kwargs):
-        if inputs_embeds is not None or past_key_values is not None:
-            raise AfkError("inputs_embeds / past_key_values are not supported by the MI355X training path yet")
+        if past_key_values is not None:
+            raise AfkError("forward(past_key_values=...) is not supported: the KV-cache path is generate()")
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         self._require_hip()
         a, lm = self.arena, self._lm
-        ids = input_ids.to(self.device_)
-        B, S = ids.shape
-        ids_flat = ids.reshape(-1).contiguous()
+        if inputs_embeds is not None:
+            # the reference merges audio only when input_ids are given (modeling_audioflamingo3.py:532-545): precomputed embeddings pass through
+            B, S = inputs_embeds.shape[:2]
+            ids = ids_flat = None
+            input_features = None
+        else:
+            ids = input_ids.to(self.device_)
+            B, S = ids.shape
+            ids_flat = ids.reshape(-1).contiguous()
         audio, src = None, None
         if input_features is not None:
             audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask, input_ids=ids)
@@ -315,34 +368,41 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 e = int(expected)
                 if n != e:
                     raise ValueError(f"Audio features and audio tokens do not match, tokens: {n}, features: {e}")
-        kv_len = None
+        kv_len, krange = None, None
         if attention_mask is not None:
-            am = attention_mask.to(self.device_)
-            if not bool(am.all()):
-                lens = am.sum(-1)
-                if not bool((am.cumsum(-1) == torch.minimum(torch.arange(1, S + 1, device=am.device)[None], lens[:, None])).all()):
-                    raise AfkError("only right-padded attention_mask is supported on the MI355X path")
-                kv_len = lens.to(torch.int32).contiguous()
+            iv = self._mask_intervals(attention_mask)
+            if iv is not None:
+                lo, hi = iv
+                if bool((lo == 0).all()):   # right padding only: the LDS-staged causal kernels take the key count per sample
+                    kv_len = hi.to(self.device_, torch.int32).contiguous()
+                else:                        # left padding (processing_audioflamingo3.py:46): causal AND key in [lo_b, hi_b) per query row
+                    lo, hi = lo.to(self.device_, torch.int32), hi.to(self.device_, torch.int32)
+                    i1 = torch.arange(1, S + 1, device=self.device_, dtype=torch.int32)[None]
+                    end = torch.minimum(i1, hi[:, None])
+                    krange = torch.stack([lo[:, None].expand(B, S), torch.maximum(end, lo[:, None])], -1).contiguous()
         pos = None
         if position_ids is not None:
             pos = position_ids.to(self.device_).expand(B, S).reshape(-1).to(torch.int32).contiguous()
         cos, sin = self._rope_tables(S if pos is None else int(self.config.text_config.max_position_embeddings))
-        x = F_.EmbedScatterFn.apply(audio, self._anchor(lm + "embed_tokens.weight"), a, lm + "embed_tokens.weight", ids_flat, src)
+        if inputs_embeds is not None:
+            x = inputs_embeds.to(self.device_, torch.bfloat16).reshape(B * S, self.H).contiguous()
+        else:
+            x = F_.EmbedScatterFn.apply(audio, self._anchor(lm + "embed_tokens.weight"), a, lm + "embed_tokens.weight", ids_flat, src)
         audio_hidden = audio
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
             x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
-                            self.rms_eps, cos, sin, pos, kv_len)
+                            self.rms_eps, cos, sin, pos, kv_len, krange)
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
         loss, logits = None, None
         if labels is not None:
-            lab = labels.to(self.device_)
-            shift = torch.nn.functional.pad(lab, (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
+            shift, rows = self._valid_rows(labels) if self.loss_on_valid_rows_only else (
+                torch.nn.functional.pad(labels.to(self.device_), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous(), None)
             if num_items_in_batch is not None:
                 denom = torch.as_tensor(num_items_in_batch, device=self.device_, dtype=torch.float32).reshape(1)
             else:
                 denom = ops.count_valid(shift)
-            loss = F_.LMHeadLossFn.apply(x, self._anchor("lm_head.weight"), a, "lm_head.weight", shift, denom)
+            loss = F_.LMHeadLossFn.apply(x, self._anchor("lm_head.weight"), a, "lm_head.weight", shift, denom, rows)
         if labels is None or return_logits:
             xs = x
             if isinstance(logits_to_keep, int) and logits_to_keep > 0:
@@ -412,6 +472,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
 
+    loss_on_valid_rows_only = True  # lm_head + CE (+ their backward GEMMs) on the rows with a label only (False: all B*S rows, as the reference)
     decode_splits = 8  # key-range splits of the Q = 1 attention (0: use the interval MFMA kernel instead)
     decode_fused_glue = True  # B <= 4: one glue kernel per Linear (csrc/decode_glue.hip) instead of reduce / bias / rope / append / norm / SwiGLU launches
 
@@ -526,6 +587,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     self._decode_step(st)
+                graph.replay()  # capture only records: the step for t == 2 itself still has to run
             elif graph is not None:
                 graph.replay()
             else:

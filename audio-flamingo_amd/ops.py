@@ -386,9 +386,12 @@ def embed_scatter_fwd(ids, src, embed, audio):
     return out
 
 
-def embed_scatter_bwd(ids, src, dout, d_embed, d_audio):
+def embed_scatter_bwd(ids, src, dout, d_embed, d_audio, perm=None):
+    """perm: int32 row indices sorted stably by token id (index plumbing: torch.sort) - built here when d_embed is wanted"""
     n, H = ids.numel(), dout.shape[-1]
-    _lib.call("afk_embed_scatter_bwd", ids.data_ptr(), _p(src), dout.data_ptr(), _p(d_embed), _p(d_audio), n, H, _stream())
+    if d_embed is not None and perm is None:
+        perm = torch.sort(ids.reshape(-1), stable=True).indices.to(torch.int32)
+    _lib.call("afk_embed_scatter_bwd", ids.data_ptr(), _p(src), dout.data_ptr(), _p(d_embed), _p(d_audio), _p(perm), n, H, _stream())
 
 
 # ---------------------------------------------------------------------------------------------- attention
@@ -458,6 +461,65 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
     return dqkv
 
 
+def xattn_fwd(q, k, v, krange, B, Sq, Sk, Hq, Hkv, D, scale):
+    """interval attention (afk_xattn_fwd): query row i of sample b sees keys [krange[b,i,0], krange[b,i,1]) (None: all Sk keys; an empty
+    interval yields a zero row).  q [B*Sq, >=Hq*D], k / v [B*Sk, >=Hkv*D] row-strided views.  -> o [B*Sq, Hq*D], lse [B, Hq, Sq]"""
+    sqp, skp = pad64(Sq), pad64(Sk)
+    vt = transpose_heads(v, B, Sk, Hkv, D, v.stride(0), skp)
+    o = torch.empty((B * Sq, Hq * D), device=q.device, dtype=BF16)
+    lse = torch.empty((B, Hq, Sq), device=q.device, dtype=torch.float32)
+    _lib.call("afk_xattn_fwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
+              vt.data_ptr(), o.data_ptr(), Sq * Hq * D, D, Hq * D, lse.data_ptr(), 0, _p(krange), B, Hq, Hkv, Sq, Sk, sqp, skp, D,
+              float(scale), _stream())
+    return o, lse
+
+
+def xattn_bwd(q, k, v, o, do, lse, krange, B, Sq, Sk, Hq, Hkv, D, scale, dq, dk, dv):
+    """backward of xattn_fwd; dq [B*Sq, >=Hq*D], dk / dv [B*Sk, >=Hkv*D] are written in place (row-strided views allowed)"""
+    dev = q.device
+    sqp, skp = pad64(Sq), pad64(Sk)
+    ldo = Hq * D
+    delta = torch.empty((B, Hq, Sq), device=dev, dtype=torch.float32)
+    _lib.call("afk_attn_delta", o.data_ptr(), Sq * ldo, D, ldo, do.data_ptr(), Sq * ldo, D, ldo, delta.data_ptr(), B, Hq, Sq, D, _stream())
+    qt = transpose_heads(q, B, Sq, Hq, D, q.stride(0), sqp)
+    kt = transpose_heads(k, B, Sk, Hkv, D, k.stride(0), skp)
+    dot = transpose_heads(do, B, Sq, Hq, D, ldo, sqp)
+    _lib.call("afk_xattn_bwd", q.data_ptr(), Sq * q.stride(0), D, q.stride(0), k.data_ptr(), Sk * k.stride(0), D, k.stride(0),
+              v.data_ptr(), Sk * v.stride(0), D, v.stride(0), do.data_ptr(), Sq * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(),
+              dot.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), Sq * dq.stride(0), D, dq.stride(0),
+              dk.data_ptr(), Sk * dk.stride(0), D, dk.stride(0), dv.data_ptr(), Sk * dv.stride(0), D, dv.stride(0), 0, _p(krange),
+              B, Hq, Hkv, Sq, Sk, sqp, skp, D, float(scale), _stream())
+
+
+def attn_interval_fwd(qkv, krange, B, S, Hq, Hkv, D, *, scale):
+    """self-attention on a fused q|k|v projection with a per-query key interval (left / right / both-side padding, causal or not)"""
+    _chk(qkv, BF16, "qkv")
+    return xattn_fwd(qkv, qkv[:, Hq * D:], qkv[:, (Hq + Hkv) * D:], krange, B, S, S, Hq, Hkv, D, scale)
+
+
+def attn_interval_bwd(qkv, o, do, lse, krange, B, S, Hq, Hkv, D, *, scale):
+    dqkv = torch.empty_like(qkv)
+    xattn_bwd(qkv, qkv[:, Hq * D:], qkv[:, (Hq + Hkv) * D:], o, do, lse, krange, B, S, S, Hq, Hkv, D, scale,
+              dqkv, dqkv[:, Hq * D:], dqkv[:, (Hq + Hkv) * D:])
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------- row gather / scatter
+def gather_rows(x, rows):
+    """out[i] = x[rows[i]]   (x [M, H] contiguous bf16, rows int64 on the device): the embedding-gather kernel on an activation matrix"""
+    _chk(x, BF16, "gather_rows x")
+    assert x.is_contiguous() and rows.dtype == torch.int64
+    return embed_scatter_fwd(rows, None, x, None)
+
+
+def scatter_rows(src, rows, M):
+    """out [M, H] zeros except out[rows[i]] = src[i]   (rows unique, ascending)"""
+    out = torch.zeros((M, src.shape[1]), device=src.device, dtype=BF16)
+    perm = torch.arange(rows.numel(), device=src.device, dtype=torch.int32)
+    embed_scatter_bwd(rows, None, src, out, None, perm=perm)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- loss
 def count_valid(labels):
     out = torch.empty(1, device=labels.device, dtype=torch.float32)
@@ -478,10 +540,18 @@ def loss_reduce(row_loss, denom, loss, *, accumulate=False):
 
 
 # ---------------------------------------------------------------------------------------------- optimizer
-def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_blocks=0):
+def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_blocks=0, gate=None, hyper=None):
+    """gate: optional device int32[1]; the launch leaves every buffer untouched when it reads 0.
+    hyper: optional device float32[3] = (lr, 1 - beta1^t, sqrt(1 - beta2^t)) overriding lr / step (HIP-graph replay)"""
     _lib.call("afk_adamw_step", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), param.numel(),
               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
-              int(max_blocks), _stream())
+              int(max_blocks), _p(gate), _p(hyper), _stream())
+
+
+def set_f32(dst, values):
+    """dst[:len(values)] = values (<= 4 floats), by a kernel launch on the current stream"""
+    v = [float(x) for x in values] + [0.0] * (4 - len(values))
+    _lib.call("afk_set_f32", _chk(dst, torch.float32).data_ptr(), len(values), v[0], v[1], v[2], v[3], _stream())
 
 
 def gemm_set_variant(v: int):
@@ -490,6 +560,21 @@ def gemm_set_variant(v: int):
 
 
 # ---------------------------------------------------------------------------------------------- profiling
+KERNEL_FAMILIES = ("gemm_nt128", "gemm_nt256", "gemm_nn256", "gemm_tn256", "gemm_splitk", "gemv", "attn2_fwd_d64", "attn2_fwd_d128",
+                   "attn2_bwd_d64", "attn2_bwd_d128", "gqa_reduce", "xattn_fwd", "xattn_bwd", "attn1_fwd", "attn1_bwd")
+
+
+def kernel_counts(reset: bool = False) -> dict:
+    """launches per kernel family since the last reset (include/afk.h AFK_CNT_*): lets a test assert which kernel served a shape"""
+    import ctypes
+
+    buf = (ctypes.c_int64 * len(KERNEL_FAMILIES))()
+    _lib.call("afk_kernel_counts", ctypes.addressof(buf), len(KERNEL_FAMILIES))
+    if reset:
+        _lib.call("afk_kernel_counts_reset")
+    return dict(zip(KERNEL_FAMILIES, list(buf)))
+
+
 def prof_enable(on: bool):
     _lib.call("afk_prof_enable", int(on))
 

@@ -25,13 +25,15 @@ class AfkAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.fused = FusedAdamW(self.arena, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.grad_scale = 1.0  # set to 1/world by a caller that hands over SUMMED data-parallel gradients
+        self.gates = None      # data parallel: DataParallelEngine.bucket_gate of the exchange that preceded this step
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
         self.fused.lr, self.fused.betas, self.fused.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])
-        self.fused.step(grad_scale=self.grad_scale)
+        self.fused.step(grad_scale=self.grad_scale, gates=self.gates)
+        self.gates = None
         return loss
 
     def zero_grad(self, set_to_none: bool = True):
@@ -50,6 +52,7 @@ class AfkAdamW(torch.optim.Optimizer):
             g.update(s)
         self.arena.params.copy_(f.master)  # bf16 working copy follows the fp32 master
         self.arena.step_counter += 1
+        f._mark_synced()  # the fp32 master just restored is the truth; do not re-derive it from the bf16 working copy
         self.arena.refresh_shadows(force=True)
 
 
@@ -81,7 +84,7 @@ class AfkTrainer(_trainer_base()):
             self._afk_engine = DataParallelEngine(self.model.arena, overlap=True)
             self._afk_engine.broadcast_parameters(0)
             if isinstance(self.optimizer, AfkAdamW):
-                self.optimizer.fused.master.copy_(self.model.arena.params)
+                self.optimizer.fused.sync_master()
             self._afk_scale = torch.full((1,), 1.0 / self._afk_engine.world, device=self.model.arena.device, dtype=torch.float32)
         return self._afk_engine
 
@@ -98,6 +101,8 @@ class AfkTrainer(_trainer_base()):
                 eng.finish()
                 g = self.model.arena.grads
                 ops.scale_add_(g, g, self._afk_scale, accumulate=False)  # averaged gradients: clipping / logging see the DDP convention
+                if isinstance(self.optimizer, AfkAdamW):
+                    self.optimizer.gates = eng.bucket_gate
         finally:
             eng.enabled = True
         return loss

@@ -81,63 +81,155 @@ def train_flops_per_sample(S=S_TOK, windows=1, recompute=False):
     return 3.0 * (enc + proj + lm) + (4.0 if recompute else 3.0) * layers
 
 
-def cpu_baseline(seconds_budget=30.0):
-    """The oracle (CPU restatement of the reference algorithm, fp32) timed on this host's cores on a bounded sample:
-    one sample (1 window, S=1024) through ONE encoder layer (+stem), ONE decoder layer and lm_head+CE, forward+backward,
-    composed to the full 32+28-layer step.  A reported baseline, not a target."""
-    from oracle import af3_oracle as O
+def _layer_flops():
+    """forward FLOPs of one encoder layer (per 30 s window) and one decoder layer (S = 1024): the weights of the depth extrapolation"""
+    fe = 2 * 1500 * (4 * 1280 ** 2 + 2 * 1280 * 5120) + 4 * 1500 ** 2 * 1280
+    fd = 2 * S_TOK * (2 * 3584 ** 2 + 2 * 3584 * 512 + 3 * 3584 * 18944) + 2 * S_TOK ** 2 * 3584
+    return fe, fd
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(0)
-    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.02)
-    E, Fd, H, I, V = 1280, 5120, 3584, 18944, 152064
-    at, lm = "model.audio_tower.", "model.language_model."
-    sd = {at + "conv1.weight": rnd(E, 128, 3), at + "conv1.bias": torch.zeros(E), at + "conv2.weight": rnd(E, E, 3), at + "conv2.bias": torch.zeros(E),
-          at + "embed_positions.weight": rnd(1500, E), at + "layer_norm.weight": torch.ones(E), at + "layer_norm.bias": torch.zeros(E)}
-    p = at + "layers.0."
-    for n, shp in (("self_attn.q_proj", (E, E)), ("self_attn.k_proj", (E, E)), ("self_attn.v_proj", (E, E)), ("self_attn.out_proj", (E, E)), ("fc1", (Fd, E)), ("fc2", (E, Fd))):
-        sd[p + n + ".weight"] = rnd(*shp)
-        if n != "self_attn.k_proj":
-            sd[p + n + ".bias"] = torch.zeros(shp[0])
-    for n in ("self_attn_layer_norm", "final_layer_norm"):
-        sd[p + n + ".weight"], sd[p + n + ".bias"] = torch.ones(E), torch.zeros(E)
-    q = lm + "layers.0."
-    for n, shp in (("self_attn.q_proj", (H, H)), ("self_attn.k_proj", (512, H)), ("self_attn.v_proj", (512, H))):
-        sd[q + n + ".weight"], sd[q + n + ".bias"] = rnd(*shp), torch.zeros(shp[0])
-    sd[q + "self_attn.o_proj.weight"] = rnd(H, H)
-    sd[q + "mlp.gate_proj.weight"], sd[q + "mlp.up_proj.weight"], sd[q + "mlp.down_proj.weight"] = rnd(I, H), rnd(I, H), rnd(H, I)
-    for n in ("input_layernorm", "post_attention_layernorm"):
-        sd[q + n + ".weight"] = torch.ones(H)
-    sd[lm + "norm.weight"] = torch.ones(H)
-    head = rnd(V, H).requires_grad_(True)
-    for v in sd.values():
-        v.requires_grad_(True)
 
-    def timed(fn):
+def _pick_cpu_threads(cap):
+    """eager CPU kernels do not scale to every hardware thread of a 2-socket host (r01: 256 threads ran the 1+1-layer probe 5x slower than
+    8 threads of the build container): take the thread count that runs a gate/up-sized fp32 GEMM fastest"""
+    a, b = torch.randn(1024, 3584), torch.randn(18944, 3584)
+    best, best_t = 1, float("inf")
+    for n in (8, 16, 32, 64, 128, 256):
+        if n > cap:
+            break
+        torch.set_num_threads(n)
+        torch.nn.functional.linear(a, b)
         t0 = time.perf_counter()
-        out = fn()
-        out.backward()
-        return time.perf_counter() - t0
+        for _ in range(3):
+            torch.nn.functional.linear(a, b)
+        t = time.perf_counter() - t0
+        if t < 0.92 * best_t:
+            best, best_t = n, t
+    return best
 
-    feats = torch.randn(1, 128, 3000, generator=g)
-    x_dec = torch.randn(1, S_TOK, H, generator=g).requires_grad_(True)
-    labels = torch.randint(0, V, (S_TOK,), generator=g)
-    labels[: S_TOK - N_ANSWER] = -100
-    t_enc_all = timed(lambda: O.encoder(sd, feats, None, 20)[0].float().pow(2).mean())          # stem + 1 layer + pool/LN
-    t_dec = timed(lambda: O.decoder(sd, x_dec, 28, 4, 1e-6, 1e6).float().pow(2).mean())          # 1 layer + final norm
-    t_head = timed(lambda: torch.nn.functional.cross_entropy(torch.nn.functional.linear(x_dec[0], head).float(), labels, ignore_index=-100))
-    # isolate the per-layer encoder cost with a stem-only run
-    sd0 = {k: v for k, v in sd.items() if ".layers.0." not in k or not k.startswith(at)}
-    t_stem = timed(lambda: O.encoder(sd0, feats, None, 20)[0].float().pow(2).mean())
-    t_enc_layer = max(t_enc_all - t_stem, 1e-6)
-    full = t_stem + 32 * t_enc_layer + 28 * t_dec + t_head
+
+def cpu_baseline(budget_s=25.0):
+    """The REFERENCE implementation itself (transformers.AudioFlamingo3ForConditionalGeneration, SURVEY.md §8d protocol) timed on this
+    host's cores on a bounded sample of the same workload: full WIDTH, depth-reduced (2 encoder + 2 decoder layers, then 1 + 1), one
+    sample (one 30 s window, S = 1024: 9 prompt + 750 <sound> + 9 prompt + 256 answer, loss on the answer), forward + backward, eager
+    PyTorch CPU, in fp32 and in bf16, 1 warm-up + up to 3 timed iterations each (bounded by budget_s per dtype).  The full-depth figure is
+    EXTRAPOLATED linearly in layer count: T(32, 28) = T(1,1) + (T(2,2) - T(1,1)) * (31 fE + 27 fD) / (fE + fD), fE / fD = FLOPs of an
+    encoder / decoder layer (the two depths separate the per-layer cost from stem + projector + lm_head + loss).  No optimizer step.
+    A reported baseline, not a target."""
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    ncpu = os.cpu_count() or 1
+    threads = _pick_cpu_threads(ncpu)
+    torch.set_num_threads(threads)
+    fe, fd = _layer_flops()
+    ids = torch.randint(0, 151643, (1, S_TOK))
+    ids[0, 9: 9 + N_AUDIO_TOK] = AUDIO_ID
+    labels = ids.clone()
+    labels[:, : S_TOK - N_ANSWER] = -100
+    feats = torch.randn(1, 128, 3000) * 0.5
+    times, detail = {}, {}
+    for depth in (2, 1):
+        with torch.device("meta"):
+            model = AudioFlamingo3ForConditionalGeneration(af3_7b_config(depth, depth))
+        model = model.to_empty(device="cpu")
+        with torch.no_grad():
+            for n_, p_ in model.named_parameters():
+                if n_.endswith("norm.weight") or n_.endswith("layer_norm.weight"):
+                    p_.fill_(1.0)
+                elif n_.endswith(".bias"):
+                    p_.zero_()
+                else:
+                    p_.normal_(0.0, 0.02)
+        model.train()
+        for dt in (torch.float32, torch.bfloat16):
+            model = model.to(dt)
+            kw = dict(input_ids=ids, input_features=feats.to(dt), input_features_mask=torch.ones(1, 3000, dtype=torch.long), labels=labels)
+            ts, t_start = [], time.perf_counter()
+            for it in range(4):  # 1 warm-up + up to 3 timed
+                t0 = time.perf_counter()
+                model.zero_grad(set_to_none=True)
+                model(**kw).loss.backward()
+                dtm = time.perf_counter() - t0
+                if it > 0:
+                    ts.append(dtm)
+                if it >= 1 and time.perf_counter() - t_start > budget_s * (1.0 if depth == 2 else 0.5):
+                    break
+            key = "fp32" if dt == torch.float32 else "bf16"
+            times[(depth, key)] = sum(ts) / len(ts)
+            detail[f"T({depth},{depth})_{key}_s"] = [round(t, 3) for t in ts]
+        del model
+    scale = (31 * fe + 27 * fd) / (fe + fd)
+    full = {k: times[(1, k)] + max(times[(2, k)] - times[(1, k)], 0.0) * scale for k in ("fp32", "bf16")}
     return {
-        "value": CLIP_SECONDS / full, "unit": "audio-s/s", "cores": cores, "kind": "port",
-        "decoder_tokens_per_s": S_TOK / full,
-        "sample": (f"oracle/af3_oracle.py fp32, B=1 (one 30 s window, S=1024) fwd+bwd of stem ({t_stem:.2f}s), 1 encoder layer ({t_enc_layer:.2f}s), "
-                   f"1 decoder layer ({t_dec:.2f}s), lm_head+CE ({t_head:.2f}s); composed to 32 enc + 28 dec layers = {full:.1f}s/sample (extrapolated, no optimizer)"),
+        "value": CLIP_SECONDS / full["bf16"], "unit": "audio-s/s", "cores": threads, "kind": "reference",
+        "decoder_tokens_per_s": S_TOK / full["bf16"], "dtype": "bf16",
+        "fp32": {"value": CLIP_SECONDS / full["fp32"], "decoder_tokens_per_s": S_TOK / full["fp32"], "s_per_sample_extrapolated": round(full["fp32"], 2)},
+        "s_per_sample_extrapolated": round(full["bf16"], 2), "host_cpus": ncpu, "timings": detail,
+        "sample": (f"transformers AudioFlamingo3ForConditionalGeneration, eager PyTorch CPU ({threads} threads of {ncpu} hardware threads), full width, "
+                   f"B=1 (one 30 s window, S=1024), fwd+bwd, 1 warm-up + {len(detail['T(2,2)_bf16_s'])} timed at 2+2 layers and at 1+1 layers; "
+                   f"bf16: T(2,2)={times[(2, 'bf16')]:.2f}s T(1,1)={times[(1, 'bf16')]:.2f}s, fp32: T(2,2)={times[(2, 'fp32')]:.2f}s "
+                   f"T(1,1)={times[(1, 'fp32')]:.2f}s; EXTRAPOLATED linearly in layer count (FLOP-weighted enc/dec split) to 32+28 layers: "
+                   f"{full['bf16']:.1f}s (bf16) / {full['fp32']:.1f}s (fp32) per sample, no optimizer step"),
     }
+
+
+def eager_rocm_baseline(dev, feats, ids, labels, steps=3):
+    """The same-node "before" number (SURVEY.md §8d last row, BASELINE.md §2 "B-rocm-eager"): the UNMODIFIED reference model
+    (transformers.AudioFlamingo3ForConditionalGeneration, attn_implementation sdpa, rocBLAS/hipBLASLt GEMMs, MIOpen convs) at full depth
+    in bf16 on this MI355X with torch.optim.AdamW (fused), on the same synthetic batch (micro-batch halved until it fits).  1 warm-up +
+    `steps` timed steps.  Also: the vendor GEMM (what F.linear dispatches to) on the gate|up shape 8192 x 37888 x 3584, HIP-event timed."""
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        model = AudioFlamingo3ForConditionalGeneration(af3_7b_config()).to(torch.bfloat16)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, fused=True)
+    B = ids.shape[0]
+    res = None
+    while B >= 1 and res is None:
+        kw = dict(input_ids=ids[:B], input_features=feats[:B], input_features_mask=torch.ones(B, feats.shape[-1], device=dev, dtype=torch.long),
+                  labels=labels[:B])
+        try:
+            ts = []
+            for it in range(steps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                opt.zero_grad(set_to_none=True)
+                loss = model(**kw).loss
+                loss.backward()
+                opt.step()
+                torch.cuda.synchronize()
+                if it > 0:
+                    ts.append(time.perf_counter() - t0)
+            ms = 1000.0 * sum(ts) / len(ts)
+            res = {"ms_per_step": ms, "micro_batch": B, "value": B * CLIP_SECONDS / (ms * 1e-3), "unit": "audio-s/s",
+                   "decoder_tokens_per_s": B * ids.shape[1] / (ms * 1e-3), "loss_last": float(loss.detach()),
+                   "model_tflops_per_gpu": train_flops_per_sample(ids.shape[1]) * B / (ms * 1e-3) / 1e12,
+                   "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+        except torch.OutOfMemoryError:
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.empty_cache()
+            B //= 2
+    del model, opt
+    torch.cuda.empty_cache()
+    # vendor GEMM on the largest shape of the step (decoder gate|up projection)
+    a = torch.randn(8192, 3584, device=dev, dtype=torch.bfloat16)
+    w = torch.randn(37888, 3584, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.nn.functional.linear(a, w)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.nn.functional.linear(a, w)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / 10
+    out = res or {"ms_per_step": None, "value": None, "unit": "audio-s/s", "micro_batch": 0}
+    out.update({"kind": "reference model, eager PyTorch-ROCm (sdpa, vendor BLAS), torch.optim.AdamW(fused), bf16, full depth 32+28",
+                "vendor_gemm_gate_up": {"shape": [8192, 37888, 3584], "ms": gemm_ms, "tflops": 2.0 * 8192 * 37888 * 3584 / (gemm_ms * 1e-3) / 1e12,
+                                        "what": "torch.nn.functional.linear (rocBLAS / hipBLASLt) on random bf16 operands, HIP events, 10 launches"},
+                "steps": steps, "warmup": 1})
+    return out
 
 
 def settle_hbm(dev, quiet_s=8.0, timeout_s=60.0):
@@ -188,6 +280,9 @@ def main():
     ap.add_argument("--enc-layers", type=int, default=32)
     ap.add_argument("--dec-layers", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the unmodified reference model on this GPU (eager PyTorch-ROCm)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
+    ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) of the default run")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW after backward instead of bucket-by-bucket inside it")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient branch on the compute stream")
@@ -232,7 +327,7 @@ def main():
     if use_dp:
         engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
         engine.broadcast_parameters(0)
-        opt.master.copy_(model.arena.params)
+        opt.sync_master()
     from audio_flamingo_amd import functional as F_
     model.arena.lazy_T_shadows = F_.BWD_FORM == "direct"
     model.arena.refresh_shadows(force=True)
@@ -245,23 +340,25 @@ def main():
     if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
         overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
 
+    data = {"waves": waves, "ids": ids, "labels": labels}
+
     def step(serial=False):
-        feats = frontend(waves, out_dtype=torch.bfloat16)
+        feats = frontend(data["waves"], out_dtype=torch.bfloat16)
         model.arena.zero_grad()
         if overlap is not None and not serial:
             # per bucket, inside backward, on a side stream: [all-reduce] -> AdamW -> W^T shadow refresh
             overlap.begin_step()
-            out = model(input_ids=ids, input_features=feats, labels=labels)
+            out = model(input_ids=data["ids"], input_features=feats, labels=data["labels"])
             out.loss.backward()
             overlap.finish()
             return out.loss
         if engine is not None:
             engine.begin_backward()
-        out = model(input_ids=ids, input_features=feats, labels=labels)
+        out = model(input_ids=data["ids"], input_features=feats, labels=data["labels"])
         out.loss.backward()
         if engine is not None:
             engine.finish()
-        opt.step(grad_scale=engine.grad_scale if engine is not None else 1.0)
+        opt.step(grad_scale=engine.grad_scale if engine is not None else 1.0, gates=engine.bucket_gate if engine is not None else None)
         return out.loss
 
     def fence():
@@ -270,15 +367,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # N = 1: the step (static shapes) is captured once into a HIP graph - three streams, ~3 000 launches -> one hipGraphLaunch per step.
+    # N > 1 keeps the eager enqueue (RCCL inside a capture is not validated on this pool's 1-GPU boxes; the host keeps ahead of the GPU there).
+    use_graph = (not args.no_graph) and not use_dp and overlap is not None and not ckpt
+    first_loss = float(step().detach())  # ~ ln(152064) = 11.9 for random-init weights: the line checks itself (the last loss is lower)
+    run = step
+    if use_graph:
+        from audio_flamingo_amd.graphs import GraphedTrainStep
+
+        run = GraphedTrainStep(model, opt, overlap, step, warmup=1)
     loss = None
-    for _ in range(args.warmup):
-        loss = step()
+    for i in range(args.warmup):
+        loss = run()
     fence()
     ops.prof_reset()
     ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside): << dt means the GPU is never starved
     fence()
     dt = time.perf_counter() - t0
@@ -305,12 +411,55 @@ def main():
             _lib.call("afk_prof_dump", os.environ["AFK_PROF_DUMP"].encode())
     else:
         gemm_ms, gemm_flops, gemm_launches, prof_steps = ov_ms, ov_flops, ov_launches, args.steps
+    final_loss = float(loss.detach()) if loss is not None else float("nan")
+    if first_loss is None:
+        first_loss = final_loss
+    rank_losses, replicas_identical = [final_loss], None
     if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    final_loss = float(loss.detach()) if loss is not None else float("nan")
+        # every replica must hold bit-identical parameters after the timed steps (same reduced gradients, same AdamW): checksum per rank
+        model.arena.join_streams()
+        p32 = model.arena.params.float()
+        chk = torch.stack([p32.sum().double(), p32.abs().sum().double(), torch.tensor(final_loss, device=dev, dtype=torch.float64)])
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        replicas_identical = all(bool(torch.equal(c[:2], allc[0][:2])) for c in allc)
+        rank_losses = [float(c[2]) for c in allc]
+        assert replicas_identical, f"data-parallel replicas diverged: {[c[:2].tolist() for c in allc]}"
+        del p32
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+
+    # BASELINE configs[4] (long audio) beside the headline: a few steps of the 5-minute workload on the same replica, so that the
+    # driver's plain `bench.py --gpus N` run records it too (one sample = 10 windows, S = 7 774, per-layer activation checkpointing)
+    long_audio = None
+    if args.workload == "clip30" and full_model and not args.no_long_audio:
+        lw = WORKLOADS["long5min"]
+        data["waves"], data["ids"], data["labels"] = synthetic_batch(lw["batch"], rank * lw["batch"], dev, lw["windows"])
+        model.gradient_checkpointing_enable()
+        for _ in range(2):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        fence()
+        ldt = time.perf_counter() - t0
+        if use_dp:
+            t = torch.tensor([ldt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ldt = float(t.item())
+        model.gradient_checkpointing_disable()
+        ls = 9 + N_AUDIO_TOK * lw["windows"] + 9 + N_ANSWER
+        sps = world * lw["batch"] * 3 / ldt
+        long_audio = {"workload": f"AF3-7B bf16 train step, 5-min clips = {lw['windows']} windows/sample, S={ls}, micro-batch {lw['batch']}/GPU, per-layer "
+                                  "activation checkpointing ON (BASELINE configs[4])", "ms_per_step": 1000.0 * ldt / 3, "steps": 3, "warmup": 2,
+                      "value": sps * CLIP_SECONDS * lw["windows"], "unit": "audio-s/s", "decoder_tokens_per_s": sps * ls,
+                      "model_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"]) * sps / world / 1e12,
+                      "hardware_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"], True) * sps / world / 1e12,
+                      "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+        data["waves"], data["ids"], data["labels"] = waves, ids, labels
 
     if rank == 0:
         ms_per_step = 1000.0 * dt / args.steps
@@ -326,6 +475,10 @@ def main():
                               "shape": tj["shape"], "source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
         hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
+        # lm_head + loss (forward, dgrad, wgrad) run only on the rows that carry a label: identical loss and gradients, fewer executed FLOPs.
+        # model_tflops stays ALGORITHMIC (the reference's 3 x forward over every row); executed = what the kernels really did.
+        skipped = 3.0 * 2 * (s_tok - N_ANSWER) * 3584 * 152064 if model.loss_on_valid_rows_only else 0.0
+        exec_tf = (train_flops_per_sample(s_tok, windows, ckpt) - skipped) * samples_per_s / world / 1e12 if full_model else None
         res = {
             "metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train",
             "value": samples_per_s * CLIP_SECONDS * windows, "unit": "audio-s/s",
@@ -339,10 +492,14 @@ def main():
                        "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": s_tok, "audio_tokens": n_audio_tok,
                        "windows_per_sample": windows, "activation_checkpointing": ckpt,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
-            "loss": final_loss, "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
+            "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
+            "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
+            "replicas_identical_after_steps": replicas_identical, "long_audio_configs4": long_audio,
+            "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
             "waited_for_free_hbm_s": waited,
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
-            "hardware_tflops_per_gpu": hw_tf,
+            "hardware_tflops_per_gpu": hw_tf, "executed_tflops_per_gpu": exec_tf,
+            "lm_head_rows": {"executed": N_ANSWER, "of": s_tok, "note": "lm_head/CE and their backward GEMMs run on the labelled rows only (same loss, same gradients)"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",
                          "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic, "traffic_detail": traffic_detail,
                          "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),
@@ -352,11 +509,31 @@ def main():
                          "note": ("HIP events around every GEMM launch on its launch stream; measured on one extra untimed step with the wgrad stream "
                                   "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")},
         }
+        if not args.no_eager_baseline and world == 1 and args.workload == "clip30":
+            # the reference's own model on this GPU: free our replica first (the two do not fit side by side)
+            try:
+                feats_b = frontend(waves, out_dtype=torch.bfloat16)
+                model.arena.on_bucket_ready = None
+                loss = None
+                del model, opt, overlap, engine, step
+                import gc
+
+                gc.collect()
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats(dev)
+                still = torch.cuda.memory_allocated(dev) / 2 ** 30
+                eb = eager_rocm_baseline(dev, feats_b, ids, labels)
+                eb["hbm_still_allocated_before_gib"] = round(still, 1)
+                res["eager_rocm_baseline"] = eb
+                if eb.get("value"):
+                    res["speedup_vs_eager_rocm"] = res["value"] / eb["value"]
+            except Exception as e:
+                res["eager_rocm_baseline"] = {"value": None, "unit": "audio-s/s", "error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N = 1 only
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the measured line down
-                res["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+                res["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e!r}"}
         line = json.dumps(res)
     else:
         line = None

@@ -24,6 +24,27 @@ extern "C" {
 int afk_version(void);
 const char* afk_last_error(void);
 
+/* ---- launch counters per kernel family: host_out[i] = launches of family i since the last reset (i < n <= AFK_CNT_MAX).
+ * Test infrastructure: lets a parity test assert WHICH kernel served a shape (256x256 ping-pong GEMM, TN wgrad, GQA-split dK/dV...). */
+#define AFK_CNT_GEMM_NT128 0
+#define AFK_CNT_GEMM_NT256 1
+#define AFK_CNT_GEMM_NN256 2
+#define AFK_CNT_GEMM_TN256 3
+#define AFK_CNT_GEMM_SPLITK 4
+#define AFK_CNT_GEMV 5
+#define AFK_CNT_ATTN2_FWD_D64 6
+#define AFK_CNT_ATTN2_FWD_D128 7
+#define AFK_CNT_ATTN2_BWD_D64 8
+#define AFK_CNT_ATTN2_BWD_D128 9
+#define AFK_CNT_GQA_REDUCE 10
+#define AFK_CNT_XATTN_FWD 11
+#define AFK_CNT_XATTN_BWD 12
+#define AFK_CNT_ATTN1_FWD 13
+#define AFK_CNT_ATTN1_BWD 14
+#define AFK_CNT_MAX 16
+int afk_kernel_counts(int64_t* host_out, int n);
+int afk_kernel_counts_reset(void);
+
 /* ---- profiling: HIP events around every afk_gemm_nt_bf16 launch (bench.py roofline leg) ------------- */
 int afk_prof_enable(int on);
 int afk_prof_reset(void);
@@ -138,8 +159,10 @@ int afk_avgpool2_bwd(const void* dy, void* dx, int64_t out_rows, int C, void* st
 int afk_placeholder_scan(const int64_t* ids, int64_t n, int64_t audio_id, int* src, int* n_audio, void* stream);
 int afk_embed_scatter_fwd(const int64_t* ids, const int* src, const void* embed, const void* audio, void* out,
                           int64_t n, int H, void* stream);
+/* backward: d_audio[src[r]] = dout[r] for placeholder rows; d_embed[ids[r]] += sum of dout rows with that id, accumulated in fp32 in
+ * row order and rounded once (bit-deterministic, no atomics).  perm = the n row indices sorted STABLY by ids (required with d_embed). */
 int afk_embed_scatter_bwd(const int64_t* ids, const int* src, const void* dout, void* d_embed, void* d_audio,
-                          int64_t n, int H, void* stream);
+                          const int* perm, int64_t n, int H, void* stream);
 
 /* ---- attention (encoder :117-189 bidirectional 20x64; decoder modeling_qwen2.py:195-234 causal GQA 28:4x128) --
  * tensors are addressed base + b*bs + h*hs + s*rs + d (element strides) so q/k/v can live inside the fused
@@ -238,9 +261,15 @@ int afk_loss_reduce(const float* row_loss, int64_t n, const float* denom, float*
 int afk_logmel(const float* wav, int W, int64_t nsamp, const float* cosb, const float* sinb, int nbins_pad,
                const float* melT, int nmel, float* raw_ws, int* wmax_ws, void* out, int out_is_bf16, void* stream);
 
-/* ---- optimizer: AdamW on a flat parameter arena (bf16 param + fp32 master/m/v, 28 B/param) ------------- */
+/* ---- optimizer: AdamW on a flat parameter arena (bf16 param + fp32 master/m/v, 28 B/param) -------------
+ * gate (may be NULL): device int; when it reads 0 the launch leaves every buffer untouched (torch.optim skips parameters whose
+ * grad is None; under data parallelism "did any rank produce a gradient for this bucket" is only known on the device).
+ * hyper (may be NULL): device float[3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; when given it overrides lr and the bias corrections
+ * derived from `step`, so that a captured HIP graph of the training step replays with the current values (afk_set_f32 writes them). */
 int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, void* stream);
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, const int* gate,
+                   const float* hyper, void* stream);
+int afk_set_f32(float* dst, int n, float a, float b, float c, float d, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,11 +1,22 @@
 """Generates tests/golden/*.pt from the LIVE reference implementation (transformers 5.15 AudioFlamingo3, fp32 CPU).
 
-Run in the build container:  python oracle/make_golden.py
+Run in the build container:  python oracle/make_golden.py        (single-threaded on purpose: bit-reproducible, ~5 min)
 The outputs are small seeded input/output vectors that travel with the repo (the tests never need to re-run
 the reference).  Config "tiny64": full architecture, reduced width/depth, dims that satisfy the MFMA kernels
-(multiples of 64, head_dim 32/64).  Two cases: (A) full windows, no padding; (B) one padded window (5 s clip)
-exercising the key-padding mask, the token-count formula and the valid-row scatter.
+(multiples of 64, head_dim 32/64).
+
+Round 2: a random-init tiny model has nearly flat logits (|x| <= 1.2, top-1/top-2 gap below bf16 noise at 94 % of the
+positions, greedy decoding emits one constant id), so "token indices bit-exact" was barely exercised.  The reference
+model is therefore TRAINED here for a few hundred AdamW steps (the reference's own forward/backward, torch.optim) on a
+synthetic language with a sharp answer at every position: text tokens follow a fixed random permutation chain
+(next = PERM[cur]) and a <sound> placeholder is followed by another placeholder.  The trained weights are rounded to
+bf16 and every golden below is computed from the rounded weights.
+
+Cases: (A) full windows, no padding; (B) one padded window (5 s clip) + RIGHT-padded row: key-padding mask, token-count
+formula, valid-row scatter; (C) a batch built by the reference's own AudioFlamingo3Processor (synthetic word-level
+tokenizer, 5 s + 30 s clips) - LEFT padded, labels from output_labels=True.
 """
+import math
 import os
 import sys
 
@@ -22,6 +33,25 @@ TINY = dict(
                      num_key_value_heads=2, max_position_embeddings=4096),
     audio_token_id=1023,
 )
+AUDIO_ID, PAD_ID, N_WORDS = 1023, 1000, 256     # text tokens 0..255 ("w0".."w255"), <pad> = 1000, <sound> = 1023
+TRAIN_STEPS, N_GEN = 400, 24
+
+
+def perm_table():
+    return torch.randperm(N_WORDS, generator=torch.Generator().manual_seed(123))
+
+
+def chain(start, n, perm):
+    out = [int(start)]
+    for _ in range(n - 1):
+        out.append(int(perm[out[-1]]))
+    return torch.tensor(out, dtype=torch.long)
+
+
+def round_bf16_(model):
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
 
 
 def build(seed=0):
@@ -30,24 +60,52 @@ def build(seed=0):
     torch.manual_seed(seed)
     cfg = AudioFlamingo3Config(**TINY)
     model = AudioFlamingo3ForConditionalGeneration(cfg).eval()
-    # weights are rounded to bf16 so that the GPU path (bf16 storage) and the fp32 references share identical parameters
     with torch.no_grad():
-        for p in model.parameters():
-            p.copy_(p.to(torch.bfloat16).float())
         # give biases / norm weights non-trivial values (the default init leaves them 0 / 1)
         g = torch.Generator().manual_seed(seed + 1)
         for n, p in model.named_parameters():
             if n.endswith(".bias"):
-                p.copy_((0.02 * torch.randn(p.shape, generator=g)).to(torch.bfloat16).float())
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
             elif "norm" in n and n.endswith(".weight"):
-                p.copy_((1 + 0.05 * torch.randn(p.shape, generator=g)).to(torch.bfloat16).float())
+                p.copy_(1 + 0.05 * torch.randn(p.shape, generator=g))
     return cfg, model
+
+
+def train_sharp(model, steps=TRAIN_STEPS, log=True):
+    """fine-tune the REFERENCE model with the reference's own forward / autograd / torch.optim.AdamW until its next-token
+    distribution is sharp (the synthetic language above); cosine learning-rate decay 4e-3 -> 4e-4"""
+    perm = perm_table()
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=4e-3, weight_decay=0.0)
+    for step in range(steps):
+        for gr in opt.param_groups:
+            gr["lr"] = 4e-4 + 0.5 * (4e-3 - 4e-4) * (1 + math.cos(math.pi * step / steps))
+        gg = torch.Generator().manual_seed(1000 + step)
+        B, nt = 2, 125
+        feats = torch.randn(B, 128, 3000, generator=gg) * 0.5
+        fmask = torch.zeros(B, 3000, dtype=torch.long)
+        fmask[:, :500] = 1                                  # 5 s clips: 125 <sound> tokens
+        rows = []
+        for b in range(B):
+            c = chain(int(torch.randint(0, N_WORDS, (1,), generator=gg)), 126, perm)
+            cut = int(torch.randint(3, 12, (1,), generator=gg))
+            rows.append(torch.cat([c[:cut], torch.full((nt,), AUDIO_ID), c[cut:]]))
+        ids = torch.stack(rows)
+        out = model(input_ids=ids, input_features=feats, input_features_mask=fmask, labels=ids.clone())
+        opt.zero_grad()
+        out.loss.backward()
+        opt.step()
+        if log and step % 50 == 0:
+            print(f"  train step {step}: loss {float(out.loss.detach()):.4f}", flush=True)
+    model.eval()
+    return model
 
 
 def make_inputs(case):
     from transformers import WhisperFeatureExtractor
 
     rng = np.random.default_rng(1234)
+    perm = perm_table()
     fe = WhisperFeatureExtractor(feature_size=128)
     if case == "A":  # 2 samples x one full 30 s window
         waves = [rng.standard_normal(480000).astype(np.float32) * 0.1 for _ in range(2)]
@@ -57,71 +115,106 @@ def make_inputs(case):
         n_tok = [750, 125]
     out = fe(waves, sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="pt")
     feats, fmask = out["input_features"], out["attention_mask"]
-    wav_pad = np.zeros((2, 480000), np.float32)
-    for i, w in enumerate(waves):
-        wav_pad[i, : len(w)] = w
     S = 9 + 750 + 9 + 24
     ids = torch.zeros((2, S), dtype=torch.long)
     att = torch.ones((2, S), dtype=torch.long)
     labels = torch.full((2, S), -100, dtype=torch.long)
     for i in range(2):
-        text = lambda n: torch.from_numpy(rng.integers(0, 1000, n))
-        row = torch.cat([text(9), torch.full((n_tok[i],), 1023), text(9), text(24)])
+        c = chain(int(rng.integers(0, N_WORDS)), 42, perm)
+        row = torch.cat([c[:9], torch.full((n_tok[i],), AUDIO_ID), c[9:]])
         ids[i, : len(row)] = row
         att[i, len(row):] = 0  # right padding (case B second row)
         labels[i, len(row) - 24: len(row)] = row[-24:]
         if len(row) < S:
             ids[i, len(row):] = 0
-    return dict(wave=torch.from_numpy(wav_pad), feats=feats, fmask=fmask, ids=ids, att=att, labels=labels)
+    return dict(feats=feats, fmask=fmask, ids=ids, att=att, labels=labels)
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
+def make_processor():
+    """the reference's own processor with a synthetic offline tokenizer"""
+    from tokenizers import Tokenizer
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import WhitespaceSplit
+    from transformers import AudioFlamingo3Processor, PreTrainedTokenizerFast, WhisperFeatureExtractor
+
+    vocab = {f"w{i}": i for i in range(1000)}
+    vocab.update({"<pad>": PAD_ID, "<unk>": 1001, "<sound>": AUDIO_ID})
+    vocab.update({f"<r{i}>": i for i in range(1002, AUDIO_ID)})  # no holes in the id space
+    tok = Tokenizer(WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = WhitespaceSplit()
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="<pad>", unk_token="<unk>", additional_special_tokens=["<sound>"])
+    return AudioFlamingo3Processor(WhisperFeatureExtractor(feature_size=128), fast)
+
+
+def make_inputs_processor():
+    """case C: what AudioFlamingo3Processor.__call__ hands to the model for two (prompt, clip) pairs of different lengths:
+    left-padded input_ids / attention_mask, labels with -100 on <sound> and <pad> positions"""
+    rng = np.random.default_rng(4321)
+    perm = perm_table()
+    proc = make_processor()
+    waves = [rng.standard_normal(80000).astype(np.float32) * 0.1, rng.standard_normal(480000).astype(np.float32) * 0.1]
+    texts = []
+    for i, n in enumerate((20, 31)):
+        c = chain(int(rng.integers(0, N_WORDS)), n, perm).tolist()
+        texts.append(" ".join(f"w{t}" for t in c[:5]) + " <sound> " + " ".join(f"w{t}" for t in c[5:]))
+    out = proc(text=texts, audio=waves, output_labels=True)
+    return dict(feats=out["input_features"], fmask=out["input_features_mask"], ids=out["input_ids"], att=out["attention_mask"],
+                labels=out["labels"])
+
+
+PICK = ["lm_head.weight", "model.language_model.embed_tokens.weight", "model.language_model.layers.0.self_attn.k_proj.weight",
+        "model.language_model.layers.1.mlp.up_proj.weight", "model.language_model.layers.0.input_layernorm.weight",
+        "model.multi_modal_projector.linear_1.weight", "model.audio_tower.layers.0.self_attn.q_proj.bias",
+        "model.audio_tower.layers.1.fc1.weight", "model.audio_tower.conv1.weight", "model.audio_tower.conv2.bias",
+        "model.audio_tower.layer_norm.weight"]
+
+
+def golden_case(model, inp, generate_from=None):
+    # the stored feats are bf16-rounded: the reference outputs are computed on exactly those inputs
+    fe_b = inp["feats"].to(torch.bfloat16).float()
+    model.zero_grad()
+    out = model(input_ids=inp["ids"], input_features=fe_b, input_features_mask=inp["fmask"], attention_mask=inp["att"], labels=inp["labels"])
+    out.loss.backward()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    gen = None
+    with torch.no_grad():
+        audio = model.get_audio_features(fe_b, inp["fmask"]).pooler_output
+        if generate_from is not None:
+            gen = model.generate(input_ids=generate_from["ids"], input_features=fe_b[: generate_from["n_windows"]],
+                                 input_features_mask=inp["fmask"][: generate_from["n_windows"]], attention_mask=generate_from["att"],
+                                 max_new_tokens=N_GEN, do_sample=False)
+    keep = inp["labels"] != -100  # logits are stored only where the loss looks at them (argmax / top-2 gap are stored everywhere)
+    logits = out.logits.detach()
+    top2 = logits.topk(2, -1).values
+    return dict(
+        feats=inp["feats"].to(torch.bfloat16), fmask=inp["fmask"].to(torch.int32), ids=inp["ids"], att=inp["att"], labels=inp["labels"],
+        loss=out.loss.detach(), logits_bf16=logits[keep].to(torch.bfloat16), argmax=logits.argmax(-1), top_gap=(top2[..., 0] - top2[..., 1]),
+        logits_absmax=float(logits.abs().max()), audio_bf16=audio.to(torch.bfloat16),
+        grads={k: grads[k].to(torch.bfloat16) for k in PICK}, grad_norms={k: float(v.norm()) for k, v in grads.items()}, generate=gen)
+
+
+def main(out_dir=OUT):
+    torch.set_num_threads(1)  # bit-reproducible goldens (reduction order of the CPU GEMMs depends on the thread count)
+    os.makedirs(out_dir, exist_ok=True)
     cfg, model = build()
+    train_sharp(model)
+    round_bf16_(model)  # the GPU path stores bf16: both sides share identical (rounded) parameters
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    torch.save({k: v.to(torch.bfloat16) for k, v in sd.items()}, os.path.join(OUT, "tiny64_state_bf16.pt"))
-    for case in ("A", "B"):
-        inp = make_inputs(case)
-        kw = dict(input_ids=inp["ids"], input_features=inp["feats"], input_features_mask=inp["fmask"], attention_mask=inp["att"])
-        model.zero_grad()
-        out = model(**kw, labels=inp["labels"])
-        out.loss.backward()
-        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        pick = ["lm_head.weight", "model.language_model.layers.0.self_attn.k_proj.weight", "model.language_model.layers.1.mlp.up_proj.weight",
-                "model.language_model.layers.0.input_layernorm.weight", "model.multi_modal_projector.linear_1.weight",
-                "model.audio_tower.layers.0.self_attn.q_proj.bias", "model.audio_tower.layers.1.fc1.weight", "model.audio_tower.conv1.weight",
-                "model.audio_tower.conv2.bias", "model.audio_tower.layer_norm.weight"]
-        with torch.no_grad():
-            gen = model.generate(**{k: v[:1] for k, v in kw.items()}, max_new_tokens=4, do_sample=False) if case == "A" else None
-            audio = model.get_audio_features(inp["feats"], inp["fmask"]).pooler_output
-        keep = inp["labels"] != -100  # logits are stored only where the loss looks at them (argmax is stored everywhere)
-        gold = dict(
-            wave=inp["wave"][:, :160000].clone() if case == "A" else inp["wave"].clone()[:, :80000],  # enough to re-derive nothing: feats are stored
-            feats=inp["feats"].to(torch.bfloat16), fmask=inp["fmask"].to(torch.int32), ids=inp["ids"], att=inp["att"], labels=inp["labels"],
-            loss=out.loss.detach(), logits_bf16=out.logits.detach()[keep].to(torch.bfloat16),
-            argmax=out.logits.detach().argmax(-1), audio_bf16=audio.to(torch.bfloat16),
-            grads={k: grads[k].to(torch.bfloat16) for k in pick}, grad_norms={k: float(v.norm()) for k, v in grads.items()},
-            generate=gen,
-        )
-        # the stored feats are bf16-rounded: recompute the reference outputs on exactly those inputs
-        fe_b = inp["feats"].to(torch.bfloat16).float()
-        model.zero_grad()
-        out = model(input_ids=inp["ids"], input_features=fe_b, input_features_mask=inp["fmask"], attention_mask=inp["att"], labels=inp["labels"])
-        out.loss.backward()
-        grads = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
-        with torch.no_grad():
-            audio = model.get_audio_features(fe_b, inp["fmask"]).pooler_output
-            gen = model.generate(input_ids=inp["ids"][:1], input_features=fe_b[:1], input_features_mask=inp["fmask"][:1],
-                                 attention_mask=inp["att"][:1], max_new_tokens=4, do_sample=False) if case == "A" else None
-        top2 = out.logits.detach().topk(2, -1).values
-        gold.update(loss=out.loss.detach(), logits_bf16=out.logits.detach()[keep].to(torch.bfloat16), argmax=out.logits.detach().argmax(-1),
-                    top_gap=(top2[..., 0] - top2[..., 1]), audio_bf16=audio.to(torch.bfloat16),
-                    grads={k: grads[k].to(torch.bfloat16) for k in pick}, grad_norms={k: float(v.norm()) for k, v in grads.items()},
-                    generate=gen)
-        del gold["wave"]
-        torch.save(gold, os.path.join(OUT, f"tiny64_case{case}.pt"))
-        print(case, "loss", float(out.loss), "gen", None if gen is None else gen[0, -4:].tolist())
-    # log-mel golden: 2 s of the case-A waveform -> features from the reference feature extractor
+    torch.save({k: v.to(torch.bfloat16) for k, v in sd.items()}, os.path.join(out_dir, "tiny64_state_bf16.pt"))
+    for case in ("A", "B", "C"):
+        inp = make_inputs(case) if case != "C" else make_inputs_processor()
+        gen_from = None
+        if case == "A":    # sample 0, prompt + audio + the first 4 answer tokens -> greedy continuation along the chain
+            gen_from = dict(ids=inp["ids"][:1, : 9 + 750 + 9 + 4], att=inp["att"][:1, : 9 + 750 + 9 + 4], n_windows=1)
+        elif case == "C":  # the processor's left-padded batch as it is (both rows)
+            gen_from = dict(ids=inp["ids"], att=inp["att"], n_windows=inp["feats"].shape[0])
+        gold = golden_case(model, inp, gen_from)
+        torch.save(gold, os.path.join(out_dir, f"tiny64_case{case}.pt"))
+        valid = inp["att"].bool()
+        conf = (gold["top_gap"] > 0.25) & valid
+        print(case, "loss", float(gold["loss"]), "logits |max|", round(gold["logits_absmax"], 2), "confident",
+              int(conf.sum()), "/", int(valid.sum()), "gen tail", None if gold["generate"] is None else gold["generate"][0, -N_GEN:].tolist())
+    # log-mel golden: 10 s of signal + silence -> features from the reference feature extractor
     from transformers import WhisperFeatureExtractor
 
     rng = np.random.default_rng(7)
@@ -130,10 +223,10 @@ def main():
     fe = WhisperFeatureExtractor(feature_size=128)
     f = fe._torch_extract_fbank_features(w[None])
     torch.save(dict(wave_head=torch.from_numpy(w[:160000].copy()), feats_sub=torch.from_numpy(f[0, :, ::37].copy()), stride=37,
-                    n=480000), os.path.join(OUT, "logmel_case.pt"))
-    for fn in sorted(os.listdir(OUT)):
-        print(fn, os.path.getsize(os.path.join(OUT, fn)) // 1024, "KiB")
+                    n=480000), os.path.join(out_dir, "logmel_case.pt"))
+    for fn in sorted(os.listdir(out_dir)):
+        print(fn, os.path.getsize(os.path.join(out_dir, fn)) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(*sys.argv[1:2]))

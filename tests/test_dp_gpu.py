@@ -1,0 +1,169 @@
+"""Data-parallel correctness on a GPU through the REAL model (SURVEY.md §8e "Equivalence test").
+
+Two ranks drive DataParallelEngine + BackwardOverlap / the post-backward path through the tiny AF3 model, each on half of the
+golden case-A batch; rank 0 also runs the single-process step on the concatenated batch.  Required:
+    averaged DP gradients == single-process gradients (mean loss, equal label counts per rank => exact up to summation order),
+    parameters after AdamW agree, every rank ends with identical parameters, every rank issued the same collectives in the same
+    order - including the UNEVEN step where one rank's batch has no audio (its audio-tower buckets are reduced in finish()).
+Reference behaviour: torch DDP, TORCH/nn/parallel/distributed.py:662-666 (bucketed all-reduce), :1442 (no_sync).
+
+  * test_dp_two_ranks_one_gpu_gloo : both ranks share cuda:0, process group "gloo", gradient slices staged through the host
+                                     (runs on the 1-GPU boxes of this pool)
+  * test_dp_two_ranks_rccl         : one GPU per rank, "nccl" = RCCL over xGMI; skipped unless >= 2 GPUs are visible
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys, torch, torch.distributed as dist
+ROOT, backend = sys.argv[1], sys.argv[2]
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+from transformers import AudioFlamingo3Config
+from audio_flamingo_amd.arena import FusedAdamW
+from audio_flamingo_amd.dp import BackwardOverlap, DataParallelEngine
+from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+from tests.test_host_cpu import TINY
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", rank if backend == "nccl" else 0)
+torch.cuda.set_device(dev)
+dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+G = os.path.join(ROOT, "tests", "golden")
+g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
+LR, WD = 1e-3, 0.01
+
+def model(seed):
+    m = Mine(AudioFlamingo3Config(**TINY), device=dev, init_seed=seed)
+    return m
+
+def batch(rows):
+    return dict(input_ids=g["ids"][rows].to(dev), input_features=g["feats"][rows].to(dev), input_features_mask=g["fmask"][rows].to(dev),
+                labels=g["labels"][rows].to(dev))
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
+
+report = {}
+for mode in ("overlap", "post"):
+    # ---- DP replica: different init per rank on purpose, rank 0's weights (the golden state) are broadcast
+    m = model(seed=10 + rank)
+    if rank == 0:
+        m.load_state_dict(sd)
+    opt = FusedAdamW(m.arena, lr=LR, weight_decay=WD)
+    eng = DataParallelEngine(m.arena, overlap=True)
+    eng.broadcast_parameters(0)
+    if mode == "overlap":
+        m.arena.enable_wgrad_stream(True)
+    ov = BackwardOverlap(m.arena, opt, eng) if mode == "overlap" else None
+    # ---- single-process reference on the concatenated batch (every rank computes it: cheap, and no extra communication)
+    ref = model(seed=0); ref.load_state_dict(sd)
+    ropt = FusedAdamW(ref.arena, lr=LR, weight_decay=WD)
+    assert torch.equal(m.arena.params, ref.arena.params), "broadcast_parameters failed"
+    mine = slice(rank, rank + 1)
+    for step in range(3):
+        uneven = step == 2   # last step: rank 1 trains on text only (no audio tower on that rank)
+        ref.zero_grad()
+        if uneven:
+            # mean over ranks of per-rank mean losses: rank 0 = audio sample 0, rank 1 = text-only tail of sample 1
+            text = g["ids"][1:2, -40:].to(dev)
+            (0.5 * ref(**batch(slice(0, 1))).loss).backward()       # one forward / backward at a time: weight gradients accumulate in the arena
+            (0.5 * ref(input_ids=text, labels=text).loss).backward()
+        else:
+            ref(**batch(slice(0, 2))).loss.backward()
+        ref_grads = ref.arena.grads.clone()
+        ropt.step()
+        m.zero_grad()
+        if ov is not None:
+            ov.begin_step()
+        else:
+            eng.begin_backward()
+        if uneven and rank == 1:
+            out = m(input_ids=text, labels=text)
+        else:
+            out = m(**batch(mine))
+        out.loss.backward()
+        if ov is not None:
+            ov.finish()
+        else:
+            eng.finish()
+            opt.step(grad_scale=eng.grad_scale, gates=eng.bucket_gate)
+        torch.cuda.synchronize()
+        issued = [None] * world
+        dist.all_gather_object(issued, list(eng.issued))
+        assert all(o == issued[0] for o in issued), ("collective order differs across ranks", issued)
+        assert sorted(issued[0]) == list(range(len(m.arena.bucket_names))), issued[0]
+        assert eng.bucket_gate.tolist() == [1] * len(m.arena.bucket_names), eng.bucket_gate.tolist()
+        # averaged DP gradient == single-process gradient of the global mean loss
+        gr = rel(m.arena.grads.float() * eng.grad_scale, ref_grads)
+        # step 0 starts from bit-identical parameters (summation-order noise only: 2e-2); later steps start from parameters that already
+        # differ by AdamW's sign-flip noise (next assert), which the gradient inherits
+        assert gr <= (2e-2 if step == 0 else 6e-2), (mode, step, "grad rel-L2", gr)
+        # AdamW normalises the update (|m/sqrt(v)| ~ 1): a bf16-noise sign flip of a near-zero gradient moves a weight by up to 2*lr
+        dp = (m.arena.params.float() - ref.arena.params.float()).abs()
+        assert float(dp.max()) <= 2.5 * LR * (step + 1) + 2 ** -7, (mode, step, float(dp.max()))
+        assert float(dp.mean()) <= 0.2 * LR, (mode, step, float(dp.mean()))
+        # replicas stay identical
+        chk = torch.stack([m.arena.params.float().sum(), m.arena.params.float().abs().sum()]).cpu()
+        allc = [None] * world
+        dist.all_gather_object(allc, chk.tolist())
+        assert all(c == allc[0] for c in allc), ("replicas diverged", allc)
+        report[f"{mode}_step{step}"] = {"grad_rel_l2": gr, "param_max_abs": float(dp.max()), "param_mean_abs": float(dp.mean()),
+                                        "loss": float(out.loss), "issued": issued[0][:4]}
+    m.arena.on_bucket_ready = None
+dist.barrier()
+if rank == 0:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"dp_equivalence_{backend}.json"), "w") as f:
+        json.dump(report, f, indent=1)
+dist.destroy_process_group()
+print("DP_OK", rank, flush=True)
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(backend, world=2, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER, ROOT, backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, _ = p.communicate(timeout=timeout)
+            outs.append(o)
+    finally:
+        for p in procs:  # exact PIDs we started
+            if p.poll() is None:
+                p.kill()
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"DP_OK {r}" in o, f"rank {r} failed (rc {p.returncode}):\n{o[-4000:]}"
+
+
+def test_dp_two_ranks_one_gpu_gloo(dev):
+    _run("gloo")
+
+
+def test_dp_two_ranks_rccl(dev):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box): RCCL over xGMI")
+    _run("nccl")

@@ -1,0 +1,221 @@
+"""Parity at the widths the benchmark actually runs.
+
+The tiny64 goldens run the encoder at head_dim 32 (old attention.hip) and every GEMM on the 128x128 / split-K kernels, so
+the bench's hot kernels never saw a value check.  Here:
+  * a full-WIDTH, depth-reduced AF3 (1 encoder + 1 decoder layer at hidden 1280 / 3584, 20x64 and 28:4x128 heads, ffn 5120 /
+    18944, vocab 152 064, S = 1024, one 30 s window per sample, B = 4) - HIP model vs oracle/af3_oracle.py (fp32 CPU) forward AND
+    backward, every parameter gradient; the launch counters prove that gemm_nt_bf16_k256, gemm_xt_bf16_k256<TN>, the D = 64 and
+    D = 128 LDS attention kernels and the GQA group-7 split + gqa_reduce path served it;
+  * op level, against plain fp32 torch on the device: attention forward + backward VALUES at the AF3 decoder shapes
+    (8, 1024, 28, 4, 128, causal) and (1, 7774, 28, 4, 128, causal: ragged last 64-tile, heavy-first ordering), encoder shape
+    (8, 1500, 20, 20, 64); the headline GEMM shapes on sampled rows (NT 8192x37888x3584, 4096x152064x3584, 8192x3584x18944;
+    TN wgrad 37888x3584x8192, 3584x3584x8192, 152064x3584x4096).
+Tolerances are the ones of tests/test_ops_gpu.py / tests/test_model_gpu.py (written next to each assert).
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-20))
+
+
+def _rand(shape, dev, scale=1.0, seed=0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return torch.randn(shape, generator=g, device=dev) * scale
+
+
+# ------------------------------------------------------------------------------------------------ model level
+def test_fullwidth_depth_reduced_model_vs_oracle(dev):
+    import bench
+    from audio_flamingo_amd import ops
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+    from oracle import af3_oracle as O
+
+    cfg = bench.af3_7b_config(enc_layers=1, dec_layers=1)
+    m = Mine(cfg, device=dev, init_seed=3)
+    # biases / norm weights off their trivial init so that every gradient path carries signal
+    g = torch.Generator(device=dev).manual_seed(4)
+    with torch.no_grad():
+        for blk in m.arena.order:
+            if blk.key.endswith(".bias"):
+                blk.data.copy_((0.02 * torch.randn(blk.shape, device=dev, generator=g)).to(BF))
+            elif blk.key.endswith("norm.weight"):
+                blk.data.copy_((1 + 0.05 * torch.randn(blk.shape, device=dev, generator=g)).to(BF))
+        E = m.E
+        m.arena["model.audio_tower.layers.0.self_attn.qkv.bias"].data[E: 2 * E].zero_()  # k_proj has no bias
+    m.arena.step_counter += 1
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+
+    B, S = 4, 1024  # 4096 decoder rows / 6000 encoder rows: enough 256x256 tiles that the bench's kernel choices apply
+    gen = torch.Generator().manual_seed(11)
+    feats = (torch.randn(B, 128, 3000, generator=gen) * 0.5).to(BF)
+    ids = torch.randint(0, 151643, (B, S), generator=gen)
+    ids[:, 9: 9 + 750] = bench.AUDIO_ID
+    labels = ids.clone()
+    labels[:, : S - 256] = -100
+
+    ops.kernel_counts(reset=True)
+    m.zero_grad()
+    out = m(input_ids=ids.to(dev), input_features=feats.to(dev), labels=labels.to(dev), return_logits=True)
+    out.loss.backward()
+    m.arena.join_streams()
+    torch.cuda.synchronize()
+    cnt = ops.kernel_counts()
+    # the bench's hot kernels, not their small-shape stand-ins
+    assert cnt["gemm_nt256"] >= 10 and cnt["gemm_tn256"] >= 6, cnt
+    assert cnt["attn2_fwd_d64"] == 1 and cnt["attn2_fwd_d128"] == 1 and cnt["attn2_bwd_d64"] == 1 and cnt["attn2_bwd_d128"] == 1, cnt
+    assert cnt["gqa_reduce"] == 1 and cnt["attn1_fwd"] == 0 and cnt["xattn_fwd"] == 0, cnt
+
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    torch.set_num_threads(os.cpu_count() or 8)
+    ref = O.forward(leaves, dict(enc_heads=20, heads=28, kv_heads=4, eps=1e-6, theta=1e6, audio_token_id=bench.AUDIO_ID),
+                    ids, feats.float(), None, labels=labels)
+    ref["loss"].backward()
+
+    rep = {"loss": float(out.loss), "loss_ref": float(ref["loss"])}
+    assert abs(rep["loss"] - rep["loss_ref"]) <= 1e-2, rep                                  # tests/test_model_gpu.py: loss |d| <= 1e-2
+    sel = labels != -100
+    lg = out.logits.float().cpu()[sel]
+    rl = ref["logits"].detach()[sel]
+    rep["logits_max_err"] = float((lg - rl).abs().max())
+    rep["logits_ref_absmax"] = float(rl.abs().max())
+    assert rep["logits_max_err"] <= 4e-2 * max(1.0, rep["logits_ref_absmax"]), rep          # LOGIT_TOL of test_model_gpu (logit scale ~1)
+    top2 = rl.topk(2, -1).values
+    conf = (top2[:, 0] - top2[:, 1]) > 2 * 4e-2
+    rep["n_confident"] = int(conf.sum())
+    assert int((lg.argmax(-1)[conf] != rl.argmax(-1)[conf]).sum()) == 0, rep
+    params = dict(m.named_parameters())
+    bad, worst = {}, 0.0
+    for k, v in leaves.items():
+        if v.grad is None:
+            continue
+        if not params[k].requires_grad:   # embed_positions is frozen in the reference (modeling_audioflamingo3.py:332)
+            continue
+        got = params[k].grad
+        assert got is not None, k
+        r = _rel(got, v.grad)
+        worst = max(worst, r)
+        if r > 6e-2:                                                                          # test_model_gpu: grad rel-L2 <= 6e-2 (bf16 gradient storage)
+            bad[k] = r
+    rep["grad_rel_l2_worst"] = worst
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+
+    with open(os.path.join(ROOT, "gpurun_out", "fullwidth_parity_report.json"), "w") as f:
+        json.dump({**rep, "kernel_counts": cnt, "bad": bad}, f, indent=1)
+    assert not bad, (bad, rep)
+
+
+# ------------------------------------------------------------------------------------------------ attention values at the AF3 shapes
+def _attn_ref(q, k, v, do, scale, causal):
+    """fp32 torch reference for one sample: q [Hq, S, D], k / v [Hkv, S, D] -> o, dq, dk, dv (GQA by repeat)"""
+    Hq, S, D = q.shape
+    g = Hq // k.shape[0]
+    q, k, v = q.float().requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True)
+    kk, vv = k.repeat_interleave(g, 0), v.repeat_interleave(g, 0)
+    s = (q @ kk.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(~torch.ones(S, S, dtype=torch.bool, device=q.device).tril(), float("-inf"))
+    o = torch.softmax(s, -1) @ vv
+    o.backward(do.float())
+    return o.detach(), q.grad, k.grad, v.grad
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,causal,samples", [
+    (8, 1024, 28, 4, 128, True, (0, 5)),        # decoder, bench shape: GQA group 7, split-head sweep + gqa_reduce
+    (1, 7774, 28, 4, 128, True, (0,)),          # long-audio decoder: ragged last tile, 61 query blocks heavy-first
+    (8, 1500, 20, 20, 64, False, (3,)),         # encoder, bench shape (S not a multiple of 64)
+])
+def test_attention_values_at_af3_shapes(dev, B, S, Hq, Hkv, D, causal, samples):
+    from audio_flamingo_amd import ops
+
+    ld = (Hq + 2 * Hkv) * D
+    qkv = (_rand((B * S, ld), dev, 1.0, seed=S) * 1.0).to(BF)
+    do = _rand((B * S, Hq * D), dev, 1.0, seed=S + 1).to(BF)
+    scale = D ** -0.5
+    ops.kernel_counts(reset=True)
+    o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=causal)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=causal)
+    torch.cuda.synchronize()
+    cnt = ops.kernel_counts()
+    fam = "d128" if D == 128 else "d64"
+    assert cnt[f"attn2_fwd_{fam}"] == 1 and cnt[f"attn2_bwd_{fam}"] == 1 and cnt["gqa_reduce"] == (1 if Hq != Hkv else 0), cnt
+    for b in samples:
+        rows = slice(b * S, (b + 1) * S)
+        q = qkv[rows, : Hq * D].reshape(S, Hq, D).transpose(0, 1)
+        k = qkv[rows, Hq * D: (Hq + Hkv) * D].reshape(S, Hkv, D).transpose(0, 1)
+        v = qkv[rows, (Hq + Hkv) * D:].reshape(S, Hkv, D).transpose(0, 1)
+        dor = do[rows].reshape(S, Hq, D).transpose(0, 1)
+        # one kv head and its query group at a time keeps the fp32 S x S reference small (7 x 7774^2 x 4 B = 1.7 GB)
+        g = Hq // Hkv
+        for hk in ((0, Hkv - 1) if Hkv > 1 else (0,)):
+            hq = slice(hk * g, (hk + 1) * g)
+            ro, rdq, rdk, rdv = _attn_ref(q[hq], k[hk: hk + 1], v[hk: hk + 1], dor[hq], scale, causal)
+            go = o[rows].reshape(S, Hq, D).transpose(0, 1)[hq].float()
+            gdq = dqkv[rows, : Hq * D].reshape(S, Hq, D).transpose(0, 1)[hq].float()
+            gdk = dqkv[rows, Hq * D: (Hq + Hkv) * D].reshape(S, Hkv, D).transpose(0, 1)[hk: hk + 1].float()
+            gdv = dqkv[rows, (Hq + Hkv) * D:].reshape(S, Hkv, D).transpose(0, 1)[hk: hk + 1].float()
+            # tests/test_ops_gpu.py::test_attention bars: forward 2e-2 abs / 2e-2 rel; gradients rel-L2 <= 3e-2 per tensor
+            assert float((go - ro).abs().max()) <= 2e-2 + 2e-2 * float(ro.abs().max()), ("o", b, hk)
+            for name, got, ref_ in (("dq", gdq, rdq), ("dk", gdk, rdk), ("dv", gdv, rdv)):
+                r = float((got - ref_).norm() / ref_.norm())
+                assert r <= 3e-2, (name, b, hk, r)
+            del ro, rdq, rdk, rdv
+            torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------------ headline GEMM shapes, sampled rows
+def _rows(M, n=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randperm(M, generator=g)[: n - 4].tolist()
+    return sorted(set(r + [0, 255, 256, M - 1]))  # tile edges included
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 37888, 3584), (4096, 152064, 3584), (8192, 3584, 18944), (8192, 4608, 3584), (12000, 5120, 1280)])
+def test_gemm_nt_headline_shapes_sampled_rows(dev, M, N, K):
+    """gate|up, lm_head chunk, down_proj, decoder qkv, encoder fc1 - the bench's NT launches - against fp32 on 64 sampled rows"""
+    from audio_flamingo_amd import ops
+
+    a = (_rand((M, K), dev, 1.0, seed=1)).to(BF)
+    b = (_rand((N, K), dev, 1.0, seed=2)).to(BF)
+    bias = _rand((N,), dev, 1.0, seed=3).to(BF)
+    ops.kernel_counts(reset=True)
+    c = ops.gemm_nt(a, b, bias=bias)
+    torch.cuda.synchronize()
+    cnt = ops.kernel_counts()
+    assert cnt["gemm_nt256"] == 1 and cnt["gemm_nt128"] == 0, cnt
+    rows = torch.tensor(_rows(M), device=dev)
+    ref = a[rows].float() @ b.float().t() + bias.float()
+    err = (c[rows].float() - ref).abs()
+    tol = 0.02 * math.sqrt(K) + 1e-2 * ref.abs()          # tests/test_ops_gpu.py::test_gemm_plain
+    assert bool((err <= tol).all()), (float(err.max()), float(ref.abs().max()))
+    assert torch.equal(ops.gemm_nt(a, b, bias=bias), c), "non-deterministic GEMM result"
+
+
+@pytest.mark.parametrize("M,N,K", [(37888, 3584, 8192), (3584, 3584, 8192), (3584, 18944, 8192), (152064, 3584, 4096), (5120, 1280, 12000)])
+def test_gemm_tn_wgrad_headline_shapes_sampled_rows(dev, M, N, K):
+    """dW[M,N] = dY[K,M]^T . X[K,N]: gate|up, o_proj, down_proj, lm_head, encoder fc1 weight gradients as the step launches them"""
+    from audio_flamingo_amd import ops
+
+    at = _rand((K, M), dev, 1.0, seed=5).to(BF)
+    bt = _rand((K, N), dev, 1.0, seed=6).to(BF)
+    ops.kernel_counts(reset=True)
+    c = ops.gemm(at, bt, trans_a=True, trans_b=True)
+    torch.cuda.synchronize()
+    cnt = ops.kernel_counts()
+    assert cnt["gemm_tn256"] == 1, cnt
+    rows = torch.tensor(_rows(M, seed=1), device=dev)
+    ref = at[:, rows].float().t() @ bt.float()
+    err = (c[rows].float() - ref).abs()
+    tol = 0.02 * math.sqrt(K) + 1e-2 * ref.abs()          # tests/test_ops_gpu.py::test_gemm_tn_wgrad_form
+    assert bool((err <= tol).all()), (float(err.max()), float(ref.abs().max()))
+    assert torch.equal(ops.gemm(at, bt, trans_a=True, trans_b=True), c), "non-deterministic TN GEMM result"

@@ -30,28 +30,40 @@ def _hf_model(cfg_dict, dev, state=None, seed=0):
     return m.to(dev).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("case", ["A", "B"])
+@pytest.mark.parametrize("case", ["A", "B", "C"])
 def test_reference_model_with_afk_attention_vs_golden(dev, case):
+    """the reference's own bf16 model on this device, attention through libafk.so, against the fp32 golden - beside the SAME model with its
+    stock sdpa attention (the bf16 noise floor of these trained, sharp-softmax goldens): the plugin run may deviate from the golden by the
+    bars of tests/_tol.py or by 2x what the stock run deviates, whichever is larger"""
     from audio_flamingo_amd import hf_plugin
+    from tests._tol import GRAD_REL_L2, LOSS_ATOL, logit_tol
     from tests.test_host_cpu import TINY
 
     name = hf_plugin.register()
     g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
     m = _hf_model(TINY, dev, torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
-    m.set_attn_implementation(name)
     m.train()
-    att = g["att"].to(dev) if case == "B" else None
-    out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
-            attention_mask=att, labels=g["labels"].to(dev))
-    out.loss.backward()
-    torch.cuda.synchronize()
-    assert abs(float(out.loss.detach()) - float(g["loss"])) <= 1e-2
-    assert hf_plugin.calls["interval"] + hf_plugin.calls["lds"] >= 4  # 2 encoder + 2 decoder layers went through libafk.so
+    att = g["att"].to(dev) if case != "A" else None
     sel = g["labels"] != -100
-    err = float((out.logits.float().cpu()[sel] - g["logits_bf16"].float()).abs().max())
-    assert err <= 4e-2, err
-    params = dict(m.named_parameters())
-    bad = {k: _rel(params[k].grad, v) for k, v in g["grads"].items() if _rel(params[k].grad, v) > 6e-2}
+    res = {}
+    for impl in ("sdpa", name):
+        m.set_attn_implementation(impl)
+        m.zero_grad()
+        before = hf_plugin.calls["interval"] + hf_plugin.calls["lds"]
+        out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+                attention_mask=att, labels=g["labels"].to(dev))
+        out.loss.backward()
+        torch.cuda.synchronize()
+        if impl == name:
+            assert hf_plugin.calls["interval"] + hf_plugin.calls["lds"] - before >= 4  # 2 encoder + 2 decoder layers went through libafk.so
+        params = dict(m.named_parameters())
+        res[impl] = dict(loss=abs(float(out.loss.detach()) - float(g["loss"])),
+                         logit=float((out.logits.float().cpu()[sel] - g["logits_bf16"].float()).abs().max()),
+                         grads={k: _rel(params[k].grad, v) for k, v in g["grads"].items()})
+    floor, got = res["sdpa"], res[name]
+    assert got["loss"] <= max(LOSS_ATOL, 2 * floor["loss"]), (got, floor)
+    assert got["logit"] <= max(logit_tol(g["logits_absmax"]), 2 * floor["logit"]), (got["logit"], floor["logit"])
+    bad = {k: (v, floor["grads"][k]) for k, v in got["grads"].items() if v > max(GRAD_REL_L2, 2 * floor["grads"][k])}
     assert not bad, bad
 
 

@@ -136,6 +136,34 @@ with eng.no_sync():
     eng.finish()
 assert float(a.order[0].grad.float().mean()) == float(rank + 1)
 assert abs(eng.grad_scale - 1.0 / world) < 1e-12
+# uneven step (ADVICE r01): rank 1's batch has no audio -> its backward never touches the audio tower / projector buckets.  Every rank
+# must still issue the SAME collectives in the SAME order, stale slices must not leak in, and the "touched by any rank" gate must be 1.
+audio = lambda b: b.key.startswith("model.audio_tower") or b.key.startswith("model.multi_modal_projector")
+for blk in a.order:
+    blk.grad.fill_(7.0)                      # stale values from "the previous step"
+a.zero_grad(); eng.begin_backward()
+for blk in reversed(a.order):
+    if rank == 1 and audio(blk):
+        continue
+    blk.grad.fill_(1.0); a.grad_written(blk)
+eng.finish()
+orders = [None] * world
+dist.all_gather_object(orders, list(eng.issued))
+assert all(o == orders[0] for o in orders), orders
+assert orders[0] == list(reversed(range(len(a.bucket_names)))), orders[0]
+for blk in a.order:
+    want = 1.0 if audio(blk) else float(world)
+    assert float(blk.grad.float().min()) == want == float(blk.grad.float().max()), (blk.key, float(blk.grad.float().mean()))
+assert eng.bucket_gate.tolist() == [1] * len(a.bucket_names)
+# nobody touches the audio side (text-only step everywhere): gate 0 there -> the optimizer leaves those buckets alone
+a.zero_grad(); eng.begin_backward()
+for blk in reversed(a.order):
+    if not audio(blk):
+        blk.grad.fill_(1.0); a.grad_written(blk)
+eng.finish()
+gate = eng.bucket_gate.tolist()
+for i, name in enumerate(a.bucket_names):
+    assert gate[i] == (0 if (name.startswith("enc") or name == "stem") else 1), (name, gate[i])
 dist.destroy_process_group()
 print("OK", rank)
 '''

@@ -1,11 +1,9 @@
 """Model-level parity on MI355X: the HIP path (through the C ABI) against the golden vectors produced by the live
 reference implementation and against the CPU oracle restatement on the same seeded inputs.
 
-Tolerances (north_star: "token indices bit-exact, logits within a stated fp tolerance"):
-  * reference = fp32 CPU on bf16-rounded weights; ours = bf16 storage / fp32 accumulate.
-  * loss: |d| <= 1e-2;  logits: max |d| <= 4e-2 (logit scale ~1) ; audio features: rel-L2 <= 2e-2
-  * greedy token ids: equal wherever the reference's top-1/top-2 gap exceeds 2x the logit tolerance; generate() ids equal
-  * gradients: relative L2 error per tensor <= 6e-2 (bf16 gradient storage, eps 2^-8 per element)
+Tolerances: tests/_tol.py (loss |d| <= 1e-2; logits max |d| <= 2^-6 x max(1, |ref|max); audio rows rel-L2 <= 2e-2; greedy token
+ids equal wherever the reference's top-1/top-2 gap exceeds 2x the logit bar - >= 97 % of the valid positions on the trained
+round-2 goldens -; generate() ids identical; parameter gradients rel-L2 <= 6e-2 per tensor).
 """
 import json
 import os
@@ -17,7 +15,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-LOGIT_TOL = 4e-2
+from tests._tol import AUDIO_REL_L2, GRAD_REL_L2, LOSS_ATOL, logit_tol
+
+LOGIT_TOL = 4e-2  # absolute bar used only where the logits are O(1) (random-init comparisons against the oracle)
 REPORT = {}
 
 
@@ -36,6 +36,14 @@ def _model(dev):
     return m
 
 
+def _fresh_model(dev, seed=7):
+    """random-init weights N(0, 0.02) (logits O(1), smooth loss surface): for the checks that are about plumbing (ragged windows, long
+    sequences, optimizer trajectories), where the sharp trained goldens would only add softmax sensitivity"""
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    return Mine(_cfg(), device=dev, init_seed=seed)
+
+
 def _rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-12))
@@ -47,43 +55,102 @@ def _dump():
         json.dump(REPORT, f, indent=1)
 
 
-@pytest.mark.parametrize("case", ["A", "B"])
-def test_forward_backward_vs_reference_golden(dev, case):
-    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
-    m = _model(dev)
-    m.zero_grad()
-    att = g["att"].to(dev) if case == "B" else None
-    out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
-            attention_mask=att, labels=g["labels"].to(dev), return_logits=True)
+def _ref_bf16(dev):
+    """the reference's OWN implementation in bf16 on this device (eager PyTorch-ROCm, sdpa): its deviation from its fp32 CPU run is the
+    noise floor every bf16 implementation of this model lives on"""
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    ref_m = AudioFlamingo3ForConditionalGeneration(_cfg())
+    ref_m.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    return ref_m.to(dev).to(torch.bfloat16).train()
+
+
+def _stats(err):
+    err = err.float().abs().flatten()
+    return {"max": float(err.max()), "rms": float(err.pow(2).mean().sqrt()), "p999": float(err.kthvalue(max(1, int(0.999 * err.numel()))).values)}
+
+
+def _floor(ref_m, g, dev):
+    """reference-bf16-on-device vs the fp32 golden: logit error stats on the label rows, argmax mismatches, gradient rel-L2 per stored tensor"""
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+              attention_mask=g["att"].to(dev), labels=g["labels"].to(dev))
+    ref_m.zero_grad()
+    out = ref_m(**kw)
     out.loss.backward()
-    torch.cuda.synchronize()
+    sel, keep = g["labels"] != -100, g["att"].bool()
+    lg = out.logits.float().cpu()
+    params = dict(ref_m.named_parameters())
+    return {"logits": _stats(lg[sel] - g["logits_bf16"].float()), "argmax_mismatch_all_valid": int((lg.argmax(-1)[keep] != g["argmax"][keep]).sum()),
+            "loss": float(out.loss.detach()), "grad_rel_l2": {k: _rel(params[k].grad, v) for k, v in g["grads"].items()}}
+
+
+def _golden_compare(g, out, m):
+    """-> report dict of one golden case (loss / logits / argmax / audio rows / gradients)"""
     rep = {"loss": float(out.loss), "loss_ref": float(g["loss"])}
     sel = g["labels"] != -100
     lg = out.logits.float().cpu()
     ref = g["logits_bf16"].float()
-    rep["logits_max_err"] = float((lg[sel] - ref).abs().max())
-    rep["logits_ref_absmax"] = float(ref.abs().max())
+    tol = logit_tol(g["logits_absmax"])
+    rep["logit_tol"] = tol
+    rep["logits"] = _stats(lg[sel] - ref)
+    rep["logits_ref_absmax"] = float(g["logits_absmax"])
     keep = g["att"].bool()
-    confident = (g["top_gap"] > 2 * LOGIT_TOL) & keep
+    confident = (g["top_gap"] > 2 * tol) & keep
     am = lg.argmax(-1)
     rep["argmax_mismatch_confident"] = int((am[confident] != g["argmax"][confident]).sum())
     rep["argmax_mismatch_all_valid"] = int((am[keep] != g["argmax"][keep]).sum())
-    rep["n_confident"] = int(confident.sum())
-    # audio rows: compare the rows the placeholders consume
+    rep["n_confident"], rep["n_valid"] = int(confident.sum()), int(keep.sum())
     n_tok = ((g["fmask"].sum(-1) - 1) // 2 + 1 - 2) // 2 + 1
     rows = torch.cat([out.audio_hidden_states.float().cpu()[w * 750: w * 750 + int(n)] for w, n in enumerate(n_tok)])
     rep["audio_rel_l2"] = _rel(rows, g["audio_bf16"])
     params = dict(m.named_parameters())
     rep["grad_rel_l2"] = {k: _rel(params[k].grad, v) for k, v in g["grads"].items()}
     rep["grad_norm_ratio"] = {k: float(params[k].grad.float().norm()) / max(g["grad_norms"][k], 1e-12) for k in g["grads"]}
-    REPORT[f"case{case}"] = rep
-    _dump()
-    assert abs(rep["loss"] - rep["loss_ref"]) <= 1e-2, rep
-    assert rep["logits_max_err"] <= LOGIT_TOL, rep
+    return rep
+
+
+def _golden_assert(rep, floor):
+    """absolute bars of tests/_tol.py, each relaxed to 2x the reference's own bf16 noise floor where that is higher: on the TRAINED goldens the
+    softmax is sharp, so bf16 noise in a handful of high-loss positions moves the loss gradient by tens of percent in ANY bf16
+    implementation (the floor shows it); nothing is ever looser than 2x what the reference's bf16 run does on the same inputs"""
+    assert abs(rep["loss"] - rep["loss_ref"]) <= max(LOSS_ATOL, 2 * abs(floor["loss"] - rep["loss_ref"])), (rep, floor)
+    assert rep["logits"]["rms"] <= 2 * floor["logits"]["rms"] + 1e-3, (rep["logits"], floor["logits"])
+    assert rep["logits"]["max"] <= max(rep["logit_tol"], 2 * floor["logits"]["max"]), (rep["logits"], floor["logits"], rep["logit_tol"])
+    assert rep["n_confident"] >= 0.95 * rep["n_valid"], rep          # the token-id check covers (nearly) every position
     assert rep["argmax_mismatch_confident"] == 0, rep
-    assert rep["audio_rel_l2"] <= 2e-2, rep
-    bad = {k: v for k, v in rep["grad_rel_l2"].items() if v > 6e-2}
-    assert not bad, rep
+    assert rep["argmax_mismatch_all_valid"] <= floor["argmax_mismatch_all_valid"] + 1, (rep, floor)
+    assert rep["audio_rel_l2"] <= AUDIO_REL_L2, rep
+    bad = {k: (v, floor["grad_rel_l2"][k]) for k, v in rep["grad_rel_l2"].items() if v > max(GRAD_REL_L2, 2 * floor["grad_rel_l2"][k])}
+    assert not bad, (bad, rep)
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C"])
+def test_forward_backward_vs_reference_golden(dev, case):
+    """A: full windows; B: padded window + RIGHT-padded row (kv_len path); C: the batch the reference's own AudioFlamingo3Processor
+    builds - LEFT padded (interval attention path), labels from output_labels=True - handed over as the processor hands it (CPU tensors).
+    Every figure is reported beside the reference's own bf16-on-device run against the same fp32 golden (noise floor)."""
+    from audio_flamingo_amd import ops
+
+    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
+    m = _model(dev)
+    m.zero_grad()
+    ops.kernel_counts(reset=True)
+    if case == "C":
+        out = m(input_ids=g["ids"], input_features=g["feats"], input_features_mask=g["fmask"], attention_mask=g["att"], labels=g["labels"],
+                return_logits=True)
+    else:
+        att = g["att"].to(dev) if case == "B" else None
+        out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+                attention_mask=att, labels=g["labels"].to(dev), return_logits=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    cnt = ops.kernel_counts()
+    assert (cnt["xattn_fwd"] >= 2 and cnt["xattn_bwd"] >= 2) if case == "C" else cnt["xattn_fwd"] == 0, cnt
+    rep = _golden_compare(g, out, m)
+    floor = _floor(_ref_bf16(dev), g, dev)
+    REPORT[f"case{case}"] = {"ours": rep, "reference_bf16_on_device": floor}
+    _dump()
+    _golden_assert(rep, floor)
 
 
 def test_against_cpu_oracle_fresh_inputs(dev):
@@ -91,8 +158,8 @@ def test_against_cpu_oracle_fresh_inputs(dev):
     from oracle import af3_oracle as O
 
     torch.manual_seed(5)
-    sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
-    m = _model(dev)
+    m = _fresh_model(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     feats = (torch.randn(3, 128, 3000) * 0.5).to(torch.bfloat16)
     fmask = torch.ones(3, 3000, dtype=torch.int32)
     fmask[1, 1000:] = 0  # 1000 frames -> 250 tokens
@@ -118,11 +185,35 @@ def test_against_cpu_oracle_fresh_inputs(dev):
         m(input_ids=bad.to(dev), input_features=feats.to(dev), input_features_mask=fmask.to(dev))
 
 
-def test_generate_greedy_ids_bit_exact(dev):
+N_GEN = 24
+
+
+def _gen_prompt(g):
+    n0 = g["generate"].shape[1] - N_GEN
+    return g["generate"][:1, :n0]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_generate_greedy_ids_bit_exact(dev, use_graph):
+    """24 greedy tokens of the trained tiny model (non-constant: they walk the permutation chain) against the live reference's
+    generate(); with and without the HIP-graph replay of the decode step (the captured step for t == 2 was never executed,
+    which a constant-token golden could not see)"""
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    assert len(set(g["generate"][0, -N_GEN:].tolist())) >= 12
     m = _model(dev)
-    ids = m.generate(g["ids"][:1].to(dev), input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=4)
+    ids = m.generate(_gen_prompt(g).to(dev), input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev),
+                     max_new_tokens=N_GEN, use_graph=use_graph)
     assert ids.cpu().tolist() == g["generate"].tolist()
+
+
+def test_generate_left_padded_processor_batch_bit_exact(dev):
+    """case C: the processor's left-padded two-row batch, 24 new tokens per row, against the live reference's generate()"""
+    g = torch.load(os.path.join(G, "tiny64_caseC.pt"))
+    m = _model(dev)
+    for use_graph in (False, True):
+        ids = m.generate(g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev),
+                         attention_mask=g["att"].to(dev), max_new_tokens=N_GEN, use_graph=use_graph)
+        assert ids.cpu().tolist() == g["generate"].tolist(), use_graph
 
 
 def test_grad_accumulation_and_optimizer_step(dev):
@@ -143,7 +234,8 @@ def test_grad_accumulation_and_optimizer_step(dev):
     (m(**kw).loss * 0.5).backward()
     rel = float((m.arena.grads.float() - 0.5 * g1).norm() / (0.5 * g1).norm())
     assert rel < 2e-2, rel
-    # a few optimizer steps reduce the loss on the fixed batch
+    # a few optimizer steps reduce the loss on the fixed batch (random-init weights: the trained goldens sit at their optimum)
+    m = _fresh_model(dev)
     opt = FusedAdamW(m.arena, lr=2e-3)
     losses = []
     for _ in range(4):
@@ -155,6 +247,63 @@ def test_grad_accumulation_and_optimizer_step(dev):
     REPORT["train_losses"] = losses
     _dump()
     assert losses[-1] < losses[0] - 0.05, losses
+
+
+def test_text_only_step_leaves_the_audio_tower_untouched(dev):
+    """zero_grad() only flips flags; a batch without audio never runs the audio tower, and its buckets must NOT be stepped
+    with the previous step's stale gradients (torch.optim skips parameters whose grad is None) - serial and overlapped schedules"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import BackwardOverlap
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    audio_kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    text_ids = g["ids"][:, -40:].to(dev)
+    text_kw = dict(input_ids=text_ids, labels=text_ids)
+    for overlapped in (False, True):
+        m = _model(dev)
+        opt = FusedAdamW(m.arena, lr=1e-3, weight_decay=0.01)
+        ov = BackwardOverlap(m.arena, opt) if overlapped else None
+        for kw in (audio_kw, text_kw):
+            before = m.arena.params.clone()
+            m_before, t_before = opt.m.clone(), opt.t
+            m.zero_grad()
+            if ov is not None:
+                ov.begin_step()
+            m(**kw).loss.backward()
+            if ov is not None:
+                ov.finish()
+            else:
+                opt.step()
+            torch.cuda.synchronize()
+            assert opt.t == t_before + 1
+            changed = {n: not torch.equal(m.arena.params[s:e], before[s:e]) for n, (s, e) in
+                       zip(m.arena.bucket_names, (m.arena.bucket_range(i) for i in range(len(m.arena.bucket_names))))}
+            audio_buckets = [n for n in changed if n.startswith("enc") or n == "stem"]
+            if kw is audio_kw:
+                assert all(changed.values()), changed
+            else:
+                assert not any(changed[n] for n in audio_buckets), {n: changed[n] for n in audio_buckets}
+                assert changed["dec0"] and changed["head"] and changed["embed"], changed
+                s, e = m.arena.bucket_range(m.arena.bucket_names.index("enc0"))
+                assert torch.equal(opt.m[s:e], m_before[s:e]), "moments of an untouched bucket moved"
+
+
+def test_optimizer_master_follows_load_state_dict(dev):
+    """parameters rewritten after the optimizer was built (load_state_dict) must not be overwritten by the stale fp32 master"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    m = Mine(_cfg(), device=dev, init_seed=5)          # random weights ...
+    opt = FusedAdamW(m.arena, lr=1e-4)                 # ... captured by the optimizer's master copy
+    m.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    ref = _model(dev)
+    ropt = FusedAdamW(ref.arena, lr=1e-4)
+    for mm, oo in ((m, opt), (ref, ropt)):
+        mm.zero_grad(); mm(**kw).loss.backward(); oo.step()
+    torch.cuda.synchronize()
+    assert torch.equal(m.arena.params, ref.arena.params)
 
 
 def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
@@ -187,14 +336,58 @@ def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
             assert torch.equal(ma.arena.shadow(k), mb.arena.shadow(k)), f"stale W^T shadow for {k}"
 
 
+def test_graphed_step_matches_eager(dev):
+    """graphs.GraphedTrainStep: the whole step (three streams, optimizer inside backward) captured once and replayed must leave
+    bit-identical parameters / optimizer state / loss to the eager step, step after step (lr and bias corrections come from device memory)"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import BackwardOverlap
+    from audio_flamingo_amd.graphs import GraphedTrainStep
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    ms, opts, ovs = [], [], []
+    for _ in range(2):
+        m = _model(dev)
+        m.check_placeholders = False
+        m.arena.enable_wgrad_stream(True)
+        o = FusedAdamW(m.arena, lr=1e-3, weight_decay=0.01)
+        ms.append(m), opts.append(o), ovs.append(BackwardOverlap(m.arena, o))
+
+    def body(i):
+        def f():
+            ms[i].zero_grad()
+            ovs[i].begin_step()
+            loss = ms[i](**kw).loss
+            loss.backward()
+            ovs[i].finish()
+            return loss
+        return f
+
+    eager = body(0)
+    gstep = GraphedTrainStep(ms[1], opts[1], ovs[1], body(1), warmup=2)
+    for _ in range(2):
+        eager()
+    for k in range(4):
+        opts[0].lr = opts[1].lr = 1e-3 * (1 + k)   # a schedule: must reach the captured AdamW launches
+        la, lb = eager(), gstep()
+        torch.cuda.synchronize()
+        assert float(la) == float(lb), (k, float(la), float(lb))
+        assert opts[0].t == opts[1].t
+        assert torch.equal(ms[0].arena.params, ms[1].arena.params), k
+        assert torch.equal(opts[0].m, opts[1].m) and torch.equal(opts[0].v, opts[1].v) and torch.equal(opts[0].master, opts[1].master), k
+    for key in ("model.language_model.layers.0.mlp.gate_up.weight", "model.audio_tower.conv2.weight"):
+        assert torch.equal(ms[0].arena.shadow(key), ms[1].arena.shadow(key)), f"stale W^T shadow for {key}"
+
+
 def test_generate_kv_cache_matches_prefix_recompute(dev):
     """the KV-cache decode path (prefill + Q=1 steps over the cache) against re-running the whole prefix through forward() each step"""
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
     m = _model(dev)
     kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=12)
-    a = m.generate(g["ids"][:1].to(dev), use_cache=True, **kw)
-    b = m.generate(g["ids"][:1].to(dev), use_cache=False, **kw)
+    a = m.generate(_gen_prompt(g).to(dev), use_cache=True, **kw)
+    b = m.generate(_gen_prompt(g).to(dev), use_cache=False, **kw)
     assert a.shape == b.shape and torch.equal(a, b), (a[:, -12:], b[:, -12:])
+    assert len(set(a[0, -12:].tolist())) >= 6  # non-degenerate tokens
 
 
 def test_generate_fused_decode_glue_matches_unfused(dev):
@@ -204,9 +397,9 @@ def test_generate_fused_decode_glue_matches_unfused(dev):
     m = _model(dev)
     kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=12)
     m.decode_fused_glue = True
-    a = m.generate(g["ids"][:1].to(dev), **kw)
+    a = m.generate(_gen_prompt(g).to(dev), **kw)
     m.decode_fused_glue = False
-    b = m.generate(g["ids"][:1].to(dev), **kw)
+    b = m.generate(_gen_prompt(g).to(dev), **kw)
     assert torch.equal(a, b), (a[:, -12:], b[:, -12:])
 
 
@@ -214,8 +407,8 @@ def test_generate_left_padded_batch_matches_single(dev):
     """two prompts of different length, LEFT padded into one batch (processor convention): each row must decode exactly as it does alone"""
     torch.manual_seed(3)
     m = _model(dev)
-    p0 = torch.randint(0, 1000, (1, 40))
-    p1 = torch.randint(0, 1000, (1, 23))
+    p0 = torch.randint(0, 256, (1, 40))
+    p1 = torch.randint(0, 256, (1, 23))
     alone = [m.generate(p.to(dev), max_new_tokens=8).cpu() for p in (p0, p1)]
     pad = 40 - 23
     ids = torch.cat([p0, torch.cat([torch.zeros(1, pad, dtype=torch.long), p1], 1)], 0)
@@ -245,8 +438,8 @@ def test_long_audio_shape_config5_like(dev):
     from oracle import af3_oracle as O
 
     torch.manual_seed(11)
-    sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
-    m = _model(dev)
+    m = _fresh_model(dev)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     m.gradient_checkpointing_enable()
     feats = (torch.randn(4, 128, 3000) * 0.5).to(torch.bfloat16)
     S = 9 + 3000 + 9 + 40
@@ -334,25 +527,50 @@ def test_music_flamingo_vs_reference_golden(dev):
 
 
 def test_hf_trainer_runs_unchanged_script(dev, tmp_path):
-    """a stock transformers.Trainer loop (AfkTrainer subclass: fused arena optimizer behind torch.optim.Optimizer, LR
-    scheduler, gradient clipping, gradient accumulation) fine-tunes the HIP model; optimizer state round-trips through state_dict"""
-    from transformers import TrainingArguments
+    """the SAME stock training script, run twice - (i) transformers.Trainer + torch.optim.AdamW on the reference model (fp32
+    CPU: the reference trajectory), (ii) AfkTrainer (fused arena optimizer behind torch.optim.Optimizer, LR scheduler, gradient clipping,
+    gradient accumulation 2) on the HIP model - from identical weights on identical data: the logged loss and gradient-norm trajectories
+    must agree step by step (bf16 forward/backward against fp32: |d loss| <= 3e-2, grad norm within 10 %), and the optimizer state must
+    round-trip through state_dict bit for bit."""
+    from transformers import AudioFlamingo3ForConditionalGeneration, Trainer, TrainingArguments
 
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
     from audio_flamingo_amd.trainer import AfkAdamW, AfkTrainer
 
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
-    m = _model(dev)
-    rows = [dict(input_ids=g["ids"][i % 2], input_features=g["feats"][i % 2], input_features_mask=g["fmask"][i % 2], labels=g["labels"][i % 2])
+    torch.manual_seed(0)
+    ref = AudioFlamingo3ForConditionalGeneration(_cfg())
+    with torch.no_grad():
+        for p_ in ref.parameters():
+            p_.copy_(p_.to(torch.bfloat16).float())   # both sides start from the same bf16-representable weights (random init: smooth loss surface)
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    rows = [dict(input_ids=g["ids"][i % 2], input_features=g["feats"][i % 2].float(), input_features_mask=g["fmask"][i % 2], labels=g["labels"][i % 2])
             for i in range(16)]
-    args = TrainingArguments(output_dir=str(tmp_path), per_device_train_batch_size=2, gradient_accumulation_steps=2, max_steps=4,
-                             learning_rate=2e-3, lr_scheduler_type="linear", warmup_steps=1, logging_steps=1, save_strategy="no",
-                             report_to=[], remove_unused_columns=False, dataloader_pin_memory=False, max_grad_norm=1.0, seed=0)
-    tr = AfkTrainer(model=m, args=args, train_dataset=rows)
-    out = tr.train()
+
+    def targs(out, **kw):
+        return TrainingArguments(output_dir=str(out), per_device_train_batch_size=2, gradient_accumulation_steps=2, max_steps=4,
+                                 learning_rate=2e-3, weight_decay=0.01, lr_scheduler_type="linear", warmup_steps=1, logging_steps=1,
+                                 save_strategy="no", report_to=[], remove_unused_columns=False, dataloader_pin_memory=False, max_grad_norm=1.0,
+                                 seed=0, **kw)
+
+    rt = Trainer(model=ref, args=targs(tmp_path / "ref", use_cpu=True), train_dataset=rows)
+    rt.train()
+    ref_log = [(h["loss"], h["grad_norm"]) for h in rt.state.log_history if "loss" in h]
+
+    m = Mine(_cfg(), device=dev, init_seed=None)
+    m.load_state_dict(sd0)
+    tr = AfkTrainer(model=m, args=targs(tmp_path / "afk"), train_dataset=rows)
+    tr.train()
     opt = getattr(tr.optimizer, "optimizer", tr.optimizer)  # accelerate wraps it in AcceleratedOptimizer
     assert isinstance(opt, AfkAdamW) and opt.fused.t == 4
-    losses = [h["loss"] for h in tr.state.log_history if "loss" in h]
-    assert len(losses) == 4 and losses[-1] < losses[0] - 0.05, losses
+    log = [(h["loss"], h["grad_norm"]) for h in tr.state.log_history if "loss" in h]
+    REPORT["trainer_trajectory"] = {"reference_fp32_cpu": ref_log, "afk_bf16_mi355x": log}
+    _dump()
+    assert len(log) == len(ref_log) == 4, (log, ref_log)
+    for (l, gn), (rl, rgn) in zip(log, ref_log):
+        assert abs(l - rl) <= 3e-2, (log, ref_log)
+        assert abs(gn - rgn) <= 0.10 * rgn + 1e-3, (log, ref_log)
+    assert log[-1][0] < log[0][0], log
     # checkpoint / resume of the optimizer: state_dict round trip reproduces the next step bit for bit
     sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in opt.state_dict()["state"].items()}
     pg = opt.state_dict()["param_groups"]

@@ -1,4 +1,5 @@
-"""GEMM microbenchmark on the AF3-7B shapes (random data, guide rule 25): both kernel variants, HIP-event timed through afk_prof_*."""
+"""GEMM microbenchmark on the AF3-7B shapes (random data, guide rule 25): the two 256x256 NT kernels (v2 = 8-wave ping-pong, v3 = 4-wave
+128x128 per wave), HIP-event timed through afk_prof_*.   python tools/bench_gemm.py [zeros]   (zeros: zero-filled operands = DVFS probe)"""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,13 +14,18 @@ SHAPES = [  # (name, M, N, K)
     ("square 4096", 4096, 4096, 4096), ("square 8192", 8192, 8192, 8192),
 ]
 dev = torch.device("cuda")
+ZEROS = len(sys.argv) > 1 and sys.argv[1] == "zeros"
+if len(sys.argv) > 1 and sys.argv[1] == "nt":
+    SHAPES = SHAPES[:12] + SHAPES[-2:]
 res = []
 for name, M, N, K in SHAPES:
     a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand((N, K), device=dev) * 2 - 1).to(torch.bfloat16)
+    if ZEROS:
+        a.zero_(); b.zero_()
     c = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
     row = {"name": name, "M": M, "N": N, "K": K}
-    for v in (1, 2):
+    for v in (2, 3):
         ops.gemm_set_variant(v)
         for _ in range(2):
             ops.gemm_nt(a, b, out=c)
@@ -35,6 +41,8 @@ for name, M, N, K in SHAPES:
     res.append(row)
     print(json.dumps(row), flush=True)
 
+if len(sys.argv) > 1:
+    sys.exit(0)
 # ---- backward forms: NN (dgrad) and TN (wgrad) against the NT kernel fed with pre-transposed operands
 print("--- NN / TN forms (v2 = 256 kernels); nt_* = same contraction on the NT kernel incl. nothing else", flush=True)
 BW = [("dec gate_up dgrad NN", "NN", 8192, 3584, 37888), ("dec down dgrad NN", "NN", 8192, 18944, 3584), ("dec qkv dgrad NN", "NN", 8192, 3584, 4608),
