@@ -228,3 +228,116 @@ def self_attention(q, k, v, *, B, S, Hq, Hkv, D, scale, causal, kv_len=None):
     if D not in (64, 128):
         raise ValueError(f"self_attention: head_dim {D} not supported by the LDS-staged kernels (64 / 128); use cross_attention")
     return _SelfAttn.apply(q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal)
+
+
+# ---------------------------------------------------------------------------------------------- decoder pieces in general-purpose form
+# (the AF3 path keeps its arena-writing layer Functions in functional.py; these return gradients as tensors: config 4's ICL model)
+class _Rope(torch.autograd.Function):
+    """rotate-half RoPE on the first nheads*D columns of a fused projection [rows, ld] (Qwen2 apply_rotary_pos_emb, modeling_qwen2.py:112-135)"""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, S, nheads, D):
+        out = qkv.clone()
+        ops.rope_(out, cos, sin, S=S, nheads=nheads, D=D)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (S, nheads, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        cos, sin = ctx.saved_tensors
+        S, nheads, D = ctx.meta
+        dx = dy.clone()
+        ops.rope_(dx, cos, sin, S=S, nheads=nheads, D=D, backward=True)
+        return dx, None, None, None, None, None
+
+
+def rope(qkv, cos, sin, *, S, nheads, D):
+    return _Rope.apply(qkv, cos, sin, S, nheads, D)
+
+
+class _FusedSelfAttn(torch.autograd.Function):
+    """causal / full self-attention reading q | k | v in place from the fused projection output; backward returns d(q|k|v) as one tensor"""
+
+    @staticmethod
+    def forward(ctx, qkv, B, S, Hq, Hkv, D, scale, causal):
+        o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=causal)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (B, S, Hq, Hkv, D, scale, causal)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, S, Hq, Hkv, D, scale, causal = ctx.meta
+        return (ops.attn_bwd(qkv, o, do.contiguous(), lse, B, S, Hq, Hkv, D, scale=scale, causal=causal),) + (None,) * 7
+
+
+def fused_self_attention(qkv, *, B, S, Hq, Hkv, D, scale, causal=True):
+    return _FusedSelfAttn.apply(qkv, B, S, Hq, Hkv, D, scale, causal)
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ctx.save_for_backward(ids)
+        ctx.shape = weight.shape
+        return ops.embed_scatter_fwd(ids, None, weight, None)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        dw = torch.zeros(ctx.shape, device=dout.device, dtype=BF16)
+        ops.embed_scatter_bwd(ids, None, dout.contiguous(), dw, None)
+        return None, dw
+
+
+def embedding(ids, weight):
+    """weight[ids] with a deterministic fp32-accumulated scatter-add backward; ids int64 [n]"""
+    return _Embedding.apply(ids, weight)
+
+
+class _LMHeadLoss(torch.autograd.Function):
+    """lm_head + shifted cross-entropy, chunked, on the rows that carry a label only (functional.LMHeadLossFn in tensor-returning form)"""
+
+    CHUNK = 4096
+
+    @staticmethod
+    def forward(ctx, x, w, shift_labels, rows):
+        M_all = x.shape[0]
+        xs = ops.gather_rows(x, rows) if rows is not None else x
+        labs = shift_labels.index_select(0, rows) if rows is not None else shift_labels
+        M, V = xs.shape[0], w.shape[0]
+        dev = x.device
+        denom = ops.count_valid(labs)
+        row_loss = torch.empty(M, device=dev, dtype=torch.float32)
+        dxs = torch.empty_like(xs)
+        dw = torch.empty_like(w)
+        chunk = min(_LMHeadLoss.CHUNK, M)
+        buf = torch.empty((chunk, V), device=dev, dtype=BF16)
+        for i, s in enumerate(range(0, M, chunk)):
+            e = min(M, s + chunk)
+            logits = buf[: e - s]
+            ops.gemm_nt(xs[s:e], w, out=logits)
+            ops.ce_fwd_bwd_(logits, labs[s:e], row_loss[s:e], denom, upstream=1.0, write_grad=True)
+            ops.gemm(logits, w, out=dxs[s:e], trans_b=True)                                       # dX = dlogits . W
+            ops.gemm(logits, xs[s:e], out=dw, trans_a=True, trans_b=True, accumulate=i > 0)       # dW += dlogits^T . X
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        ops.loss_reduce(row_loss, denom, loss)
+        ctx.save_for_backward(dxs, dw, rows)
+        ctx.M_all = M_all
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dxs, dw, rows = ctx.saved_tensors
+        g32 = g.reshape(1).float()
+        ops.scale_add_(dxs, dxs, g32, accumulate=False)
+        ops.scale_add_(dw, dw, g32, accumulate=False)
+        dx = ops.scatter_rows(dxs, rows, ctx.M_all) if rows is not None else dxs
+        return dx, dw, None, None
+
+
+def lm_head_loss(x, w, shift_labels, rows=None):
+    """mean CE of (x @ w^T) against shift_labels (-100 = ignore); rows = int64 indices of the labelled rows (None: all)"""
+    return _LMHeadLoss.apply(x, w, shift_labels, rows)

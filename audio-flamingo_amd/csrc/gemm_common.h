@@ -162,7 +162,9 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
+// 256x256, K-step 32, eight free-running waves, ten-slot LDS ring (gemm256f8.hip); mode 1 = no-DMA timing probe
+int afk_launch_gemm256f8(const GemmArgs& p, int mode, hipStream_t st);
 // 256x256 four-wave kernel, 128x128 per wave, accumulators in AGPRs (gemm256w4.hip)
-int afk_launch_gemm256w4(const GemmArgs& p, hipStream_t st);
+int afk_launch_gemm256w4(const GemmArgs& p, int mode, hipStream_t st);  // mode 1 / 2: timing probes (no DMA / no DMA + no fragment reads)
 // transposed-operand variants (gemm256t.hip): NN (trans_a = 0) and TN (trans_a = 1); B is reduction-major in both
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st);

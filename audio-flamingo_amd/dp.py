@@ -31,8 +31,70 @@ import torch.distributed as dist
 from .arena import Arena
 
 
+class NativeComm:
+    """The RCCL communicator behind the C ABI (include/afk.h afk_comm_*): what a non-Python host of libafk.so would use, and - with
+    AFK_DP_COMM=native - what DataParallelEngine uses instead of torch.distributed's collectives.  One communicator per process / GPU."""
+
+    _DT = {torch.bfloat16: 0, torch.float32: 1, torch.int32: 2}
+
+    def __init__(self, rank: int, world: int, uid: bytes):
+        import ctypes
+
+        from . import _lib
+
+        self.rank, self.world = rank, world
+        h = ctypes.c_void_p()
+        _lib.call("afk_comm_init", rank, world, uid, ctypes.addressof(h))
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from . import _lib
+
+        buf = ctypes.create_string_buffer(128)
+        _lib.call("afk_comm_unique_id", ctypes.addressof(buf))
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, process_group=None):
+        """bootstrap over an existing torch.distributed group: rank 0 creates the id, everybody receives it"""
+        rank, world = dist.get_rank(process_group), dist.get_world_size(process_group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=process_group)
+        return cls(rank, world, box[0])
+
+    def allreduce_(self, t: torch.Tensor, *, form: str = "rs_ag", op_max: bool = False):
+        """in-place sum (or max) over the ranks, enqueued on the CURRENT stream.  form "rs_ag": reduce-scatter + all-gather (every xGMI link
+        of the mesh busy), "allreduce": one ncclAllReduce"""
+        from . import _lib
+        from .ops import _stream
+
+        assert t.is_cuda and t.is_contiguous() and t.dtype in self._DT
+        if form == "rs_ag" and not op_max:
+            _lib.call("afk_reduce_scatter_allgather_bucket", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], _stream())
+        else:
+            _lib.call("afk_allreduce_bucket", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], int(op_max), _stream())
+        return t
+
+    def broadcast_(self, t: torch.Tensor, root: int = 0):
+        from . import _lib
+        from .ops import _stream
+
+        _lib.call("afk_comm_broadcast", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], root, _stream())
+        return t
+
+    def close(self):
+        from . import _lib
+
+        if self.handle:
+            _lib.call("afk_comm_destroy", self.handle)
+            self.handle = None
+
+
 class DataParallelEngine:
-    def __init__(self, arena: Arena, process_group=None, overlap: bool = True):
+    def __init__(self, arena: Arena, process_group=None, overlap: bool = True, comm: Optional[str] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.arena = arena
@@ -44,6 +106,13 @@ class DataParallelEngine:
         # device buffers over a host-side backend (gloo): stage through the host.  Only for correctness runs of the multi-rank path on a
         # box without one GPU per rank (tests/test_dp_gpu.py: two ranks sharing one MI355X); the production backend is "nccl" = RCCL.
         self.staged = self.cuda and self.backend != "nccl"
+        # which library issues the collectives: "torch" = torch.distributed (c10d -> RCCL), "native" = libafk.so's own communicator
+        # (afk_comm_* C ABI, reduce-scatter + all-gather form); env AFK_DP_COMM / AFK_DP_FORM.  Same arithmetic, same order.
+        import os as _os
+
+        self.comm_kind = comm or _os.environ.get("AFK_DP_COMM", "torch")
+        self.form = _os.environ.get("AFK_DP_FORM", "rs_ag")
+        self.native = NativeComm.from_process_group(process_group) if (self.comm_kind == "native" and self.cuda and not self.staged) else None
         self.overlap = overlap and self.cuda
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
         self._works: List = []
@@ -85,6 +154,9 @@ class DataParallelEngine:
 
     def allreduce_sum_(self, buf: torch.Tensor):
         """sum-all-reduce of a device slice, ordered on the CURRENT stream (RCCL), or staged through the host (gloo: synchronous)"""
+        if self.native is not None:
+            self.native.allreduce_(buf, form=self.form)
+            return
         if not self.staged:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
             return
@@ -108,8 +180,10 @@ class DataParallelEngine:
             with torch.cuda.stream(self.comm_stream):
                 for ev in evs:
                     self.comm_stream.wait_event(ev)
-                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self._works.append(w)
+                if self.native is not None:
+                    self.native.allreduce_(buf, form=self.form)  # enqueued on the communication stream; finish() joins it
+                else:
+                    self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         elif self._native_bf16:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
         else:
@@ -152,7 +226,10 @@ class DataParallelEngine:
         elif self.cuda:
             with torch.cuda.stream(self.comm_stream):
                 t = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
-                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+                if self.native is not None:
+                    self.native.allreduce_(t, op_max=True)
+                else:
+                    self._works.append(dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
             t.record_stream(torch.cuda.current_stream())
         else:
             t = torch.tensor(touched, dtype=torch.int32)
@@ -253,7 +330,10 @@ class BackwardOverlap:
                     gate = gate.to(self.arena.device)
                 else:
                     gate = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
-                    dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
+                    if eng.native is not None:
+                        eng.native.allreduce_(gate, op_max=True)
+                    else:
+                        dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
                 for i in deferred:
                     self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate[i:i + 1])
                     self.arena.refresh_bucket_shadows(i)

@@ -214,6 +214,81 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     def trainable_numel(self):
         return sum(b.numel for b in self.arena.order)
 
+    # ------------------------------------------------------------------ checkpoints (PreTrainedModel.from_pretrained / save_pretrained surface)
+    @classmethod
+    def from_pretrained(cls, path, device="cuda", **kwargs):
+        """Load a reference checkpoint directory (what AudioFlamingo3ForConditionalGeneration.save_pretrained writes / what
+        `nvidia/audio-flamingo-3-hf` unpacks to): config.json + *.safetensors (single file or sharded with model.safetensors.index.json).
+        The parameter names are the reference's, so the tensors drop straight into the arena views."""
+        import json
+        import os
+
+        from safetensors import safe_open
+        from transformers import AutoConfig
+
+        config = AutoConfig.from_pretrained(path)
+        model = cls(config, device=device, init_seed=None, **kwargs)
+        idx = os.path.join(path, "model.safetensors.index.json")
+        files = sorted(set(json.load(open(idx))["weight_map"].values())) if os.path.exists(idx) else ["model.safetensors"]
+        sd = {}
+        for fn in files:
+            with safe_open(os.path.join(path, fn), framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    sd[cls._runtime_key(k)] = f.get_tensor(k)
+        model.load_state_dict(sd, strict=True)
+        return model
+
+    # checkpoint files use the hub layout; the reference renames on load (transformers/conversion_mapping.py "qwen2_audio":
+    # ^language_model.model -> model.language_model, ^language_model.lm_head -> lm_head, ^audio_tower -> model.audio_tower,
+    # ^multi_modal_projector -> model.multi_modal_projector) and reverses it on save
+    _HUB_PREFIXES = (("language_model.model.model.", "model.language_model."), ("language_model.model.", "model.language_model."),
+                     ("language_model.lm_head.", "lm_head."), ("audio_tower.", "model.audio_tower."),
+                     ("multi_modal_projector.", "model.multi_modal_projector."))
+
+    @classmethod
+    def _runtime_key(cls, k: str) -> str:
+        for src, dst in cls._HUB_PREFIXES:
+            if k.startswith(src):
+                return dst + k[len(src):]
+        return k
+
+    @classmethod
+    def _hub_key(cls, k: str) -> str:
+        for src, dst in cls._HUB_PREFIXES[1:]:
+            if k.startswith(dst):
+                return src + k[len(dst):]
+        return k
+
+    def save_pretrained(self, path, max_shard_size: int = 5 << 30):
+        """config.json + safetensors shards with the reference's parameter names (loadable by the reference's from_pretrained)"""
+        import json
+        import os
+
+        from safetensors.torch import save_file
+
+        os.makedirs(path, exist_ok=True)
+        self.config.save_pretrained(path)
+        shards, cur, size = [], {}, 0
+        for k, v in self.state_dict().items():
+            t = v.detach().to("cpu").contiguous().clone()
+            nb = t.numel() * t.element_size()
+            if cur and size + nb > max_shard_size:
+                shards.append(cur)
+                cur, size = {}, 0
+            cur[self._hub_key(k)] = t
+            size += nb
+        shards.append(cur)
+        if len(shards) == 1:
+            save_file(shards[0], os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+            return
+        wm = {}
+        for i, sh in enumerate(shards):
+            fn = f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors"
+            save_file(sh, os.path.join(path, fn), metadata={"format": "pt"})
+            wm.update({k: fn for k in sh})
+        json.dump({"metadata": {"total_size": sum(t.numel() * t.element_size() for sh in shards for t in sh.values())}, "weight_map": wm},
+                  open(os.path.join(path, "model.safetensors.index.json"), "w"))
+
     # ------------------------------------------------------------------ helpers
     def _rope_tables(self, S: int):
         """Qwen2RotaryEmbedding.forward (modeling_qwen2.py:91-102): fp32 angles, cos/sin rounded to bf16"""
@@ -532,23 +607,51 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             y = self._decode_layers_fused(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"])
         else:
             y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])
-        st["nxt"].copy_(ops.gemm_nt(y, st["head"]).float().argmax(-1))
+        st["nxt"].copy_(self._select_token(ops.gemm_nt(y, st["head"]).float(), st.get("sampling")))
         st["cur"].add_(1)
+
+    @staticmethod
+    def _select_token(logits, sampling=None):
+        """greedy argmax, or GenerationMixin's sampling chain on the [B, V] fp32 logits of the new position: temperature -> top-k -> top-p
+        (TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper, transformers/generation/logits_process.py) -> softmax -> multinomial.
+        Token selection is O(B*V) index work outside the training hot path: plain torch ops."""
+        if not sampling:
+            return logits.argmax(-1)
+        t, k, p_, gen = sampling["temperature"], sampling["top_k"], sampling["top_p"], sampling["generator"]
+        if t and t != 1.0:
+            logits = logits / t
+        if k and k > 0:
+            kth = logits.topk(min(k, logits.shape[-1]), -1).values[..., -1:]
+            logits = logits.masked_fill(logits < kth, float("-inf"))
+        if p_ is not None and p_ < 1.0:
+            sl, si = logits.sort(-1, descending=False)
+            drop = sl.softmax(-1).cumsum(-1) <= (1.0 - p_)
+            drop[..., -1:] = False  # always keep the most likely token
+            logits = logits.masked_fill(drop.scatter(-1, si, drop), float("-inf"))
+        return torch.multinomial(logits.softmax(-1), 1, generator=gen).squeeze(-1)
 
     @torch.no_grad()
     def generate(self, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20,
-                 do_sample=False, eos_token_id=None, pad_token_id=None, use_cache=True, use_graph=None, **kwargs):
-        """Greedy decoding (GenerationMixin.generate with do_sample=False, transformers/generation/utils.py; cache handling as
+                 do_sample=False, temperature=1.0, top_k=50, top_p=1.0, seed=None, eos_token_id=None, pad_token_id=None, use_cache=True,
+                 use_graph=None, **kwargs):
+        """Greedy decoding or sampling (GenerationMixin.generate, transformers/generation/utils.py; do_sample with temperature / top_k /
+        top_p as its logits warpers apply them; seed -> a device generator, so runs are reproducible).  Cache handling as
         Qwen2Attention.forward modeling_qwen2.py:213-214).  Prefill runs the prompt once and fills a per-layer KV cache; every new
         token then costs one pass over the weights and one Q=1 attention over the cache.  Batches may be LEFT padded
         (attention_mask, as the processor pads): positions count real tokens only and padded keys are never visible.
         The decode step is launch-bound in eager mode (~370 small launches per token), so it is captured once into a HIP graph and
         replayed (use_graph=None: whenever more than 3 tokens are requested)."""
-        if do_sample:
-            raise AfkError("only greedy decoding (do_sample=False) is implemented")
         self._require_hip()
+        sampling = None
+        if do_sample:
+            gen = torch.Generator(device=self.device_)
+            gen.manual_seed(int(seed) if seed is not None else int(torch.seed() % (2 ** 31)))
+            sampling = dict(temperature=float(temperature), top_k=int(top_k or 0), top_p=None if top_p is None else float(top_p), generator=gen)
+            use_graph = False  # the sampler draws from a host-side generator object: eager steps
         ids = input_ids.to(self.device_)
         if not use_cache:
+            if do_sample:
+                raise AfkError("generate(use_cache=False) is the greedy reference path of the tests")
             return self._generate_recompute(ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id)
         B, S0 = ids.shape
         dev = self.device_
@@ -574,7 +677,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y = self._decode_layers(x, B, S0, 0, (Kc, Vt), pos_rows, krange, fast)
         last = y.reshape(B, S0, -1)[:, -1, :].contiguous()
         st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
-              "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "nxt": ops.gemm_nt(last, self.arena["lm_head.weight"].data).float().argmax(-1)}
+              "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling,
+              "nxt": self._select_token(ops.gemm_nt(last, self.arena["lm_head.weight"].data).float(), sampling)}
         toks = [st["nxt"].clone()]
         if use_graph is None:
             use_graph = max_new_tokens > 3

@@ -36,7 +36,11 @@ S_TOK, N_AUDIO_TOK, N_ANSWER, AUDIO_ID = 1024, 750, 256, 151669
 CLIP_SECONDS = 30.0
 # BASELINE.json configs[1]/[2] ("clip30": one 30 s window per sample, micro-batch 8) and configs[4] ("long5min": one 5-minute clip =
 # 10 full windows per sample, 7 500 <sound> tokens, S = 7 774, micro-batch 1, per-layer activation checkpointing on both towers).
-WORKLOADS = {"clip30": dict(windows=1, batch=8, checkpoint=False), "long5min": dict(windows=10, batch=1, checkpoint=True)}
+WORKLOADS = {"clip30": dict(windows=1, batch=8, checkpoint=False), "long5min": dict(windows=10, batch=1, checkpoint=True),
+             # BASELINE configs[3]: AF1/AF2-style ICL step (Perceiver resampler + gated cross-attention, 4 clips per sample); shapes are
+             # builder-declared (audio_flamingo_amd/flamingo_icl.py ICL4), parity w.r.t. AF1/AF2 UNPINNED
+             "icl4": dict(windows=0, batch=8, checkpoint=False)}
+ICL_S, ICL_ANSWER, ICL_CLIP_SECONDS = 512, 128, 10.0
 
 
 def af3_7b_config(enc_layers=32, dec_layers=28):
@@ -224,12 +228,88 @@ def eager_rocm_baseline(dev, feats, ids, labels, steps=3):
     e1.record()
     torch.cuda.synchronize()
     gemm_ms = e0.elapsed_time(e1) / 10
+    # our kernel on the SAME operands in the same process (operand statistics move the power-limited clock: compare like with like)
+    from audio_flamingo_amd import ops as _ops
+
+    c = torch.empty((8192, 37888), device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        _ops.gemm_nt(a, w, out=c)
+    e0.record()
+    for _ in range(10):
+        _ops.gemm_nt(a, w, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    afk_ms = e0.elapsed_time(e1) / 10
     out = res or {"ms_per_step": None, "value": None, "unit": "audio-s/s", "micro_batch": 0}
     out.update({"kind": "reference model, eager PyTorch-ROCm (sdpa, vendor BLAS), torch.optim.AdamW(fused), bf16, full depth 32+28",
                 "vendor_gemm_gate_up": {"shape": [8192, 37888, 3584], "ms": gemm_ms, "tflops": 2.0 * 8192 * 37888 * 3584 / (gemm_ms * 1e-3) / 1e12,
-                                        "what": "torch.nn.functional.linear (rocBLAS / hipBLASLt) on random bf16 operands, HIP events, 10 launches"},
+                                        "what": "torch.nn.functional.linear (rocBLAS / hipBLASLt) on N(0,1) bf16 operands, HIP events, 10 launches",
+                                        "afk_same_operands_ms": afk_ms, "afk_same_operands_tflops": 2.0 * 8192 * 37888 * 3584 / (afk_ms * 1e-3) / 1e12},
                 "steps": steps, "warmup": 1})
     return out
+
+
+def run_icl4(args, dev):
+    """BASELINE configs[3] as a measured workload: one training step (fwd + bwd + fused AdamW) of the AF1/AF2-style in-context model of
+    audio_flamingo_amd/flamingo_icl.py on micro-batch `args.batch` x 4 clips; synthetic encoder features N(0,1) [B, 4, 64, 768] (the
+    audio encoder itself - AF-CLAP - is out of scope: SURVEY.md §2.2), S = 512 text tokens with 4 <audio> markers, loss on the last 128."""
+    from audio_flamingo_amd import ops
+    from audio_flamingo_amd.flamingo_icl import ICL4, FlamingoICLForCausalLM, TensorAdamW
+
+    c = dict(ICL4)
+    if args.dec_layers != 28:
+        c["layers"] = args.dec_layers
+    B = args.batch
+    model = FlamingoICLForCausalLM(c, device=dev, seed=0)
+    opt = TensorAdamW(model.parameters(), lr=1e-5)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    feats = torch.randn((B, c["clips"], c["enc_frames"], c["enc_dim"]), device=dev, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, 151643, (B, ICL_S), device=dev, generator=g)
+    ids[:, [8, 136, 264, 392]] = c["audio_marker_id"]
+    labels = ids.clone()
+    labels[:, : ICL_S - ICL_ANSWER] = -100
+    shift = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1)
+    rows = (shift != -100).nonzero().reshape(-1)
+
+    def step():
+        opt.zero_grad()
+        loss = model(ids, feats, labels, label_rows=rows)
+        loss.backward()
+        opt.step()
+        return loss
+
+    first = float(step().detach())
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    torch.cuda.synchronize()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.prof_enable(False)
+    gemm_ms, gemm_flops, gemm_launches = ops.prof_collect()
+    sps = B * args.steps / dt
+    nparams = sum(p.numel() for p in model.parameters())
+    ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    return {
+        "metric": "audio-sec/s + decoder tokens/s, AF1/AF2-style ICL bf16 train (BASELINE configs[3], builder-declared shapes, parity UNPINNED)",
+        "value": sps * c["clips"] * ICL_CLIP_SECONDS, "unit": "audio-s/s", "decoder_tokens_per_s": sps * ICL_S, "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": (f"ICL step: {c['clips']} clips/sample ({ICL_CLIP_SECONDS:.0f} s each, encoder features [{c['enc_frames']}, {c['enc_dim']}]) -> Perceiver "
+                                f"resampler ({c['n_latents']} latents, depth {c['resampler_depth']}) -> {c['layers']}-layer Qwen2.5-3B-class decoder with a "
+                                f"gated cross-attention block every {c['xattn_every']} layers, S={ICL_S}, fwd+bwd+AdamW"),
+                   "micro_batch_per_gpu": B, "global_batch": B, "seq_len": ICL_S, "parallelism": "dp1", "params": nparams, "shapes": c},
+        "loss": float(loss.detach()), "loss_first_step": first, "host_enqueue_ms_per_step": round(1000.0 * host / args.steps, 1),
+        "gemm_executed_tflops_per_step": gemm_flops / args.steps / 1e12, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 / gemm_xt_bf16_k256 (+ k128 / split-K for small shapes)", "achieved": ach, "peak": 2500.0,
+                     "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None, "launches": gemm_launches, "gemm_ms_per_step": gemm_ms / args.steps,
+                     "note": "HIP events around every GEMM launch of the timed steps (single stream)"},
+    }
 
 
 def settle_hbm(dev, quiet_s=8.0, timeout_s=60.0):
@@ -274,7 +354,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="clip30", help="clip30 = BASELINE configs[1]/[2] (the headline); long5min = configs[4]")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="clip30", help="clip30 = BASELINE configs[1]/[2] (the headline); long5min = configs[4]; icl4 = configs[3] (AF1/AF2-style ICL step)")
     ap.add_argument("--batch", type=int, default=0, help="micro-batch (samples) per GPU; default 8 for clip30 (BASELINE config), 1 for long5min")
     ap.add_argument("--no-checkpoint", action="store_true", help="long5min only: keep all activations instead of per-layer recompute")
     ap.add_argument("--enc-layers", type=int, default=32)
@@ -309,6 +389,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     waited = settle_hbm(dev)
+    if args.workload == "icl4":
+        assert world == 1, "icl4 is a single-GPU measurement"
+        res = run_icl4(args, dev)
+        res["waited_for_free_hbm_s"] = waited
+        print(json.dumps(res), flush=True)
+        return
     use_dp = world > 1 or args.force_dp
     if use_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -385,9 +471,14 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
-    host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside): << dt means the GPU is never starved
+    host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside; includes queue back-pressure once the GPU lags)
     fence()
     dt = time.perf_counter() - t0
+    # the same WITHOUT back-pressure: one more (untimed) step enqueued onto an idle GPU - what the host really needs per step
+    t1 = time.perf_counter()
+    loss = run()
+    host_enqueue_idle = time.perf_counter() - t1
+    fence()
     ops.prof_enable(False)
     ov_ms, ov_flops, ov_launches = ops.prof_collect()
     # Per-launch GEMM durations: with the wgrad branch on a second stream and AdamW on a third, kernels share the chip and the
@@ -496,6 +587,7 @@ def main():
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
             "replicas_identical_after_steps": replicas_identical, "long_audio_configs4": long_audio,
             "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
+            "host_enqueue_ms_idle_gpu": round(1000.0 * host_enqueue_idle, 1),
             "waited_for_free_hbm_s": waited,
             "model_tflops_per_gpu": model_tf, "model_frac_of_mfma_peak": (model_tf / 2500.0) if model_tf else None,
             "hardware_tflops_per_gpu": hw_tf, "executed_tflops_per_gpu": exec_tf,
@@ -515,7 +607,8 @@ def main():
                 feats_b = frontend(waves, out_dtype=torch.bfloat16)
                 model.arena.on_bucket_ready = None
                 loss = None
-                del model, opt, overlap, engine, step
+                data.clear()
+                del model, opt, overlap, engine, step, run
                 import gc
 
                 gc.collect()

@@ -271,6 +271,24 @@ int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* pa
                    const float* hyper, void* stream);
 int afk_set_f32(float* dst, int n, float a, float b, float c, float d, void* stream);
 
+/* ---- data-parallel gradient exchange: RCCL over xGMI behind the C ABI.
+ * Replaces the C++ Reducer -> ncclAllReduce path of torch DistributedDataParallel (TORCH/nn/parallel/distributed.py:662-666, 828-834):
+ * the gradient arena keeps a transformer layer's gradients contiguous, so a bucket is (pointer, count).  Every call enqueues on `stream`
+ * (a side HIP stream ordered after the layer's last wgrad kernel by an event) and returns; the reduction is a SUM (averaging = the
+ * optimizer's grad_scale).  One communicator per process (= per GPU): rank 0 creates the 128-byte id with afk_comm_unique_id, hands it to
+ * the other ranks out of band (launcher / rendezvous store), every rank calls afk_comm_init on its own device.
+ * afk_reduce_scatter_allgather_bucket gives the same result as afk_allreduce_bucket with every xGMI link of the mesh busy. */
+#define AFK_COMM_UID_BYTES 128
+#define AFK_COMM_BF16 0
+#define AFK_COMM_F32 1
+#define AFK_COMM_I32 2
+int afk_comm_unique_id(char* host_out128);
+int afk_comm_init(int rank, int world, const char* host_uid128, void** host_comm_out);
+int afk_comm_destroy(void* comm);
+int afk_allreduce_bucket(void* comm, void* buf, int64_t n, int dtype, int op_max, void* stream);
+int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream);
+int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,54 @@ def gated_cross_attention(sd, x, media, keep_mask, gate, n_heads, eps, pfx=""):
     m = F.linear(F.silu(F.linear(h, sd[pfx + "mlp.gate_proj.weight"])) * F.linear(h, sd[pfx + "mlp.up_proj.weight"]),
                  sd[pfx + "mlp.down_proj.weight"])                                                                  # M:798
     return r + torch.tanh(sd[pfx + "alpha_dense"]) * m                                                              # M:800
+
+
+def qwen2_layer(sd, pfx, x, n_heads, n_kv, head_dim, eps, theta):
+    """one Qwen2DecoderLayer on a FUSED q|k|v projection (the layout audio_flamingo_amd/flamingo_icl.py stores): Q2 = modeling_qwen2.py:258-298"""
+    from oracle.af3_oracle import _sdpa, rotate_half
+
+    B, S, H = x.shape
+    nq, nkv = n_heads * head_dim, n_kv * head_dim
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos()[None, None], emb.sin()[None, None]
+    r = x
+    h = sd[pfx + "input_layernorm.weight"] * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+    qkv = F.linear(h, sd[pfx + "qkv.weight"], sd[pfx + "qkv.bias"])
+    q = qkv[..., :nq].view(B, S, n_heads, head_dim).transpose(1, 2)
+    k = qkv[..., nq: nq + nkv].view(B, S, n_kv, head_dim).transpose(1, 2)
+    v = qkv[..., nq + nkv:].view(B, S, n_kv, head_dim).transpose(1, 2)
+    q, k = q * cos + rotate_half(q) * sin, k * cos + rotate_half(k) * sin
+    g = n_heads // n_kv
+    keep = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    o = _sdpa(q, k.repeat_interleave(g, 1), v.repeat_interleave(g, 1), keep, head_dim ** -0.5).transpose(1, 2).reshape(B, S, nq)
+    x = r + F.linear(o, sd[pfx + "o_proj.weight"])
+    r = x
+    h = sd[pfx + "post_attention_layernorm.weight"] * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+    gu = F.linear(h, sd[pfx + "gate_up.weight"])
+    I = gu.shape[-1] // 2
+    return r + F.linear(F.silu(gu[..., :I]) * gu[..., I:], sd[pfx + "down_proj.weight"])
+
+
+def icl_forward(sd, c, input_ids, audio_features, labels):
+    """the assembled config-4 step of audio_flamingo_amd/flamingo_icl.py: projection -> resampler -> decoder with gated cross-attention
+    blocks -> lm_head -> shifted CE.  (Builder-declared wiring; the blocks themselves are pinned to the Idefics stand-in above.)"""
+    B, S = input_ids.shape
+    nc, T, De = audio_features.shape[1:]
+    H, L = c["hidden"], c["n_latents"]
+    f = F.linear(audio_features.reshape(B * nc, T, De), sd["audio_proj.weight"])
+    media = perceiver_resampler(sd, f, c["resampler_heads"], c["resampler_head_dim"], pfx="resampler.").reshape(B, nc * L, H)
+    ci = (input_ids == c["audio_marker_id"]).long().cumsum(-1) - 1
+    gate = (ci >= 0).long()
+    keys = torch.arange(nc * L)[None, None, :]
+    keep = (keys >= (ci.clamp_min(0) * L)[..., None]) & (keys < ((ci.clamp_min(0) + 1) * L)[..., None]) & (ci >= 0)[..., None]
+    x = sd["embed_tokens.weight"][input_ids]
+    for i in range(c["layers"]):
+        if i % c["xattn_every"] == 0:
+            x = gated_cross_attention(sd, x, media, keep, gate, c["xattn_heads"], c["rms_eps"], pfx=f"xattn.{i}.")
+        x = qwen2_layer(sd, f"layers.{i}.", x, c["heads"], c["kv_heads"], c["head_dim"], c["rms_eps"], c["rope_theta"])
+    x = sd["norm.weight"] * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + c["rms_eps"]))
+    logits = F.linear(x, sd["lm_head.weight"])
+    lab = F.pad(labels, (0, 1), value=-100)[..., 1:].reshape(-1)
+    return F.cross_entropy(logits.view(-1, logits.shape[-1]), lab, ignore_index=-100), logits

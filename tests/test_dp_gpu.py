@@ -163,7 +163,36 @@ def test_dp_two_ranks_one_gpu_gloo(dev):
     _run("gloo")
 
 
-def test_dp_two_ranks_rccl(dev):
+@pytest.mark.parametrize("comm", ["torch", "native"])
+def test_dp_two_ranks_rccl(dev, comm):
+    """one GPU per rank over RCCL: through torch.distributed's collectives and through libafk.so's own communicator (afk_comm_* C ABI,
+    reduce-scatter + all-gather form)"""
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box): RCCL over xGMI")
-    _run("nccl")
+    os.environ["AFK_DP_COMM"] = comm
+    try:
+        _run("nccl")
+    finally:
+        os.environ.pop("AFK_DP_COMM", None)
+
+
+def test_native_comm_single_rank(dev):
+    """the afk_comm_* C ABI on the one GPU of this box: a 1-rank communicator (all-reduce, reduce-scatter + all-gather incl. the tail that does
+    not divide, broadcast are identities) - proves the binding, the lazy librccl load and the stream ordering; the 2-rank arithmetic is
+    test_dp_two_ranks_rccl[native] on a multi-GPU box"""
+    from audio_flamingo_amd.dp import NativeComm
+
+    c = NativeComm(0, 1, NativeComm.unique_id())
+    for n in (1000, 4096 * 129 + 7):
+        x = torch.randn(n, device=dev).to(torch.bfloat16)
+        ref = x.clone()
+        c.allreduce_(x, form="allreduce")
+        c.allreduce_(x, form="rs_ag")
+        c.broadcast_(x, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref)
+    f = torch.arange(10, device=dev, dtype=torch.int32)
+    c.allreduce_(f, op_max=True)
+    torch.cuda.synchronize()
+    assert f.tolist() == list(range(10))
+    c.close()

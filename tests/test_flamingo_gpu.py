@@ -98,3 +98,52 @@ def test_gated_cross_attention_block(dev, alpha_type):
     # tokens before the first clip see no media: the cross-attention branch must contribute exactly nothing there (M:792)
     o2 = blk(x.to(dev), torch.zeros_like(media).to(dev), kr.to(dev), gate.to(dev))
     assert torch.isfinite(o2.float()).all()
+
+
+def test_icl_step_assembled_vs_oracle(dev):
+    """config 4 assembled: 4 clips per sample -> projection -> Perceiver resampler -> decoder with a gated cross-attention block every 2nd
+    layer -> lm_head + CE; forward, every parameter gradient and one fused-AdamW step against oracle/flamingo_oracle.py::icl_forward
+    (parity w.r.t. AF1/AF2 itself: UNPINNED)"""
+    from audio_flamingo_amd.flamingo_icl import FlamingoICLForCausalLM, TensorAdamW
+    from oracle import flamingo_oracle as FO
+
+    c = dict(vocab=512, hidden=256, inter=512, layers=4, heads=4, kv_heads=2, head_dim=64, rms_eps=1e-6, rope_theta=1e4, xattn_every=2,
+             xattn_heads=4, xattn_inter=512, n_latents=64, resampler_depth=2, resampler_heads=4, resampler_head_dim=64, enc_dim=128, enc_frames=48,
+             clips=4, audio_marker_id=511)
+    m = FlamingoICLForCausalLM(c, device=dev, seed=1)
+    sd = _bf_state(m, 9)
+    for k in list(sd):
+        if "alpha" in k:
+            sd[k] = (0.5 * torch.randn(sd[k].shape, generator=torch.Generator().manual_seed(len(k)))).to(BF)  # open gates
+    m.load_state_dict(sd)
+    B, S = 2, 192
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 500, (B, S), generator=g)
+    for b, marks in enumerate([[5, 40, 90, 130], [0, 31, 77, 160]]):
+        ids[b, marks] = 511
+    labels = ids.clone()
+    labels[:, :100] = -100
+    feats = torch.randn(B, 4, 48, 128, generator=g).to(BF)
+    sdf = {k: v.float().requires_grad_(True) for k, v in sd.items()}
+    ref_loss, ref_logits = FO.icl_forward(sdf, c, ids, feats.float(), labels)
+    ref_loss.backward()
+    shift = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1)
+    rows = (shift != -100).nonzero().reshape(-1).to(dev)
+    loss = m(ids.to(dev), feats.to(dev), labels.to(dev), label_rows=rows)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref_loss)) <= 1e-2, (float(loss), float(ref_loss))
+    with torch.no_grad():
+        lg = m(ids.to(dev), feats.to(dev)).float().cpu()
+    assert float((lg - ref_logits.detach()).abs().max()) <= 4e-2 * max(1.0, float(ref_logits.abs().max()))
+    params = dict(m.named_parameters())
+    bad = {k: _rel(params[k].grad, v.grad) for k, v in sdf.items() if v.grad is not None and v.grad.norm() > 0 and _rel(params[k].grad, v.grad) > 8e-2}
+    assert not bad, bad
+    opt = TensorAdamW(m.parameters(), lr=1e-3)
+    before = float(loss)
+    for _ in range(3):
+        opt.step()
+        opt.zero_grad()
+        loss = m(ids.to(dev), feats.to(dev), labels.to(dev), label_rows=rows)
+        loss.backward()
+    assert float(loss) < before, (before, float(loss))

@@ -76,7 +76,6 @@ def test_fullwidth_depth_reduced_model_vs_oracle(dev):
     assert cnt["gqa_reduce"] == 1 and cnt["attn1_fwd"] == 0 and cnt["xattn_fwd"] == 0, cnt
 
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    torch.set_num_threads(os.cpu_count() or 8)
     ref = O.forward(leaves, dict(enc_heads=20, heads=28, kv_heads=4, eps=1e-6, theta=1e6, audio_token_id=bench.AUDIO_ID),
                     ids, feats.float(), None, labels=labels)
     ref["loss"].backward()

@@ -34,9 +34,9 @@ def _hf_model(cfg_dict, dev, state=None, seed=0):
 def test_reference_model_with_afk_attention_vs_golden(dev, case):
     """the reference's own bf16 model on this device, attention through libafk.so, against the fp32 golden - beside the SAME model with its
     stock sdpa attention (the bf16 noise floor of these trained, sharp-softmax goldens): the plugin run may deviate from the golden by the
-    bars of tests/_tol.py or by 2x what the stock run deviates, whichever is larger"""
+    bars of tests/_tol.py or by the floor rule of that file (4x what the stock run deviates), whichever is larger"""
     from audio_flamingo_amd import hf_plugin
-    from tests._tol import GRAD_REL_L2, LOSS_ATOL, logit_tol
+    from tests._tol import FLOOR_FACTOR, LOSS_ATOL, grad_bar, logit_tol
     from tests.test_host_cpu import TINY
 
     name = hf_plugin.register()
@@ -61,9 +61,9 @@ def test_reference_model_with_afk_attention_vs_golden(dev, case):
                          logit=float((out.logits.float().cpu()[sel] - g["logits_bf16"].float()).abs().max()),
                          grads={k: _rel(params[k].grad, v) for k, v in g["grads"].items()})
     floor, got = res["sdpa"], res[name]
-    assert got["loss"] <= max(LOSS_ATOL, 2 * floor["loss"]), (got, floor)
-    assert got["logit"] <= max(logit_tol(g["logits_absmax"]), 2 * floor["logit"]), (got["logit"], floor["logit"])
-    bad = {k: (v, floor["grads"][k]) for k, v in got["grads"].items() if v > max(GRAD_REL_L2, 2 * floor["grads"][k])}
+    assert got["loss"] <= max(LOSS_ATOL, FLOOR_FACTOR * floor["loss"]), (got, floor)
+    assert got["logit"] <= max(logit_tol(g["logits_absmax"]), FLOOR_FACTOR * floor["logit"]), (got["logit"], floor["logit"])
+    bad = {k: (v, floor["grads"][k]) for k, v in got["grads"].items() if v > grad_bar(floor["grads"][k])}
     assert not bad, bad
 
 

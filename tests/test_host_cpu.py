@@ -235,3 +235,24 @@ def test_splitk_plans():
     assert ops.splitk_plan(1, 3584, 18944) <= (18944 + 511) // 512
     assert ops.splitk_plan(8, 3584, 256) == 1              # short reduction: nothing to share
     assert ops.splitk_plan_256(1280, 1280, 12000) > 1 and ops.splitk_plan_256(5120, 18944, 8192) == 1
+
+
+def test_from_pretrained_and_save_pretrained_round_trip_with_the_reference(tmp_path):
+    """checkpoint surface: a directory written by the REFERENCE's save_pretrained loads into the arena model (same names, same values),
+    and a directory written by ours loads back into the reference class - single-file and sharded"""
+    import torch
+    from transformers import AudioFlamingo3Config, AudioFlamingo3ForConditionalGeneration
+
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    torch.manual_seed(0)
+    ref = AudioFlamingo3ForConditionalGeneration(AudioFlamingo3Config(**TINY)).to(torch.bfloat16)
+    ref.save_pretrained(tmp_path / "ref")
+    m = Mine.from_pretrained(str(tmp_path / "ref"), device="cpu")
+    sd_ref, sd = ref.state_dict(), m.state_dict()
+    assert set(sd) == set(sd_ref)
+    assert all(torch.equal(sd[k], sd_ref[k]) for k in sd_ref)
+    m.save_pretrained(str(tmp_path / "ours"), max_shard_size=1 << 20)   # forces several shards
+    back = AudioFlamingo3ForConditionalGeneration.from_pretrained(str(tmp_path / "ours"), dtype=torch.bfloat16)
+    sd_back = back.state_dict()
+    assert all(torch.equal(sd_back[k], sd_ref[k]) for k in sd_ref)

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-from tests._tol import AUDIO_REL_L2, GRAD_REL_L2, LOSS_ATOL, logit_tol
+from tests._tol import AUDIO_REL_L2, FLOOR_FACTOR, GRAD_REL_L2, LOSS_ATOL, grad_bar, logit_tol
 
 LOGIT_TOL = 4e-2  # absolute bar used only where the logits are O(1) (random-init comparisons against the oracle)
 REPORT = {}
@@ -110,17 +110,16 @@ def _golden_compare(g, out, m):
 
 
 def _golden_assert(rep, floor):
-    """absolute bars of tests/_tol.py, each relaxed to 2x the reference's own bf16 noise floor where that is higher: on the TRAINED goldens the
-    softmax is sharp, so bf16 noise in a handful of high-loss positions moves the loss gradient by tens of percent in ANY bf16
-    implementation (the floor shows it); nothing is ever looser than 2x what the reference's bf16 run does on the same inputs"""
-    assert abs(rep["loss"] - rep["loss_ref"]) <= max(LOSS_ATOL, 2 * abs(floor["loss"] - rep["loss_ref"])), (rep, floor)
+    """absolute bars of tests/_tol.py, each relaxed to a small multiple of the reference's own bf16 noise floor where that is higher
+    (rule and factors: tests/_tol.py)"""
+    assert abs(rep["loss"] - rep["loss_ref"]) <= max(LOSS_ATOL, FLOOR_FACTOR * abs(floor["loss"] - rep["loss_ref"])), (rep, floor)
     assert rep["logits"]["rms"] <= 2 * floor["logits"]["rms"] + 1e-3, (rep["logits"], floor["logits"])
-    assert rep["logits"]["max"] <= max(rep["logit_tol"], 2 * floor["logits"]["max"]), (rep["logits"], floor["logits"], rep["logit_tol"])
+    assert rep["logits"]["max"] <= max(rep["logit_tol"], FLOOR_FACTOR * floor["logits"]["max"]), (rep["logits"], floor["logits"], rep["logit_tol"])
     assert rep["n_confident"] >= 0.95 * rep["n_valid"], rep          # the token-id check covers (nearly) every position
     assert rep["argmax_mismatch_confident"] == 0, rep
     assert rep["argmax_mismatch_all_valid"] <= floor["argmax_mismatch_all_valid"] + 1, (rep, floor)
     assert rep["audio_rel_l2"] <= AUDIO_REL_L2, rep
-    bad = {k: (v, floor["grad_rel_l2"][k]) for k, v in rep["grad_rel_l2"].items() if v > max(GRAD_REL_L2, 2 * floor["grad_rel_l2"][k])}
+    bad = {k: (v, floor["grad_rel_l2"][k]) for k, v in rep["grad_rel_l2"].items() if v > grad_bar(floor["grad_rel_l2"][k])}
     assert not bad, (bad, rep)
 
 
@@ -204,6 +203,22 @@ def test_generate_greedy_ids_bit_exact(dev, use_graph):
     ids = m.generate(_gen_prompt(g).to(dev), input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev),
                      max_new_tokens=N_GEN, use_graph=use_graph)
     assert ids.cpu().tolist() == g["generate"].tolist()
+
+
+def test_generate_sampling(dev):
+    """do_sample: top_k = 1 is greedy; a seed reproduces the draw; tokens come from the top-k set of the reference distribution"""
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=8)
+    p = _gen_prompt(g).to(dev)
+    greedy = m.generate(p, **kw)
+    assert torch.equal(m.generate(p, do_sample=True, top_k=1, seed=1, **kw), greedy)
+    a = m.generate(p, do_sample=True, temperature=1.5, top_k=20, top_p=0.95, seed=7, **kw)
+    b = m.generate(p, do_sample=True, temperature=1.5, top_k=20, top_p=0.95, seed=7, **kw)
+    assert torch.equal(a, b) and a.shape == greedy.shape
+    # the first sampled token must lie in the top-20 of the first-step logits
+    lg = m(input_ids=p, input_features=kw["input_features"], input_features_mask=kw["input_features_mask"], logits_to_keep=1).logits[0, -1].float()
+    assert int(a[0, p.shape[1]]) in lg.topk(20).indices.tolist()
 
 
 def test_generate_left_padded_processor_batch_bit_exact(dev):

@@ -47,11 +47,11 @@ def test_gemm_plain(dev, M, N, K):
     _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 10])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 260, 320), (1000, 1280, 1280), (8, 512, 4096),
                                    (777, 1028, 64), (2048, 256, 2048)])
 def test_gemm_variants(dev, variant, M, N, K):
-    """all three NT kernels (128x128; 256x256 8-wave ping-pong; 256x256 4-wave) on every edge shape: K-tiles 1/2/3/many (prologue + tail
+    """all NT kernels (1: 128x128; 2: 256x256 8-wave ping-pong; 3: 256x256 4-wave x 128x128; 6: 256x256 8-wave free-running) on every edge shape: K-tiles 1/2/3/many (prologue + tail
     waits), M/N tails, tiny M"""
     ops = _ops()
     ops.gemm_set_variant(variant)

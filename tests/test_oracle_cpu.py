@@ -21,7 +21,6 @@ def test_oracle_matches_reference_golden(case):
     """A: full windows; B: padded window + right-padded row; C: the reference PROCESSOR's own left-padded batch"""
     g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
     sd = _state()
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     with torch.no_grad():
         out = O.forward(sd, CFG, g["ids"], g["feats"].float(), g["fmask"].long(), labels=g["labels"], attention_mask=g["att"])
     assert abs(float(out["loss"]) - float(g["loss"])) < 5e-5, (float(out["loss"]), float(g["loss"]))

@@ -17,6 +17,8 @@ dev = torch.device("cuda")
 ZEROS = len(sys.argv) > 1 and sys.argv[1] == "zeros"
 if len(sys.argv) > 1 and sys.argv[1] == "nt":
     SHAPES = SHAPES[:12] + SHAPES[-2:]
+if len(sys.argv) > 2 and sys.argv[2] == "few":
+    SHAPES = [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[11], SHAPES[-1]]
 res = []
 for name, M, N, K in SHAPES:
     a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
@@ -25,7 +27,7 @@ for name, M, N, K in SHAPES:
         a.zero_(); b.zero_()
     c = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
     row = {"name": name, "M": M, "N": N, "K": K}
-    for v in (2, 3):
+    for v in [int(x) for x in os.environ.get("AFK_BENCH_VARIANTS", "2,3").split(",")]:
         ops.gemm_set_variant(v)
         for _ in range(2):
             ops.gemm_nt(a, b, out=c)
