@@ -1,10 +1,10 @@
 """HIP-graph capture of one whole training step (frontend -> forward -> backward -> per-bucket AdamW + W^T shadow refresh).
 
-Why: a step of AF3-7B enqueues ~3 000 kernel launches from Python (ctypes -> libafk.so) on three HIP streams; the host needs
-220-300 ms per step for that (bench.py `host_enqueue_ms_per_step`), i.e. more than half of the GPU's 435 ms - any further kernel
-speed-up would end host-bound.  Shapes are static in training, so the launch sequence of a step - including the fork / join of the
-weight-gradient stream and of the optimizer side stream, which become graph dependencies - is captured ONCE and replayed with a
-single hipGraphLaunch (~1 ms of host time).  Same kernels, same order per stream, same arithmetic: the replayed step is
+Why: a step of AF3-7B enqueues ~3 000 kernel launches from Python (ctypes -> libafk.so) on three HIP streams; on an idle GPU the host
+needs ~41 ms per step for that (bench.py `host_enqueue_ms_idle_gpu`; the 220-414 ms seen inside a timed loop are queue back-pressure),
+9 % of the GPU's 440 ms - a limit that would bind as the kernels get faster or the batch smaller.  Shapes are static in training, so the
+launch sequence of a step - including the fork / join of the weight-gradient stream and of the optimizer side stream, which become graph
+dependencies - is captured ONCE and replayed with a single hipGraphLaunch (9 ms of host time per step, measured).  Same kernels, same order per stream, same arithmetic: the replayed step is
 bit-identical to the eager step (tests/test_model_gpu.py::test_graphed_step_matches_eager).
 
 What changes between replays lives in device memory, never in kernel arguments:

@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--dec-layers", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the unmodified reference model on this GPU (eager PyTorch-ROCm)")
+    ap.add_argument("--eager-only", action="store_true", help="measure ONLY the unmodified reference model on this GPU (eager PyTorch-ROCm): for rocprofv3 kernel tables")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
     ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) of the default run")
     ap.add_argument("--no-overlap", action="store_true")
@@ -389,6 +390,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     waited = settle_hbm(dev)
+    if args.eager_only:
+        from audio_flamingo_amd.frontend import LogMelFrontend
+
+        waves, ids, labels = synthetic_batch(args.batch, 0, dev, 1)
+        feats_b = LogMelFrontend(dev)(waves, out_dtype=torch.bfloat16)
+        print(json.dumps({"eager_rocm_baseline": eager_rocm_baseline(dev, feats_b, ids, labels, steps=args.steps)}), flush=True)
+        return
     if args.workload == "icl4":
         assert world == 1, "icl4 is a single-GPU measurement"
         res = run_icl4(args, dev)

@@ -20,6 +20,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "nt":
 if len(sys.argv) > 2 and sys.argv[2] == "few":
     SHAPES = [SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[11], SHAPES[-1]]
 res = []
+if len(sys.argv) > 1 and sys.argv[1] in ("bw", "bwzeros"):
+    SHAPES = []
 for name, M, N, K in SHAPES:
     a = (torch.rand((M, K), device=dev) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand((N, K), device=dev) * 2 - 1).to(torch.bfloat16)
@@ -43,8 +45,9 @@ for name, M, N, K in SHAPES:
     res.append(row)
     print(json.dumps(row), flush=True)
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] not in ("bw", "bwzeros"):
     sys.exit(0)
+ZEROS = ZEROS or (len(sys.argv) > 1 and sys.argv[1] == "bwzeros")
 # ---- backward forms: NN (dgrad) and TN (wgrad) against the NT kernel fed with pre-transposed operands
 print("--- NN / TN forms (v2 = 256 kernels); nt_* = same contraction on the NT kernel incl. nothing else", flush=True)
 BW = [("dec gate_up dgrad NN", "NN", 8192, 3584, 37888), ("dec down dgrad NN", "NN", 8192, 18944, 3584), ("dec qkv dgrad NN", "NN", 8192, 3584, 4608),
@@ -61,6 +64,8 @@ for name, form, M, N, K in BW:
         a = (torch.rand((K, M), device=dev) * 2 - 1).to(torch.bfloat16)
         b = (torch.rand((K, N), device=dev) * 2 - 1).to(torch.bfloat16)
         kw = dict(trans_a=True, trans_b=True)
+    if ZEROS:
+        a.zero_(); b.zero_()
     c = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
     for _ in range(2):
         ops.gemm(a, b, out=c, **kw)
