@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     constexpr int KS = D / 16, DT = D / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // grid = (heads, batch, query blocks, last block first): workgroups go to the XCDs round-robin in linear order, so the fastest grid
+    // dimension must not be the one the (causal) work per block depends on - see attention_lds.hip
+    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
+    const int q0 = ((int)gridDim.z - 1 - (int)blockIdx.z) * 128 + wave * 32;
     if (q0 >= p.S) return;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs p) {
     constexpr int KS = D / 16, DT = D / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, hk = blockIdx.y, group = p.Hq / p.Hkv;
-    const int key0 = blockIdx.x * 128 + wave * 32;
+    const int b = blockIdx.y, hk = blockIdx.x, group = p.Hq / p.Hkv;  // grid = (kv heads, batch, key blocks)
+    const int key0 = blockIdx.z * 128 + wave * 32;
     if (key0 >= p.Sk) return;
     const int key = key0 + l31;
     const int keyc = min(key, p.Sk - 1);
@@ -279,8 +281,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int KS = D / 16, DT = D / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // grid = (heads, batch, query blocks, last block first): workgroups go to the XCDs round-robin in linear order, so the fastest grid
+    // dimension must not be the one the (causal) work per block depends on - see attention_lds.hip
+    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
+    const int q0 = ((int)gridDim.z - 1 - (int)blockIdx.z) * 128 + wave * 32;
     if (q0 >= p.S) return;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -376,7 +380,7 @@ extern "C" int afk_attn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
     p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
     p.LSE = LSE; p.kv_len = kv_len;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.Sk = S; p.Skpad = Spad; p.scale = scale; p.causal = causal;
-    dim3 grid((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
     if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, st, p);
     else if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p);
@@ -422,8 +426,8 @@ extern "C" int afk_attn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.Sk = S; p.Skpad = Spad; p.scale = scale; p.causal = causal;
     hipStream_t st = (hipStream_t)stream;
-    dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)Hkv, (unsigned)B);
-    dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    dim3 gkv((unsigned)Hkv, (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     if (D == 128) {
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<128>, gkv, dim3(256), 0, st, p);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);
@@ -455,7 +459,7 @@ extern "C" int afk_xattn_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
     p.LSE = LSE; p.kv_len = kv_len; p.krange = krange;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = Sq; p.Spad = Sqpad; p.Sk = Sk; p.Skpad = Skpad; p.scale = scale; p.causal = 0;
-    dim3 grid((unsigned)afk_cdiv(Sq, 128), (unsigned)Hq, (unsigned)B);
+    dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(Sq, 128));
     hipStream_t st = (hipStream_t)stream;
     if (D == 128) hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, st, p);
     else if (D == 64) hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, p);
@@ -487,8 +491,8 @@ extern "C" int afk_xattn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len; p.krange = krange;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = Sq; p.Spad = Sqpad; p.Sk = Sk; p.Skpad = Skpad; p.scale = scale; p.causal = 0;
     hipStream_t st = (hipStream_t)stream;
-    dim3 gkv((unsigned)afk_cdiv(Sk, 128), (unsigned)Hkv, (unsigned)B);
-    dim3 gq((unsigned)afk_cdiv(Sq, 128), (unsigned)Hq, (unsigned)B);
+    dim3 gkv((unsigned)Hkv, (unsigned)B, (unsigned)afk_cdiv(Sk, 128));
+    dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(Sq, 128));
     if (D == 128) {
         hipLaunchKernelGGL(attn_bwd_dkdv_kernel<128>, gkv, dim3(256), 0, st, p);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, gq, dim3(256), 0, st, p);

@@ -36,6 +36,7 @@ struct AttnArgs2 {
     int B, Hq, Hkv, S, Spad;
     float scale;
     int causal;
+    int dbg;          // AFK_ATTN_DBG experiments (0 in production)
     int split_heads;  // dK/dV sweep: one block per QUERY head, partial dK/dV per query head (GQA), reduced afterwards
 };
 
@@ -157,9 +158,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const typename T::Offs offs = T::make_offs(lane);
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
+    // grid = (heads, batch, position blocks): the hardware deals workgroups to the 8 XCDs round-robin in linear block order, so the FASTEST
+    // grid dimension must not be the one the work per block depends on - with the 8 causal position blocks of S = 1024 in x, XCD k received
+    // every block of length class k and the kernel ran as long as the XCD holding the 16-tile blocks (profiles/r02_attn_probes.md).
+    // Position blocks are the slowest dimension, longest first.
+    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
     // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
-    const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
+    const int qb0 = (p.causal ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z) * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[dt][4 * qd + e] * inv);
                 *(bf16x4*)(Op + dt * 32 + 8 * qd + 4 * hi) = o;
             }
-        if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? m + __log2f(l) : NEG_INF;  // log2 domain (internal to the v2 kernels)
+        // internal to the v2 kernels: MINUS the log-sum-exp in SCORE units, P = 2^(c2 (S + LSE)); +inf for a row that saw no key
+        if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? -(m + __log2f(l)) / c2 : INFINITY;
     }
 }
 
@@ -336,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const typename T::Offs offs = T::make_offs(lane);
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (p.Hq / p.Hkv);
-    const int qb0 = (p.causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x) * 128;
+    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);  // grid = (heads, batch, position blocks), see the forward kernel
+    const int qb0 = (p.causal ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z) * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -352,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         dof[ks] = *(const bf16x8*)(dOp + ks * 16);
     }
     const float c2 = p.scale * LOG2E;
-    const float nlse = -p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc];  // log2 domain
-    const float ndlt = -p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];
+    const float nlse = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc] * c2;  // stored negated, in score units (see the forward epilogue)
+    const float ndlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];      // stored negated (attn2_delta_kernel)
     const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
     const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
 
@@ -487,16 +493,18 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     using T = Tile<D>;
     constexpr int KS = T::KS, DT = T::DT;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][Q image | dO image]
+    uint64_t rt_entry = 0, rt1 = 0;
+    if (p.dbg & 4) asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const typename T::Offs offs = T::make_offs(lane);
-    const int b = blockIdx.z, group = p.Hq / p.Hkv;
-    const int hy = blockIdx.y;
+    const int b = blockIdx.y, group = p.Hq / p.Hkv;  // grid = (heads, batch, key blocks), see the forward kernel; causal: key block 0 is the longest
+    const int hy = blockIdx.x;
     const int hk = p.split_heads ? hy / group : hy;
     const int g_begin = p.split_heads ? hy % group : 0;
     const int g_count = p.split_heads ? 1 : group;
-    const int kb0 = blockIdx.x * 128;
+    const int kb0 = blockIdx.z * 128;
     const int key0 = kb0 + wave * 32;
     const int key = key0 + l31;
     const int keyc = min(key, p.S - 1);
@@ -522,8 +530,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     }
     const int qt_begin = p.causal ? (kb0 >> 6) : 0;  // block-uniform first 64-query tile
     const int qt_end = (p.S + 63) >> 6;
-    const int per_head = qt_end - qt_begin;
-    const int ntiles = per_head * g_count;
+    const int ntiles = (qt_end - qt_begin) * g_count;
     // interior query tiles of one head: [qt_int0, qt_int1): all 64 queries exist, causal: every query >= every key of the block;
     // a block holding padded keys (kb0 + 128 > kv_len) has none
     const int qt_int0 = (kb0 + 128 > kv_len) ? qt_end : (p.causal ? min((kb0 + 128 + 63) >> 6, qt_end) : 0);
@@ -535,101 +542,221 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) qtr[dt][pc] = lds0 + offs.tr[dt][pc];
 
-    // lse / delta of the tile's 64 queries travel with the tile: one extra 1-KiB LDS-DMA piece per tile (wave 0; lanes 0-15 fetch
-    // lse[64], lanes 16-31 delta[64], the upper half duplicates them) into a stats strip behind the two images.  Each lane then
-    // ds_reads the 4 consecutive queries it needs right where it uses them - as global loads they either sat in 64 VGPRs or made
-    // the wave wait for the prefetch queued behind them.
     constexpr int STATS = 2 * T::BYTES;      // offset of the strip inside a buffer
     constexpr int BUF = 2 * T::BYTES + 1024;  // buffer pitch
-    auto stage_stats = [&](int t, int h, int qt) {
-        if (wave == 0) {
-            const float* src = ((lane & 16) ? p.delta : p.LSE) + ((int64_t)b * p.Hq + h) * p.Spad + qt * 64 + (lane & 15) * 4;
-            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + (t & 1) * BUF + STATS), 16, 0, 0);
+    // Staging tile (h, qt) into buffer `slot`: per-lane part of every source address is a tile-independent 32-bit byte offset (row r of
+    // the tile, swizzled chunk), the tile part (batch, head, first row) is wave-uniform - scalar base + VGPR offset addressing, no
+    // per-tile address VALU.  A ragged last tile (rows >= S) takes the row-clamping general form.
+    constexpr int NP = T::UNITS / 4;
+    uint32_t qoff[NP], dooff[NP];
+#pragma unroll
+    for (int u0 = 0; u0 < NP; ++u0) {
+        const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
+        qoff[u0] = (uint32_t)(r * (int)p.q_rs + chunk * 8) * 2u;
+        dooff[u0] = (uint32_t)(r * (int)p.do_rs + chunk * 8) * 2u;
+    }
+    const float* stat_lane = ((lane & 16) ? p.delta : p.LSE) + (int64_t)b * p.Hq * p.Spad + (lane & 15) * 4;
+    const int n_full = p.S >> 6;  // tiles whose 64 query rows all exist
+    auto stage = [&](int slot, int h, int qt) {
+        char* buf = smem + slot * BUF;
+        const bf16* qb = p.Q + b * p.q_bs + h * p.q_hs;
+        const bf16* dob = p.dO + b * p.do_bs + h * p.do_hs;
+        if (qt < n_full) {
+            const char* q0 = (const char*)(qb + (int64_t)qt * 64 * p.q_rs);
+            const char* d0 = (const char*)(dob + (int64_t)qt * 64 * p.do_rs);
+#pragma unroll
+            for (int u0 = 0; u0 < NP; ++u0) {
+                __builtin_amdgcn_global_load_lds((gbl_void*)(q0 + qoff[u0]), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gbl_void*)(d0 + dooff[u0]), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+            }
+        } else {
+            T::stage(buf, qb, p.q_rs, qt * 64, p.S - 1, wave, lane);
+            T::stage(buf + T::BYTES, dob, p.do_rs, qt * 64, p.S - 1, wave, lane);
         }
-    };
-    auto stage = [&](int t) {
-        const int tt = min(t, ntiles - 1);
-        const int gi = tt / per_head, qt = qt_begin + (tt - gi * per_head);
-        const int h = hk * group + g_begin + gi;
-        char* buf = smem + (t & 1) * BUF;
-        T::stage(buf, p.Q + b * p.q_bs + h * p.q_hs, p.q_rs, qt * 64, p.S - 1, wave, lane);
-        T::stage(buf + T::BYTES, p.dO + b * p.do_bs + h * p.do_hs, p.do_rs, qt * 64, p.S - 1, wave, lane);
-        stage_stats(t, h, qt);
+        // lse / delta of the tile's 64 queries travel with the tile: one extra 1-KiB LDS-DMA piece (wave 0; lanes 0-15 fetch lse[64],
+        // lanes 16-31 delta[64], the upper half duplicates them) into a stats strip behind the two images
+        if (wave == 0)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(stat_lane + (int64_t)h * p.Spad + qt * 64), (lds_void*)(buf + STATS), 16, 0, 0);
     };
 
-    auto body = [&](int t, int qt, auto masked_) {
-        constexpr bool MASKED = decltype(masked_)::value;
-        const char* qimg = smem + (t & 1) * BUF;
-        const char* doimg = qimg + T::BYTES;
-        const float* stats = (const float*)(qimg + STATS) + 4 * hi;
-        const uint32_t boff = (t & 1) * BUF;
-        f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
+    // Per tile and wave (one wave per SIMD for head_dim 128: everything below is ONE in-order instruction stream, so the order written
+    // here is the overlap that happens):
+    //   0. the accumulators of S and dP START at -lse (score units) and -delta, read from the stats strip: S' = Q.K^T - lse and
+    //      dP' = dO.V^T - delta come out of the matrix pipe, P = 2^(c2 S') and dS = P o dP' are one multiply each;
+    //   1. S' (2 KS MFMAs) then dP' (2 KS MFMAs), row fragments through a ring of opaque ds_read_b128 groups (4 fragments per group,
+    //      RD groups deep: 8 reads in flight behind the group being consumed - two reads per lgkmcnt(0) reached a fifth of the LDS
+    //      rate); the exponentials of S' are written between the dP' MFMAs, which they do not depend on;
+    //   2. dV^T += dO^T.P (4 DT MFMAs, tr-read ring) with dS = P o dP' written between them, then dK^T += Q^T.dS (4 DT MFMAs).
+    // ONE body for interior and boundary tiles (the mask is a wave-uniform branch around VALU-only code): with two inlined copies of
+    // the MFMA chains the register allocator kept the 128 dK/dV accumulators of each copy in different AGPRs and moved all of them
+    // back at the end of every tile (128 v_accvgpr_mov + the MFMA-drain s_nops in front of them, ~15 % of the tile).
+    uint64_t c_start = 0, ts0 = 0, ts1 = 0, ts2 = 0, tsm = 0, sum_body = 0, sum_ph1 = 0, sum_bar = 0, rt0 = 0;
+    const bool probe = (p.dbg & 4) != 0;
+    uint32_t qrow[KS];  // Q row-fragment addresses in buffer 0 (kt2 = 1: + 32 rows, dO: + T::BYTES)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            st[0] = MFMA(T::row_frag(qimg, offs, 0, ks), kf[ks], st[0]);
-            st[1] = MFMA(T::row_frag(qimg, offs, 1, ks), kf[ks], st[1]);
-            dp[0] = MFMA(T::row_frag(doimg, offs, 0, ks), vf[ks], dp[0]);
-            dp[1] = MFMA(T::row_frag(doimg, offs, 1, ks), vf[ks], dp[1]);
-        }
-        // transposed fragments: group 2*dt = dO^T d-tile dt (-> dV), group 2*dt+1 = Q^T d-tile dt (-> dK); group 0 in flight during the
-        // VALU block, the rest through the two-deep ring
-        bf16x8 fa[4], fb[4];
-        auto issue = [&](auto g_, bf16x8(&dst)[4]) {
-            constexpr int g = decltype(g_)::value, dt = g >> 1;
-            constexpr int IMG = (g & 1) ? 0 : T::BYTES;
-            const uint32_t a0 = qtr[dt][0] + boff, a1 = qtr[dt][1] + boff;
-            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<IMG + s4 * 16 * T::RS>(a0, a1); });
-        };
-        issue(std::integral_constant<int, 0>{}, fa);
-        const f32x2 c2v = {c2, c2};
-        bf16x8 pb[4], dsb[4];
+    for (int ks = 0; ks < KS; ++ks) qrow[ks] = lds0 + offs.row[ks];
+    constexpr int NG = KS;                     // row-fragment groups: [0, NG/2) = Q (S'), [NG/2, NG) = dO (dP'); group = 2 k-steps
+    constexpr int RD = (D == 128) ? 3 : 2;     // ring depth (head_dim 64 runs two waves per SIMD on half the registers)
+    constexpr int PCH = 8 / NG;                // 8-value chunks of P per dO group (4 chunks per tile)
+    constexpr int SCH = 4 / DT;                // 8-value chunks of dS per dV group
+    auto body = [&](int t, int qt, bool masked) {
+        const uint32_t boff = (t & 1) * BUF;
+        const float* stats = (const float*)(smem + boff + STATS) + 4 * hi;
+        f32x16 st[2], dp[2];
 #pragma unroll
         for (int qt2 = 0; qt2 < 2; ++qt2)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4 a = *(const f32x4*)(stats + qt2 * 32 + 8 * qd);
+                const f32x4 d = *(const f32x4*)(stats + 64 + qt2 * 32 + 8 * qd);
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int r = 4 * qd + e;
-                    const f32x2 s2 = {st[qt2][r], st[qt2][r + 1]};
-                    const f32x2 l2 = *(const f32x2*)(stats + qt2 * 32 + 8 * qd + e);
-                    const f32x2 dl2 = *(const f32x2*)(stats + 64 + qt2 * 32 + 8 * qd + e);
-                    const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, -l2);
-                    f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-                    const f32x2 d2 = {dp[qt2][r], dp[qt2][r + 1]};
-                    if (MASKED) {
-                        const int qq = qt * 64 + qt2 * 32 + 8 * qd + 4 * hi + e;
-                        if (key_dead || (qq >= p.S) || (p.causal && key > qq)) p2[0] = 0.f;
-                        if (key_dead || (qq + 1 >= p.S) || (p.causal && key > qq + 1)) p2[1] = 0.f;
-                    }
-                    const f32x2 ds2 = p2 * (d2 - dl2);
-                    pb[2 * qt2 + (r >> 3)][r & 7] = (bf16)p2[0];
-                    pb[2 * qt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
-                    dsb[2 * qt2 + (r >> 3)][r & 7] = (bf16)ds2[0];
-                    dsb[2 * qt2 + (r >> 3)][(r & 7) + 1] = (bf16)ds2[1];
+                for (int e = 0; e < 4; ++e) {
+                    st[qt2][4 * qd + e] = a[e];
+                    dp[qt2][4 * qd + e] = d[e];
                 }
+            }
+        bf16x8 r0[4], r1[4], r2[4];
+        auto rbuf = [&](auto i_) -> bf16x8(&)[4] {
+            constexpr int i = decltype(i_)::value;
+            if constexpr (i == 0) return r0;
+            else if constexpr (i == 1) return r1;
+            else return r2;
+        };
+        auto issue_rows = [&](auto g_) {
+            constexpr int G = decltype(g_)::value;
+            constexpr int IMG = (G >= NG / 2) ? T::BYTES : 0, ks0 = (2 * G) % KS;
+            bf16x8(&dst)[4] = rbuf(std::integral_constant<int, G % RD>{});
+            const uint32_t a0 = qrow[ks0] + boff, a1 = qrow[ks0 + 1] + boff;
+            dst[0] = afk_lds_b128<IMG>(a0);
+            dst[1] = afk_lds_b128<IMG + 32 * T::RS>(a0);
+            dst[2] = afk_lds_b128<IMG>(a1);
+            dst[3] = afk_lds_b128<IMG + 32 * T::RS>(a1);
+        };
+        // transposed fragments: groups [0, DT) = dO^T d-tile g (-> dV), [DT, 2 DT) = Q^T d-tile g - DT (-> dK)
+        bf16x8 fa[4], fb[4];
+        auto issue = [&](auto g_, bf16x8(&dst)[4]) {
+            constexpr int g = decltype(g_)::value, dt = g % DT;
+            constexpr int IMG = (g < DT) ? T::BYTES : 0;
+            const uint32_t a0 = qtr[dt][0] + boff, a1 = qtr[dt][1] + boff;
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<IMG + s4 * 16 * T::RS>(a0, a1); });
+        };
+        const f32x2 c2v = {c2, c2};
+        bf16x8 pb[4], dsb[4];
+        float pr[4][8];
+        // first query this lane keeps: a key sees queries >= key (causal) and < S; a padded key sees none
+        const int q_lo = key_dead ? p.S : (p.causal ? key : 0);
+        auto p_chunk = [&](auto c_) {
+            constexpr int c = decltype(c_)::value, qt2 = c >> 1, rb = 8 * (c & 1);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 s2 = {st[qt2][rb + e], st[qt2][rb + e + 1]};
+                const f32x2 t2 = s2 * c2v;
+                pr[c][e] = __builtin_amdgcn_exp2f(t2[0]);
+                pr[c][e + 1] = __builtin_amdgcn_exp2f(t2[1]);
+            }
+            if (masked) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int qq = qt * 64 + qt2 * 32 + 8 * ((rb + e) >> 2) + 4 * hi + ((rb + e) & 3);
+                    if (qq < q_lo || qq >= p.S) pr[c][e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[c][e] = (bf16)pr[c][e];
+        };
+        auto ds_chunk = [&](auto c_) {
+            constexpr int c = decltype(c_)::value, qt2 = c >> 1, rb = 8 * (c & 1);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 p2 = {pr[c][e], pr[c][e + 1]};
+                const f32x2 d2 = {dp[qt2][rb + e], dp[qt2][rb + e + 1]};
+                const f32x2 ds2 = p2 * d2;
+                dsb[c][e] = (bf16)ds2[0];
+                dsb[c][e + 1] = (bf16)ds2[1];
+            }
+        };
+
+        afk_static_for<RD - 1>([&](auto g_) { issue_rows(g_); });
+        afk_static_for<NG>([&](auto g_) {
+            constexpr int G = decltype(g_)::value;
+            bf16x8(&cur)[4] = rbuf(std::integral_constant<int, G % RD>{});
+            if constexpr (G + RD - 1 < NG) {
+                issue_rows(std::integral_constant<int, G + RD - 1>{});
+                afk_lgkmcnt<4 * (RD - 1)>();
+            } else if constexpr (G + 1 < NG) {
+                afk_lgkmcnt<4 * (NG - 1 - G)>();
+            } else {
+                afk_lgkmcnt<8>();  // behind this group: the 8 tr-reads of dO^T group 0
+            }
+            afk_lds_tie(cur[0], cur[1], cur[2], cur[3]);
+            constexpr int ks0 = (2 * G) % KS;
+            if constexpr (G < NG / 2) {
+                st[0] = MFMA(cur[0], kf[ks0], st[0]);
+                st[1] = MFMA(cur[1], kf[ks0], st[1]);
+                st[0] = MFMA(cur[2], kf[ks0 + 1], st[0]);
+                st[1] = MFMA(cur[3], kf[ks0 + 1], st[1]);
+            } else {
+                dp[0] = MFMA(cur[0], vf[ks0], dp[0]);
+                dp[1] = MFMA(cur[1], vf[ks0], dp[1]);
+                dp[0] = MFMA(cur[2], vf[ks0 + 1], dp[0]);
+                dp[1] = MFMA(cur[3], vf[ks0 + 1], dp[1]);
+            }
+            if constexpr (G + 2 == NG) issue(std::integral_constant<int, 0>{}, fa);
+            if constexpr (G >= NG / 2)
+                afk_static_for<PCH>([&](auto i_) { p_chunk(std::integral_constant<int, (G - NG / 2) * PCH + decltype(i_)::value>{}); });
+        });
+        if (p.dbg & 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tsm)::"memory");
+            sum_ph1 += tsm - ts0;
+        }
         afk_frag_ring<2 * DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
-            constexpr int g = decltype(g_)::value, dt = g >> 1;
+            constexpr int g = decltype(g_)::value, dt = g % DT;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                if (g & 1) dkacc[dt] = MFMA(f[s4], dsb[s4], dkacc[dt]);
-                else dvacc[dt] = MFMA(f[s4], pb[s4], dvacc[dt]);
+                if (g < DT) dvacc[dt] = MFMA(f[s4], pb[s4], dvacc[dt]);
+                else dkacc[dt] = MFMA(f[s4], dsb[s4], dkacc[dt]);
             }
+            if constexpr (g < DT) afk_static_for<SCH>([&](auto i_) { ds_chunk(std::integral_constant<int, g * SCH + decltype(i_)::value>{}); });
         }, fa, fb);
     };
 
-    if (ntiles > 0) stage(0);
+    // AFK_ATTN_DBG & 4 (tools/attn_waits.py): s_memtime stamps around the body and the barrier of every tile, summed per wave
+    const int h0 = hk * group + g_begin;
+    if (ntiles > 0) stage(0, h0, qt_begin);
     AFK_ATTN_BARRIER();
+    if (probe) asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c_start), "=s"(rt0)::"memory");
     int t = 0;
     for (int gi = 0; gi < g_count; ++gi) {
-        const int h = hk * group + g_begin + gi;
+        const int h = h0 + gi;
         for (int qt = qt_begin; qt < qt_end; ++qt, ++t) {
-            stage(t + 1);  // clamped to the last tile (a redundant re-stage lands in the other buffer and is never read)
-            if (qt >= qt_int0 && qt < qt_int1) {
-                body(t, qt, std::false_type{});
-            } else if (wave_live && !(p.causal && qt * 64 + 63 < key0)) {  // wave-uniform: causal tiles entirely before this wave's keys contribute nothing
-                body(t, qt, std::true_type{});
+            {
+                // next tile (all scalar): the following query tile of this head, else the first tile of the next head; after the last tile a
+                // redundant re-stage of it lands in the other buffer and is never read
+                const bool wrap = qt + 1 == qt_end;
+                const bool last = wrap && gi + 1 == g_count;
+                const int nh = (wrap && !last) ? h + 1 : h, nqt = last ? qt : (wrap ? qt_begin : qt + 1);
+                if (!(p.dbg & 1) || t < 1) stage((t + 1) & 1, nh, nqt);
             }
+            const bool interior = qt >= qt_int0 && qt < qt_int1;
+            if (probe) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
+            // wave-uniform: causal tiles entirely before this wave's keys contribute nothing
+            if (!(p.dbg & 2) && (interior || (wave_live && !(p.causal && qt * 64 + 63 < key0)))) body(t, qt, !interior);
+            if (probe) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory");
             AFK_ATTN_BARRIER();
+            if (probe) {
+                asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory");
+                sum_body += ts1 - ts0;
+                sum_bar += ts2 - ts1;
+            }
+        }
+    }
+    uint64_t c_end = 0;
+    if (probe) {
+        asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c_end), "=s"(rt1)::"memory");
+        if (lane == 0) {
+            float* o = (float*)p.dQ + ((((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            o[0] = (float)(c_end - c_start); o[1] = (float)sum_body; o[2] = (float)sum_bar; o[3] = (float)ntiles;
+            o[4] = (float)(rt1 - rt0); o[5] = (float)sum_ph1; o[6] = (float)blockIdx.z;
         }
     }
     if (key < p.S) {
@@ -649,9 +776,22 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
                 *(bf16x4*)(dVp + dt * 32 + 8 * qd + 4 * hi) = ov;
             }
     }
+    if (probe) {
+        // block timeline on the 100 MHz clock: entry -> loop start -> loop end -> stores retired, + the CU the block ran on
+        uint64_t rt_end;
+        asm volatile("s_waitcnt vmcnt(0)\n s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt_end)::"memory");
+        if (threadIdx.x == 0) {
+            const uint32_t hwid = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
+            const int64_t nblk = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+            const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            double* o = (double*)((float*)p.dQ + nblk * 4 * 8) + blk * 6;
+            o[0] = (double)rt_entry; o[1] = (double)rt0; o[2] = (double)rt1; o[3] = (double)rt_end; o[4] = (double)hwid; o[5] = (double)xcc;
+        }
+    }
 }
 
-// delta[b,h,s] = sum_d dO*O  written with row pitch Spad
+// delta[b,h,s] = -sum_d dO*O  written with row pitch Spad
 template <int D>
 __global__ __launch_bounds__(256) void attn2_delta_kernel(const bf16* __restrict__ O, int64_t o_bs, int64_t o_hs, int64_t o_rs,
                                                           const bf16* __restrict__ dO, int64_t do_bs, int64_t do_hs, int64_t do_rs,
@@ -676,7 +816,7 @@ __global__ __launch_bounds__(256) void attn2_delta_kernel(const bf16* __restrict
         }
 #pragma unroll
         for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (ok && sub == 0) delta[t * Spad + s] = acc;
+        if (ok && sub == 0) delta[t * Spad + s] = -acc;  // negated: the backward kernels start the dP accumulators from it
     }
 }
 
@@ -728,7 +868,7 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
     p.LSE = LSE; p.kv_len = kv_len;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
-    dim3 grid((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
     afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
     if (D == 128) {
@@ -788,6 +928,10 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     // Given a scratch of 2 * B*S*Hq*D bf16 the sweep runs one block per QUERY head and a reduce folds the group.
     const int group = Hq / Hkv;
     const bool split = gqa_scratch != nullptr && group > 1;
+    {
+        static const char* dbg = getenv("AFK_ATTN_DBG");
+        if (dbg) p.dbg = atoi(dbg);
+    }
     AttnArgs2 pk = p;
     if (split) {
         pk.split_heads = 1;
@@ -799,22 +943,22 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     }
     afk_count(D == 128 ? AFK_CNT_ATTN2_BWD_D128 : AFK_CNT_ATTN2_BWD_D64);
     if (split) afk_count(AFK_CNT_GQA_REDUCE);
-    dim3 gkv((unsigned)afk_cdiv(S, 128), (unsigned)(split ? Hq : Hkv), (unsigned)B);
-    dim3 gq((unsigned)afk_cdiv(S, 128), (unsigned)Hq, (unsigned)B);
+    dim3 gkv((unsigned)(split ? Hq : Hkv), (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     if (D == 128) {
         constexpr int L = 4 * Tile<128>::BYTES, LKV = L + 2048;  // dK/dV sweep: + one lse/delta strip per buffer
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), LKV, st, pk);
-        hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
+        if (!(p.dbg & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
     } else {
         constexpr int L = 4 * Tile<64>::BYTES, LKV = L + 2048;
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
-        hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+        if (!(p.dbg & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
     }
-    if (split) {
+    if (split && !(p.dbg & 4)) {
         AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
                     "afk_attn2_bwd: GQA split path expects dK/dV inside one [B*S, ld] buffer with contiguous heads");
         const int64_t rows = (int64_t)B * S;

@@ -74,6 +74,20 @@ __device__ __forceinline__ bf16x8 afk_lds_tr_frag(uint32_t addr0, uint32_t addr1
     const bf16x4 b = afk_lds_tr16_b64<OFF>(addr1);
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// ds_read_b128 in the same opaque form (the compiler schedules its own ds_reads just in time - two reads, s_waitcnt lgkmcnt(0), two
+// MFMAs - which leaves a lone wave at a fraction of the LDS rate; issued as asm the caller decides how many are in flight)
+template <int OFF>
+__device__ __forceinline__ bf16x8 afk_lds_b128(uint32_t addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void afk_lgkmcnt() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
 __device__ __forceinline__ void afk_lds_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 template <typename T0, typename... Ts>
 __device__ __forceinline__ void afk_lds_tie(T0& a, Ts&... rest) {
