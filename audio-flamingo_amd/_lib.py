@@ -55,6 +55,20 @@ _lib = None
 _protos = None
 
 
+def source_hash() -> str:
+    """sha256 prefix of the kernel sources in this tree, in the Makefile's order (csrc/*.hip sorted, then the headers)"""
+    import glob
+    import hashlib
+
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")), key=os.path.basename)
+    files += [os.path.join(csrc, "common.h"), os.path.join(csrc, "gemm_common.h"), HEADER_PATH]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load():
     global _lib, _protos
     if _lib is not None:
@@ -70,6 +84,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
         fn.restype = ret
         fn.argtypes = argtypes
+    built, tree = lib.afk_build_id().decode(), source_hash()
+    if built != tree and "AFK_LIB_PATH" not in os.environ and os.environ.get("AFK_ALLOW_STALE_LIB") != "1":
+        raise AfkError(f"{LIB_PATH} was built from other sources (library {built}, tree {tree}): rebuild it "
+                       f"(`make -C audio-flamingo_amd/csrc`); AFK_ALLOW_STALE_LIB=1 overrides")
     _lib = lib
     return lib
 

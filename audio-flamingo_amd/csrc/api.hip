@@ -30,3 +30,9 @@ extern "C" int afk_kernel_counts_reset(void) {
     return AFK_OK;
 }
 extern "C" int afk_version(void) { return 1; }
+// sha256 prefix of the sources this binary was built from (Makefile: SRC_HASH); the Python binding recomputes it from the tree and refuses
+// a stale library, so a test run can only ever exercise a build of the sources it sits next to
+#ifndef AFK_SRC_HASH
+#define AFK_SRC_HASH "unknown"
+#endif
+extern "C" const char* afk_build_id(void) { return AFK_SRC_HASH; }

@@ -11,7 +11,8 @@ fused arena blocks (q|k|v and gate|up are stored contiguously so that each is on
 Deviations from the oracle surface (documented, not silent):
   * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``; lm_head and the
     loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
-  * ``generate`` is greedy (do_sample=False): prefill fills a KV cache, each new token is one HIP-graph replay;
+  * ``generate``: prefill fills a KV cache, each new token is one HIP-graph replay; greedy by default, ``do_sample=True`` with
+    ``temperature`` / ``top_k`` / ``top_p`` / ``seed`` (the reference's logits-warper order); no beam search;
   * ``attention_mask`` rows must be one contiguous run of ones (left padding - the reference processor's default -, right padding, or
     both); masks with holes raise.  Hidden states of padded positions are zeros-attended garbage in both implementations and are
     never compared.

@@ -23,6 +23,8 @@ extern "C" {
 
 int afk_version(void);
 const char* afk_last_error(void);
+/* sha256 prefix (16 hex digits) of csrc/*.hip + the headers this library was built from */
+const char* afk_build_id(void);
 
 /* ---- launch counters per kernel family: host_out[i] = launches of family i since the last reset (i < n <= AFK_CNT_MAX).
  * Test infrastructure: lets a parity test assert WHICH kernel served a shape (256x256 ping-pong GEMM, TN wgrad, GQA-split dK/dV...). */

@@ -256,3 +256,12 @@ def test_from_pretrained_and_save_pretrained_round_trip_with_the_reference(tmp_p
     back = AudioFlamingo3ForConditionalGeneration.from_pretrained(str(tmp_path / "ours"), dtype=torch.bfloat16)
     sd_back = back.state_dict()
     assert all(torch.equal(sd_back[k], sd_ref[k]) for k in sd_ref)
+
+
+def test_library_is_a_build_of_this_tree():
+    """libafk.so carries the sha256 prefix of the sources it was compiled from; the binding refuses any other tree (a GPU test run can
+    therefore only exercise a build of the sources next to it)"""
+    from audio_flamingo_amd import _lib
+
+    lib = _lib.load()
+    assert lib.afk_build_id().decode() == _lib.source_hash()

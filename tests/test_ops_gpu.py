@@ -654,8 +654,12 @@ def test_adamw(dev):
 
 # ------------------------------------------------------------------------------------------------ log-mel
 def test_logmel(dev):
-    """vs the oracle expression (feature_extraction_whisper.py:135-168) evaluated with torch.stft in fp32 on the CPU"""
+    """vs the reference feature extractor itself (transformers WhisperFeatureExtractor, feature_extraction_whisper.py:135-168 numpy path and
+    :170-201 torch path, both on the CPU).  The reference's two paths do not agree to better than ~3e-5 on this input (log10 of near-floor
+    bins amplifies fp32 rounding), so the bar is stated against that: ours within 4x the reference's own path-to-path deviation of either
+    path, and a median below 1e-5."""
     import numpy as np
+    from transformers import WhisperFeatureExtractor
     from audio_flamingo_amd.frontend import LogMelFrontend, mel_filter_bank
 
     rng = np.random.default_rng(0)
@@ -664,21 +668,21 @@ def test_logmel(dev):
     wav[0] = rng.standard_normal(n).astype(np.float32) * 0.1
     t = np.arange(80000) / 16000.0
     wav[1, :80000] = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.01 * rng.standard_normal(80000)).astype(np.float32)  # 5 s clip, zero padded
+    ref_fe = WhisperFeatureExtractor(feature_size=128, sampling_rate=16000, hop_length=160, chunk_length=30, n_fft=400)
+    assert np.array_equal(mel_filter_bank(128), ref_fe.mel_filters)  # the filter bank is the reference's, bit for bit
+    ref_np = torch.from_numpy(np.asarray(ref_fe._np_extract_fbank_features(wav, "cpu"), np.float32))
+    ref_t = torch.from_numpy(np.asarray(ref_fe._torch_extract_fbank_features(wav, "cpu"), np.float32))
+    d_ref = (ref_np - ref_t).abs().max().item()
     w = torch.from_numpy(wav)
-    window = torch.hann_window(400)
-    stft = torch.stft(w, 400, 160, window=window, return_complex=True)
-    mag = stft[..., :-1].abs() ** 2
-    mel = torch.from_numpy(mel_filter_bank(128).astype(np.float32))
-    spec = torch.clamp(mel.T @ mag, min=1e-10).log10()
-    mx = spec.amax(dim=(1, 2), keepdim=True)
-    ref = (torch.maximum(spec, mx - 8.0) + 4.0) / 4.0
     fe = LogMelFrontend(dev)
     out = fe(w.to(dev))
     assert out.shape == (2, 128, 3000)
-    err = (out.cpu() - ref).abs()
-    # the oracle documents 1e-5 agreement between its own two paths; log10 of near-floor bins amplifies fp32 noise,
-    # so the bar is 1e-4 absolute on the (x+4)/4 scale with a 1e-5 median
-    assert err.max().item() < 2e-4, f"logmel max err {err.max().item()} at {err.argmax().item()}"
-    assert err.median().item() < 1e-5, f"logmel median err {err.median().item()}"
+    e_t, e_np = (out.cpu() - ref_t).abs(), (out.cpu() - ref_np).abs()
+    err = torch.minimum(e_t, e_np)
+    bar = 4.0 * max(d_ref, 1e-5)
+    msg = f"logmel: ours vs torch path {e_t.max().item():.3g}, vs numpy path {e_np.max().item():.3g}, reference's own two paths {d_ref:.3g}"
+    print(msg)
+    assert err.max().item() <= bar, msg
+    assert e_t.median().item() < 1e-5, f"logmel median err {e_t.median().item()}"
     outb = fe(w.to(dev), out_dtype=torch.bfloat16)
     assert torch.equal(outb, out.to(torch.bfloat16))
