@@ -154,6 +154,9 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=No
     return out
 
 
+SPLITK_ROUND = int(os.environ.get("AFK_SPLITK_ROUND", "256"))
+
+
 def splitk_plan_256(M, N, K):
     """K splits for the 256x256 transposed-operand kernels (one workgroup per CU): only for outputs with < 128 tiles and K >= 2048"""
     if not SPLITK or K < 2048:
@@ -161,7 +164,9 @@ def splitk_plan_256(M, N, K):
     t256 = ((M + 255) // 256) * ((N + 255) // 256)
     if t256 >= 128:
         return 1
-    return max(1, min(16, K // 512, (256 + t256 - 1) // t256))
+    # as many splits as still fit ONE round of 256 workgroups (one per CU): ceil() here gave 275-300 workgroups for the encoder's weight
+    # gradients - a second round for 19-44 of them, 55-59 % of the CUs over the launch
+    return max(1, min(16, K // 512, SPLITK_ROUND // t256))
 
 
 def colsum(x, out, *, accumulate=False):
