@@ -200,7 +200,7 @@ class _SelfAttn(torch.autograd.Function):
         lse = torch.zeros((B, Hq, spad), device=q.device, dtype=torch.float32)
         _lib.call("afk_attn2_fwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
                   v.data_ptr(), S * v.stride(0), D, v.stride(0), o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len),
-                  B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+                  0, B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
         ctx.save_for_backward(q, k, v, o, lse, kv_len)
         ctx.meta = (B, S, Hq, Hkv, D, scale, causal)
         return o
@@ -220,7 +220,7 @@ class _SelfAttn(torch.autograd.Function):
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
                   v.data_ptr(), S * v.stride(0), D, v.stride(0), do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(),
                   dq.data_ptr(), S * ldo, D, ldo, dk.data_ptr(), S * ldk, D, ldk, dv.data_ptr(), S * ldk, D, ldk, _p(kv_len),
-                  B, Hq, Hkv, S, spad, D, float(scale), int(causal), _p(scratch), _stream())
+                  0, B, Hq, Hkv, S, spad, D, float(scale), int(causal), _p(scratch), _stream())
         return dq, dk, dv, None, None, None, None, None, None, None, None
 
 

@@ -33,6 +33,7 @@ struct AttnArgs2 {
     float* LSE;          // [B, Hq, Spad]
     const float* delta;  // [B, Hq, Spad]
     const int* kv_len;
+    const int* kv_lo;    // causal only: first visible key per sample (left-padded batches); keys [kv_lo[b], kv_len[b])
     int B, Hq, Hkv, S, Spad;
     float scale;
     int causal;
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int kv_lo = p.kv_lo ? min(max(p.kv_lo[b], 0), kv_len) : 0;  // keys before it are padding (left-padded sample)
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     bf16x8 qf[KS];
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);
-                    const bool dead = (key >= kv_len) || (p.causal && key > q);
+                    const bool dead = (key >= kv_len) || (key < kv_lo) || (p.causal && key > q);
                     st[kt2][r] = dead ? NEG_INF : st[kt2][r];
                 }
         }
@@ -292,9 +294,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         }, fa, fb);
     };
 
-    if (ntiles > 0) stage(0);
+    // left-padded sample: tiles before j0 hold no visible key; the tile that contains kv_lo is a boundary tile ahead of the interior run
+    const int j0 = kv_lo >> 6, j_int0 = (kv_lo + 63) >> 6;
+    if (ntiles > j0) stage(j0);
     AFK_ATTN_BARRIER();
-    int j = 0;
+    int j = j0;
+    for (; j < min(j_int0, ntiles); ++j) {
+        stage(min(j + 1, ntiles - 1));
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        AFK_ATTN_BARRIER();
+    }
     const int n_fast = min(n_int, n_full - 1);  // tile j+1 must be a full tile for the pointer form of the prefetch
     for (; j < n_fast; ++j) {
         stage_fast(j + 1);
@@ -348,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int kv_lo = p.kv_lo ? min(max(p.kv_lo[b], 0), kv_len) : 0;  // keys before it are padding (left-padded sample)
 
     const bf16* Qp = p.Q + b * p.q_bs + h * p.q_hs + (int64_t)qc * p.q_rs + hi * 8;
     const bf16* dOp = p.dO + b * p.do_bs + h * p.do_hs + (int64_t)qc * p.do_rs + hi * 8;
@@ -436,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
                 f32x2 ds2 = p2 * (d2 + nd);
                 if (MASKED) {
                     const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);  // r even: rows key, key+1
-                    if ((key >= kv_len) || (p.causal && key > q)) ds2[0] = 0.f;
-                    if ((key + 1 >= kv_len) || (p.causal && key + 1 > q)) ds2[1] = 0.f;
+                    if ((key >= kv_len) || (key < kv_lo) || (p.causal && key > q)) ds2[0] = 0.f;
+                    if ((key + 1 >= kv_len) || (key + 1 < kv_lo) || (p.causal && key + 1 > q)) ds2[1] = 0.f;
                 }
                 dsb[2 * kt2 + (r >> 3)][r & 7] = (bf16)ds2[0];
                 dsb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)ds2[1];
@@ -449,9 +459,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         }, fa, fb);
     };
 
-    if (ntiles > 0) stage(0);
+    const int j0 = kv_lo >> 6, j_int0 = (kv_lo + 63) >> 6;  // left-padded sample, as in the forward kernel
+    if (ntiles > j0) stage(j0);
     AFK_ATTN_BARRIER();
-    int j = 0;
+    int j = j0;
+    for (; j < min(j_int0, ntiles); ++j) {
+        stage(min(j + 1, ntiles - 1));
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        AFK_ATTN_BARRIER();
+    }
     const int n_fast = min(n_int, n_full - 1);
     for (; j < n_fast; ++j) {
         stage_fast(j + 1);
@@ -509,8 +525,9 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     const int key = key0 + l31;
     const int keyc = min(key, p.S - 1);
     const int kv_len = p.kv_len ? min(p.kv_len[b], p.S) : p.S;
+    const int kv_lo = p.kv_lo ? min(max(p.kv_lo[b], 0), kv_len) : 0;  // keys before it are padding (left-padded sample)
     const bool wave_live = key0 < p.S;
-    const bool key_dead = key >= kv_len;
+    const bool key_dead = key >= kv_len || key < kv_lo;
     const float c2 = p.scale * LOG2E;
 
     const bf16* Kp = p.K + b * p.k_bs + hk * p.k_hs + (int64_t)keyc * p.k_rs + hi * 8;
@@ -530,10 +547,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     }
     const int qt_begin = p.causal ? (kb0 >> 6) : 0;  // block-uniform first 64-query tile
     const int qt_end = (p.S + 63) >> 6;
-    const int ntiles = (qt_end - qt_begin) * g_count;
+    // a key block made of padding only (right of kv_len or left of kv_lo) sweeps nothing and writes zeros
+    const bool block_dead = kb0 >= kv_len || kb0 + 128 <= kv_lo;
+    const int ntiles = block_dead ? 0 : (qt_end - qt_begin) * g_count;
     // interior query tiles of one head: [qt_int0, qt_int1): all 64 queries exist, causal: every query >= every key of the block;
     // a block holding padded keys (kb0 + 128 > kv_len) has none
-    const int qt_int0 = (kb0 + 128 > kv_len) ? qt_end : (p.causal ? min((kb0 + 128 + 63) >> 6, qt_end) : 0);
+    const int qt_int0 = (kb0 + 128 > kv_len || kb0 < kv_lo) ? qt_end : (p.causal ? min((kb0 + 128 + 63) >> 6, qt_end) : 0);
     const int qt_int1 = max(p.S >> 6, qt_int0);
     const uint32_t lds0 = afk_lds_addr(smem);
     uint32_t qtr[DT][2];  // Q^T fragment addresses in buffer 0 (dO^T: + T::BYTES)
@@ -726,7 +745,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     AFK_ATTN_BARRIER();
     if (probe) asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c_start), "=s"(rt0)::"memory");
     int t = 0;
-    for (int gi = 0; gi < g_count; ++gi) {
+    for (int gi = 0; gi < (block_dead ? 0 : g_count); ++gi) {
         const int h = h0 + gi;
         for (int qt = qt_begin; qt < qt_end; ++qt, ++t) {
             {
@@ -854,7 +873,7 @@ int set_lds(K kern, int bytes) {
 // LSE / delta rows are Spad long (multiple of 64, zero-initialised by the host) so that the kernels can use aligned float4 reads.
 extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
                              int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
-                             int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad,
+                             int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
                              int D, float scale, int causal, void* stream) {
     AFK_REQUIRE(Q && K && V && O && LSE, "afk_attn2_fwd: null pointer");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_fwd: bad shape");
@@ -866,7 +885,8 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
     p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
     p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
-    p.LSE = LSE; p.kv_len = kv_len;
+    AFK_REQUIRE(!kv_lo || causal, "afk_attn2_fwd: kv_lo (left padding) is defined for causal attention only");
+    p.LSE = LSE; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
@@ -905,7 +925,7 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
                              int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
                              int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
                              int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
-                             int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
+                             int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
                              int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
     AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_bwd: bad shape");
@@ -921,7 +941,8 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.dQ = (bf16*)dQ; p.dq_bs = dq_bs; p.dq_hs = dq_hs; p.dq_rs = dq_rs;
     p.dK = (bf16*)dK; p.dk_bs = dk_bs; p.dk_hs = dk_hs; p.dk_rs = dk_rs;
     p.dV = (bf16*)dV; p.dv_bs = dv_bs; p.dv_hs = dv_hs; p.dv_rs = dv_rs;
-    p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len;
+    AFK_REQUIRE(!kv_lo || causal, "afk_attn2_bwd: kv_lo (left padding) is defined for causal attention only");
+    p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     hipStream_t st = (hipStream_t)stream;
     // GQA: with few kv heads the dK/dV sweep has too few blocks to fill 256 CUs (decoder: 8x4x8 = 256 long blocks).

@@ -314,7 +314,7 @@ class DecoderLayerFn(torch.autograd.Function):
     """RMSNorm -> GQA causal attention (RoPE) -> +res ; RMSNorm -> SwiGLU -> +res  (Qwen2DecoderLayer.forward, :269-298)"""
 
     @staticmethod
-    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None):
+    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None, kv_lo=None):
         A = lambda k: arena[pfx + k]
         h, rstd1 = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
         qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
@@ -322,20 +322,21 @@ class DecoderLayerFn(torch.autograd.Function):
         if krange is not None:  # left-padded rows (the reference processor's default): per-query key intervals [lo_b, min(i + 1, hi_b))
             o, lse = ops.attn_interval_fwd(qkv, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
         else:
-            o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+            # right padding: kv_len; left padding on the LDS kernels (head_dim 64 / 128): kv_lo beside it
+            o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
         x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
         h2, rstd2 = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
         gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
         a = ops.silu_mul_fwd(gu)
         x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
         # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
-        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange)
+        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo)
         ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)
         return x3
 
     @staticmethod
     def backward(ctx, dx3):
-        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange = ctx.saved_tensors
+        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo = ctx.saved_tensors
         arena, pfx, B, S, Hq, Hkv, D = ctx.meta
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
@@ -357,7 +358,7 @@ class DecoderLayerFn(torch.autograd.Function):
         if krange is not None:
             dqkv = ops.attn_interval_bwd(qkv, o, do, lse, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
         else:
-            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len)
+            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
         del do
         ops.rope_(dqkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos, backward=True)
         dh = linear_bwd(arena, dqkv, h, pfx + "self_attn.qkv.weight", bkey=pfx + "self_attn.qkv.bias")
@@ -365,7 +366,7 @@ class DecoderLayerFn(torch.autograd.Function):
         nw = A("input_layernorm.weight")
         dx = ops.rmsnorm_bwd(x, nw.data, dh, rstd1, nw.grad, dx_add=dx2, accumulate=not nw.fresh)
         arena.grad_written(nw)
-        return (dx,) + (None,) * 14
+        return (dx,) + (None,) * 15
 
 
 class RMSNormFn(torch.autograd.Function):

@@ -444,14 +444,18 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 e = int(expected)
                 if n != e:
                     raise ValueError(f"Audio features and audio tokens do not match, tokens: {n}, features: {e}")
-        kv_len, krange = None, None
+        kv_len, krange, kv_lo = None, None, None
         if attention_mask is not None:
             iv = self._mask_intervals(attention_mask)
             if iv is not None:
                 lo, hi = iv
                 if bool((lo == 0).all()):   # right padding only: the LDS-staged causal kernels take the key count per sample
                     kv_len = hi.to(self.device_, torch.int32).contiguous()
-                else:                        # left padding (processing_audioflamingo3.py:46): causal AND key in [lo_b, hi_b) per query row
+                elif ops._use_lds(self.D) and self.left_pad_on_lds_kernels:
+                    # left padding (processing_audioflamingo3.py:46) on the same kernels: keys [lo_b, hi_b) per sample, causal
+                    kv_len = hi.to(self.device_, torch.int32).contiguous()
+                    kv_lo = lo.to(self.device_, torch.int32).contiguous()
+                else:                        # other head sizes: causal AND key in [lo_b, hi_b) per query row on the interval kernels
                     lo, hi = lo.to(self.device_, torch.int32), hi.to(self.device_, torch.int32)
                     i1 = torch.arange(1, S + 1, device=self.device_, dtype=torch.int32)[None]
                     end = torch.minimum(i1, hi[:, None])
@@ -468,7 +472,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
             x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
-                            self.rms_eps, cos, sin, pos, kv_len, krange)
+                            self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo)
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
         loss, logits = None, None
         if labels is not None:
@@ -548,6 +552,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
 
+    left_pad_on_lds_kernels = True  # left-padded batches on the LDS-staged causal kernels (kv_lo); False: interval kernels (A/B, tests)
     loss_on_valid_rows_only = True  # lm_head + CE (+ their backward GEMMs) on the rows with a label only (False: all B*S rows, as the reference)
     decode_splits = 8  # key-range splits of the Q = 1 attention (0: use the interval MFMA kernel instead)
     decode_fused_glue = True  # B <= 4: one glue kernel per Linear (csrc/decode_glue.hip) instead of reduce / bias / rope / append / norm / SwiGLU launches

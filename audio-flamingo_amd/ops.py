@@ -407,8 +407,11 @@ def _use_lds(D):
     return ATTN_IMPL == "lds" and D in (64, 128)
 
 
-def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
-    """qkv [B*S, (Hq+2Hkv)*D] fused projection output (q | k | v).  -> o [B*S, Hq*D], lse [B,Hq,Spad]"""
+def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
+    """qkv [B*S, (Hq+2Hkv)*D] fused projection output (q | k | v).  -> o [B*S, Hq*D], lse [B,Hq,Spad]
+    kv_len / kv_lo: int32 [B], sample b exposes keys [kv_lo[b], kv_len[b]) (right / left padding; kv_lo needs causal and head_dim 64 / 128)"""
+    if kv_lo is not None and not (_use_lds(D) and causal):
+        raise _lib.AfkError("attn_fwd: kv_lo (left padding) runs on the LDS-staged causal kernels only; use attn_interval_fwd")
     _chk(qkv, BF16, "qkv")
     ld = qkv.stride(0)
     spad = pad64(S)
@@ -419,7 +422,7 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
     if _use_lds(D):
         lse = torch.zeros((B, Hq, spad), device=qkv.device, dtype=torch.float32)
         _lib.call("afk_attn2_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
-                  o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), B, Hq, Hkv, S, spad, D, float(scale),
+                  o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D, float(scale),
                   int(causal), _stream())
         return o, lse
     vt = transpose_heads(v, B, S, Hkv, D, ld, spad)
@@ -429,8 +432,10 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
     return o, lse
 
 
-def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
+def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
     """-> dqkv [B*S, (Hq+2Hkv)*D]"""
+    if kv_lo is not None and not (_use_lds(D) and causal and lse.shape[-1] == pad64(S)):
+        raise _lib.AfkError("attn_bwd: kv_lo (left padding) runs on the LDS-staged causal kernels only; use attn_interval_bwd")
     ld = qkv.stride(0)
     spad = pad64(S)
     q = qkv
@@ -450,7 +455,7 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None):
         scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
-                  dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), B, Hq, Hkv, S, spad, D,
+                  dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
                   float(scale), int(causal), _p(scratch), _stream())
         return dqkv
     delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)

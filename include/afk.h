@@ -200,10 +200,13 @@ int afk_xattn_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int Sqpad, int Skpad, int D, float scale, void* stream);
 
 /* ---- attention v2: LDS-staged tiles + ds_read_b64_tr_b16 transposed operands; no transposed copies in HBM.
- * Same oracle lines as afk_attn_*.  head_dim 64 / 128.  LSE and delta are [B, Hq, Spad] (Spad % 64 == 0, zero-initialised). */
+ * Same oracle lines as afk_attn_*.  head_dim 64 / 128.  LSE and delta are [B, Hq, Spad] (Spad % 64 == 0, zero-initialised) and INTERNAL
+ * to these three calls (forward: minus the log-sum-exp in score units; delta: minus rowsum(dO o O)).
+ * kv_len[b] (nullable): keys >= kv_len[b] are padding.  kv_lo[b] (nullable, causal only): keys < kv_lo[b] are padding - the left-padded
+ * batches of the reference processor (processing_audioflamingo3.py:46); query rows < kv_lo[b] produce zero output rows and zero gradients. */
 int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
                   int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
-                  int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, int B, int Hq, int Hkv, int S, int Spad,
+                  int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
                   int D, float scale, int causal, void* stream);
 int afk_attn2_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs,
                     int64_t do_rs, float* delta, int B, int H, int S, int Spad, int D, void* stream);
@@ -211,7 +214,7 @@ int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
                   int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
                   int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
-                  int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, int B, int Hq, int Hkv, int S,
+                  int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
                   int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream);
 /* gqa_scratch: NULL, or 2*B*S*Hq*D bf16 - enables the one-block-per-query-head dK/dV sweep + group reduce (GQA) */
 
