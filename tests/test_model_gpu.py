@@ -123,15 +123,19 @@ def _golden_assert(rep, floor):
     assert not bad, (bad, rep)
 
 
-@pytest.mark.parametrize("case", ["A", "B", "C"])
+@pytest.mark.parametrize("case", ["A", "B", "C", "C-interval"])
 def test_forward_backward_vs_reference_golden(dev, case):
     """A: full windows; B: padded window + RIGHT-padded row (kv_len path); C: the batch the reference's own AudioFlamingo3Processor
-    builds - LEFT padded (interval attention path), labels from output_labels=True - handed over as the processor hands it (CPU tensors).
+    builds - LEFT padded, labels from output_labels=True - handed over as the processor hands it (CPU tensors): the decoder's causal
+    LDS-staged kernels with kv_lo; C-interval: the same batch on the interval kernels (what head sizes other than 64 / 128 take).
     Every figure is reported beside the reference's own bf16-on-device run against the same fp32 golden (noise floor)."""
     from audio_flamingo_amd import ops
 
+    interval = case == "C-interval"
+    case = case[0]
     g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
     m = _model(dev)
+    m.left_pad_on_lds_kernels = not interval
     m.zero_grad()
     ops.kernel_counts(reset=True)
     if case == "C":
@@ -144,10 +148,13 @@ def test_forward_backward_vs_reference_golden(dev, case):
     out.loss.backward()
     torch.cuda.synchronize()
     cnt = ops.kernel_counts()
-    assert (cnt["xattn_fwd"] >= 2 and cnt["xattn_bwd"] >= 2) if case == "C" else cnt["xattn_fwd"] == 0, cnt
+    if interval:
+        assert cnt["xattn_fwd"] >= 2 and cnt["xattn_bwd"] >= 2, cnt
+    else:
+        assert cnt["xattn_fwd"] == 0 and cnt["attn2_fwd_d64"] >= 2 and cnt["attn2_bwd_d64"] >= 2, cnt   # tiny64 decoder: head_dim 64
     rep = _golden_compare(g, out, m)
     floor = _floor(_ref_bf16(dev), g, dev)
-    REPORT[f"case{case}"] = {"ours": rep, "reference_bf16_on_device": floor}
+    REPORT[f"case{case}" + ("_interval_kernels" if interval else "")] = {"ours": rep, "reference_bf16_on_device": floor}
     _dump()
     _golden_assert(rep, floor)
 

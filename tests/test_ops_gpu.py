@@ -501,6 +501,51 @@ def test_attention(dev, B, S, Hq, Hkv, D, causal, pad):
     _cmp("attn dv", dqkv[:, nq + nk:], qr.grad[:, nq + nk:], atol=4e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,lo,hi", [
+    (4, 200, 4, 2, 128, (0, 37, 64, 130), (200, 200, 190, 200)),     # lo inside a tile, on a tile edge, beyond the first query block
+    (3, 330, 4, 4, 64, (5, 128, 300), (330, 300, 330)),
+    (2, 1024, 14, 2, 128, (0, 700), (1024, 1024)),                     # GQA group 7 split-head sweep, whole key blocks of padding
+])
+def test_attention_left_padded(dev, B, S, Hq, Hkv, D, lo, hi):
+    """causal attention over keys [kv_lo[b], kv_len[b]) - the left-padded batches of the reference processor - on the LDS-staged kernels:
+    values vs the fp32 reference on the valid rows, exact zeros on the padded rows (output, dQ) and padded keys (dK, dV)"""
+    ops = _ops()
+    ld = (Hq + 2 * Hkv) * D
+    qkv = _rand((B * S, ld), dev, 1.0, 11).to(BF)
+    do = _rand((B * S, Hq * D), dev, 1.0, 12).to(BF)
+    scale = D ** -0.5
+    kv_lo = torch.tensor(lo, device=dev, dtype=torch.int32)
+    kv_len = torch.tensor(hi, device=dev, dtype=torch.int32)
+    ops.kernel_counts(reset=True)
+    o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+    cnt = ops.kernel_counts()
+    fam = "d128" if D == 128 else "d64"
+    assert cnt[f"attn2_fwd_{fam}"] == 1 and cnt[f"attn2_bwd_{fam}"] == 1, cnt
+    # fp32 reference
+    qr = qkv.float().requires_grad_(True)
+    q = qr[:, : Hq * D].reshape(B, S, Hq, D).transpose(1, 2)
+    k = qr[:, Hq * D: (Hq + Hkv) * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    v = qr[:, (Hq + Hkv) * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+    ar = torch.arange(S, device=dev)
+    dead = (ar[None, :] < kv_lo[:, None].long()) | (ar[None, :] >= kv_len[:, None].long())      # [B, S] keys
+    mask = dead[:, None, None, :] | torch.triu(torch.ones(S, S, dtype=torch.bool, device=dev), 1)[None, None]
+    s_ = (q @ k.transpose(-1, -2)) * scale
+    p_ = torch.nan_to_num(torch.softmax(s_.masked_fill(mask, float("-inf")), -1), nan=0.0)   # fully masked rows -> zero rows
+    ref = (p_ @ v).transpose(1, 2).reshape(B * S, Hq * D)
+    ref.backward(do.float())
+    row_pad = (ar[None, :] < kv_lo[:, None].long()).reshape(-1)      # padded QUERY rows (left padding); right-padded rows still see keys
+    key_pad = dead.reshape(-1)
+    nq, nk = Hq * D, Hkv * D
+    assert torch.isfinite(o.float()).all() and torch.isfinite(dqkv.float()).all()
+    assert (o[row_pad] == 0).all() and (dqkv[row_pad, :nq] == 0).all(), "padded query rows must be exact zeros"
+    assert (dqkv[key_pad, nq:] == 0).all(), "padded keys must get zero dK / dV"
+    _cmp("lpad fwd", o, ref, atol=2e-2, rtol=2e-2)
+    _cmp("lpad dq", dqkv[:, :nq], qr.grad[:, :nq], atol=3e-2, rtol=3e-2)
+    _cmp("lpad dk", dqkv[:, nq: nq + nk], qr.grad[:, nq: nq + nk], atol=4e-2, rtol=3e-2)
+    _cmp("lpad dv", dqkv[:, nq + nk:], qr.grad[:, nq + nk:], atol=4e-2, rtol=3e-2)
+
+
 def test_attention_online_softmax_spike(dev):
     """force a late running-max jump (guide rule 26): one key row aligned with one query row at a late tile"""
     ops = _ops()
