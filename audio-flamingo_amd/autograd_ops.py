@@ -194,20 +194,20 @@ class _SelfAttn(torch.autograd.Function):
     q [B*S, Hq*D], k / v [B*S, Hkv*D] row-strided views (e.g. slices of a fused projection).  GQA when Hkv < Hq."""
 
     @staticmethod
-    def forward(ctx, q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal):
+    def forward(ctx, q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal, kv_lo=None):
         spad = ops.pad64(S)
         o = torch.empty((B * S, Hq * D), device=q.device, dtype=BF16)
         lse = torch.zeros((B, Hq, spad), device=q.device, dtype=torch.float32)
         _lib.call("afk_attn2_fwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
                   v.data_ptr(), S * v.stride(0), D, v.stride(0), o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len),
-                  0, B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
-        ctx.save_for_backward(q, k, v, o, lse, kv_len)
+                  _p(kv_lo), B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+        ctx.save_for_backward(q, k, v, o, lse, kv_len, kv_lo)
         ctx.meta = (B, S, Hq, Hkv, D, scale, causal)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse, kv_len = ctx.saved_tensors
+        q, k, v, o, lse, kv_len, kv_lo = ctx.saved_tensors
         B, S, Hq, Hkv, D, scale, causal = ctx.meta
         do = do.contiguous()
         dev, spad, ldo, ldk = q.device, ops.pad64(S), Hq * D, Hkv * D
@@ -220,14 +220,17 @@ class _SelfAttn(torch.autograd.Function):
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * q.stride(0), D, q.stride(0), k.data_ptr(), S * k.stride(0), D, k.stride(0),
                   v.data_ptr(), S * v.stride(0), D, v.stride(0), do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(),
                   dq.data_ptr(), S * ldo, D, ldo, dk.data_ptr(), S * ldk, D, ldk, dv.data_ptr(), S * ldk, D, ldk, _p(kv_len),
-                  0, B, Hq, Hkv, S, spad, D, float(scale), int(causal), _p(scratch), _stream())
-        return dq, dk, dv, None, None, None, None, None, None, None, None
+                  _p(kv_lo), B, Hq, Hkv, S, spad, D, float(scale), int(causal), _p(scratch), _stream())
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None
 
 
-def self_attention(q, k, v, *, B, S, Hq, Hkv, D, scale, causal, kv_len=None):
+def self_attention(q, k, v, *, B, S, Hq, Hkv, D, scale, causal, kv_len=None, kv_lo=None):
+    """sample b exposes keys [kv_lo[b], kv_len[b]) (int32 [B] on the device, None = no padding on that side); kv_lo needs causal"""
     if D not in (64, 128):
         raise ValueError(f"self_attention: head_dim {D} not supported by the LDS-staged kernels (64 / 128); use cross_attention")
-    return _SelfAttn.apply(q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal)
+    if kv_lo is not None and not causal:
+        raise ValueError("self_attention: kv_lo (left padding) is defined for causal attention only")
+    return _SelfAttn.apply(q, k, v, kv_len, B, S, Hq, Hkv, D, scale, causal, kv_lo)
 
 
 # ---------------------------------------------------------------------------------------------- decoder pieces in general-purpose form

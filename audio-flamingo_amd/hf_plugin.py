@@ -12,7 +12,10 @@ so the reference's own `AudioFlamingo3ForConditionalGeneration` on a ROCm device
 one call:   audio_flamingo_amd.hf_plugin.register();  model.set_attn_implementation("afk_mi355x").
 
   * no mask, Q == K, head_dim 64/128     -> LDS-staged kernels (afk_attn2_*), causal iff `module.is_causal`
-  * everything else (bool mask - left/right padding, causal+padding -, Q != K decode steps, other head dims)
+  * bool mask, Q == K, head_dim 64/128, and the mask is "causal AND key in [lo_b, hi_b)" (left / right padded decoder batches) or
+    "every row sees [0, hi_b)" (right-padded encoder windows)
+                                         -> the same kernels with kv_lo / kv_len per sample
+  * everything else (other interval-shaped masks, Q != K decode steps, other head dims)
                                          -> interval kernels (afk_xattn_*): every query row attends a contiguous key interval
                                             [lo, hi); the mask is converted to those intervals on device and VERIFIED to be
                                             interval-shaped (one host sync per mask tensor OBJECT: the layers of one forward
@@ -50,16 +53,40 @@ def _intervals(mask: torch.Tensor) -> torch.Tensor:
     return torch.stack([lo, lo + cnt], dim=-1).contiguous()
 
 
-def _intervals_of(attention_mask: torch.Tensor, B: int, Q: int, K: int) -> torch.Tensor:
-    """intervals of the mask tensor the model hands to every layer of ONE forward (same object, same version -> same contents)"""
+def _padding_form(kr: torch.Tensor, Q: int, K: int):
+    """Is the interval table one of the two padding forms the LDS-staged kernels take?  -> ("causal" | "full", kv_lo | None, kv_len) or None
+         causal:  row i of sample b sees [lo_b, min(i + 1, hi_b))   (left / right padded causal self-attention; rows i < lo_b are padding)
+         full:    every row of sample b sees [0, hi_b)              (right-padded bidirectional self-attention)
+    Decided on the device, read back once per mask tensor (the caller caches it)."""
+    if Q != K:
+        return None
+    lo_b, hi_b = kr[:, Q - 1, 0], kr[:, Q - 1, 1]        # the last row sees the sample's whole key range in both forms
+    lo, end = kr[..., 0], kr[..., 1]
+    i1 = torch.arange(1, Q + 1, device=kr.device, dtype=torch.int32)[None]
+    live = i1 > lo_b[:, None]                              # query rows that are not left padding
+    c_end = torch.maximum(torch.minimum(i1, hi_b[:, None]), lo_b[:, None])
+    is_causal = ((~live) | ((lo == lo_b[:, None]) & (end == c_end))).all()
+    is_full = ((lo == 0) & (end == hi_b[:, None])).all()
+    any_lo = (lo_b > 0).any()
+    c, f, a = (bool(x) for x in torch.stack([is_causal, is_full, any_lo]).tolist())
+    if c:
+        return "causal", (lo_b.contiguous() if a else None), hi_b.contiguous()
+    if f:
+        return "full", None, hi_b.contiguous()
+    return None
+
+
+def _intervals_of(attention_mask: torch.Tensor, B: int, Q: int, K: int):
+    """(intervals, padding form) of the mask tensor the model hands to every layer of ONE forward (same object, same version -> same contents)"""
     shape = (B, Q, K)
-    for ref, ver, shp, kr in _mask_cache:
+    for ref, ver, shp, kr, form in _mask_cache:
         if ref() is attention_mask and ver == attention_mask._version and shp == shape:
-            return kr
+            return kr, form
     kr = _intervals(attention_mask[..., :K].expand(B, 1, Q, K))
+    form = _padding_form(kr, Q, K)
     _mask_cache[:] = [e for e in _mask_cache if e[0]() is not None][-3:]
-    _mask_cache.append((weakref.ref(attention_mask), attention_mask._version, shape, kr))
-    return kr
+    _mask_cache.append((weakref.ref(attention_mask), attention_mask._version, shape, kr, form))
+    return kr, form
 
 
 def _rows(t: torch.Tensor) -> torch.Tensor:
@@ -81,15 +108,22 @@ def afk_attention(module, query, key, value, attention_mask: Optional[torch.Tens
     scale = float(scaling) if scaling is not None else D ** -0.5
     causal = bool(is_causal if is_causal is not None else getattr(module, "is_causal", False)) and Q > 1
     q, k, v = _rows(query), _rows(key), _rows(value)
+    krange, form = None, None
+    if attention_mask is not None:
+        if attention_mask.dtype != torch.bool:
+            raise NotImplementedError("afk attention plugin: only boolean masks (the sdpa mask interface) are supported")
+        krange, form = _intervals_of(attention_mask, B, Q, K)
     if attention_mask is None and Q == K and D in (64, 128):
         calls["lds"] += 1
         o = A.self_attention(q, k, v, B=B, S=Q, Hq=Hq, Hkv=Hkv, D=D, scale=scale, causal=causal)
+    elif form is not None and D in (64, 128):
+        # a padded batch whose mask is "causal (or full) AND key in [lo_b, hi_b)": the LDS-staged kernels with kv_lo / kv_len
+        calls["lds"] += 1
+        o = A.self_attention(q, k, v, B=B, S=Q, Hq=Hq, Hkv=Hkv, D=D, scale=scale, causal=form[0] == "causal", kv_lo=form[1], kv_len=form[2])
     else:
         calls["interval"] += 1
         if attention_mask is not None:
-            if attention_mask.dtype != torch.bool:
-                raise NotImplementedError("afk attention plugin: only boolean masks (the sdpa mask interface) are supported")
-            krange = _intervals_of(attention_mask, B, Q, K)
+            pass
         elif causal:
             i = torch.arange(Q, device=query.device, dtype=torch.int32) + (K - Q)
             krange = torch.stack([torch.zeros_like(i), i + 1], -1).expand(B, Q, 2).contiguous()
