@@ -74,16 +74,40 @@ def test_hf_plugin_mask_cache_is_keyed_on_the_tensor_object():
 
     m1 = torch.ones(2, 1, 4, 6, dtype=torch.bool)
     m1[0, :, :, :2] = False
-    k1 = hf_plugin._intervals_of(m1, 2, 4, 6).clone()
+    k1 = hf_plugin._intervals_of(m1, 2, 4, 6)[0].clone()
     assert k1[0, 0].tolist() == [2, 6]
     m1[0, :, :, :3] = False                      # in-place change: version bump must invalidate
-    assert hf_plugin._intervals_of(m1, 2, 4, 6)[0, 0].tolist() == [3, 6]
+    assert hf_plugin._intervals_of(m1, 2, 4, 6)[0][0, 0].tolist() == [3, 6]
     ptr = m1.data_ptr()
     del m1
     m2 = torch.ones(2, 1, 4, 6, dtype=torch.bool)  # typically the same storage address
     m2[1, :, :, 4:] = False
-    k2 = hf_plugin._intervals_of(m2, 2, 4, 6)
+    k2, form = hf_plugin._intervals_of(m2, 2, 4, 6)
+    assert form is None   # Q != K: not a self-attention padding form
     assert k2[0, 0].tolist() == [0, 6] and k2[1, 0].tolist() == [0, 4], (k2, ptr == m2.data_ptr())
+
+
+def test_hf_plugin_recognises_padding_forms():
+    """masks of the form "causal (or full) AND key in [lo_b, hi_b)" go to the LDS-staged kernels with kv_lo / kv_len; anything else stays
+    on the interval kernels"""
+    from audio_flamingo_amd import hf_plugin
+
+    S = 7
+    tri = torch.tril(torch.ones(S, S, dtype=torch.bool))
+    keys = torch.ones(3, S, dtype=torch.bool)
+    keys[1, :2] = False       # left padded by 2
+    keys[2, 5:] = False       # right padded to 5
+    m = (tri[None, None] & keys[:, None, None, :]).clone()
+    m[1, 0, :2] = False       # padded query rows: whatever the mask builder leaves there
+    kr, form = hf_plugin._intervals_of(m, 3, S, S)
+    assert form[0] == "causal" and form[1].tolist() == [0, 2, 0] and form[2].tolist() == [7, 7, 5]
+    full = keys[:, None, None, :].expand(3, 1, S, S).clone()
+    full[1] = True
+    kr, form = hf_plugin._intervals_of(full, 3, S, S)
+    assert form[0] == "full" and form[1] is None and form[2].tolist() == [7, 7, 5]
+    band = (tri & ~torch.tril(torch.ones(S, S, dtype=torch.bool), -3))[None, None].expand(3, 1, S, S).clone()   # sliding window: intervals, not padding
+    kr, form = hf_plugin._intervals_of(band, 3, S, S)
+    assert form is None and kr[0, 5].tolist() == [3, 6]
 
 
 def test_oracle_logmel_matches_reference():
