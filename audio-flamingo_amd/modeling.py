@@ -509,11 +509,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 src = torch.where(src >= 0, row.to(torch.int32), src).contiguous()
         return ops.embed_scatter_fwd(ids_flat, src, a[lm + "embed_tokens.weight"].data, audio)
 
-    def _decode_layers(self, x, B, n, start, cache, pos_rows, krange, fast_prefill, start_dev=None):
+    def _decode_layers(self, x, B, n, start, cache, pos_rows, krange, fast_prefill, start_dev=None, kv_lo=None):
         """all decoder layers on n new positions per sample (rows [B*n, H]) at cache offset `start` (or *start_dev: graph replay).
         cache = (K [L, B, Smax, Hkv*D] post-RoPE keys, Vt [L, B, Hkv, D, Smaxpad] values stored transposed: the layout the interval
-        attention kernels read directly).  Attention: prefill without padding on the LDS-staged causal kernel; everything else
-        (decode steps, padded batches) on the interval kernel: query row i of sample b sees keys [krange[b,i,0], krange[b,i,1]);
+        attention kernels read directly).  Attention: prefill on the LDS-staged causal kernel (left-padded prompts: kv_lo); everything else
+        (decode steps, other head sizes) on the interval kernel: query row i of sample b sees keys [krange[b,i,0], krange[b,i,1]);
         with start_dev the kernel is given the whole cache length and the interval alone bounds what is visible."""
         a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
         Kc, Vt = cache
@@ -530,7 +530,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             _lib.call("afk_kv_cache_append", qkv.data_ptr(), ld, nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
                       ops._p(start_dev), int(start or 0), B, n, Hkv, D, ops._stream())
             if fast_prefill:
-                o, _ = ops.attn_fwd(qkv, B, n, Hq, Hkv, D, scale=D ** -0.5, causal=True)
+                o, _ = ops.attn_fwd(qkv, B, n, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_lo=kv_lo)
             elif n == 1 and D in (64, 128) and self.decode_splits > 0:
                 # one query row per sample: split-KV kernel (the cache is read once, nsplit blocks per head)
                 o = torch.empty((B, nq), device=x.device, dtype=torch.bfloat16)
@@ -679,8 +679,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         pos_rows = (ar[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()          # position_ids = cumsum(mask) - 1
         krange = torch.stack([lo[:, None].expand(B, S0), torch.maximum(ar[None, :] + 1, lo[:, None])], -1).contiguous()  # [lo, i+1)
         x = self._merged_embeddings(ids, input_features, input_features_mask)
-        fast = (not padded) and self.D in (64, 128) and ops.ATTN_IMPL == "lds"
-        y = self._decode_layers(x, B, S0, 0, (Kc, Vt), pos_rows, krange, fast)
+        fast = self.D in (64, 128) and ops.ATTN_IMPL == "lds" and (self.left_pad_on_lds_kernels or not padded)
+        y = self._decode_layers(x, B, S0, 0, (Kc, Vt), pos_rows, krange, fast, kv_lo=lo if padded else None)
         last = y.reshape(B, S0, -1)[:, -1, :].contiguous()
         st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
               "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling,
