@@ -111,7 +111,7 @@ def splitk_plan(M, N, K):
 
 
 def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None,
-         accumulate=False, alpha=1.0):
+         accumulate=False, alpha=1.0, _splits=None):
     """General form of the MFMA GEMM (C ABI afk_gemm_bf16).
         NT: a [M,K],  b [N,K]            (forward)
         NN: a [M,K],  b [K,N]  trans_b   (dgrad: dX = dY . W)
@@ -141,7 +141,21 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=No
         flags |= GEMM_OUT_F32
     if accumulate:
         flags |= GEMM_ACCUM
-    splits = splitk_plan_256(M, N, K) if trans_b else 1
+    if _splits is None and trans_a and trans_b and PEEL_TAIL and bias is None and residual is None and not gelu and preact_out is None:
+        plan = peel_plan_256(M, N, K)
+        if plan is not None:
+            # wave quantisation: T = 8.09 (gate|up wgrad) or 4.05 (down wgrad) rounds of 256 tiles pay for a nearly empty last round.  Peel
+            # the last tile rows (or columns) off: the main launch fills whole rounds, the strip runs split-K in one short round.
+            axis, cut, s = plan
+            kw = dict(trans_a=True, trans_b=True, accumulate=accumulate, alpha=alpha)
+            if axis == 0:
+                gemm(a[:, :cut], b, out[:cut], _splits=1, **kw)
+                gemm(a[:, cut:M], b, out[cut:M], _splits=s, **kw)
+            else:
+                gemm(a, b[:, :cut], out[:, :cut], _splits=1, **kw)
+                gemm(a, b[:, cut:N], out[:, cut:N], _splits=s, **kw)
+            return out
+    splits = _splits if _splits is not None else (splitk_plan_256(M, N, K) if trans_b else 1)
     if splits > 1:
         ws = torch.empty(splits * M * N, device=a.device, dtype=torch.float32)
         _lib.call("afk_gemm_bf16_splitk", int(trans_a), int(trans_b), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
@@ -155,6 +169,35 @@ def gemm(a, b, out=None, *, trans_a=False, trans_b=False, bias=None, residual=No
 
 
 SPLITK_ROUND = int(os.environ.get("AFK_SPLITK_ROUND", "256"))
+# Off by default - measured on the full step (same box, 2 runs each): the serial GEMM time falls 314.7 -> 309.8 ms/step (gate|up and down
+# weight gradients lose their nearly empty ninth / fifth round), but the default three-stream schedule gets SLOWER, 431.4 -> 433.7 / 437.1 ms:
+# its second stream was already filling those tails, and the strip adds two launches and a 60 MB fp32 workspace per weight gradient.
+PEEL_TAIL = os.environ.get("AFK_PEEL_TAIL", "0") == "1"
+
+
+def peel_plan_256(M, N, K):
+    """TN GEMM whose 256x256 tiles end in a nearly empty round of 256 workgroups: -> (axis, cut, splits) = run rows (axis 0) / columns
+    (axis 1) [0, cut) as the main launch (whole rounds) and the remaining strip with `splits` K-splits in one short round; None = leave it.
+    Cost model in rounds: ceil(main tiles / 256) + 1 / splits + 0.08 (second launch + fold) against ceil(tiles / 256)."""
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    T = tm * tn
+    if T <= 256 or K < 2048:
+        return None
+    base = (T + 255) // 256
+    best = None
+    for axis, (t_long, t_other) in enumerate(((tm, tn), (tn, tm))):
+        for r in range(1, 9):
+            t_tail = r * t_other
+            t_main = T - t_tail
+            if r >= t_long or t_tail > 128:
+                break
+            sp = min(16, (K // 64) // 8, SPLITK_ROUND // t_tail)
+            if sp < 2:
+                continue
+            cost = (t_main + 255) // 256 + 1.0 / sp + 0.08
+            if cost < base - 0.3 and (best is None or cost < best[0]):
+                best = (cost, axis, (t_long - r) * 256, sp)
+    return None if best is None else best[1:]
 
 
 def splitk_plan_256(M, N, K):

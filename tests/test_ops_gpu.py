@@ -454,6 +454,34 @@ def test_gemm_tn_splitk(dev):
         _cmp("tn splitk accumulate", acc, 2 * ref, atol=K ** 0.5 * 4e-2, rtol=3e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(8448, 2048, 4096), (2048, 8704, 4096)])
+def test_gemm_tn_peeled_tail(dev, request, M, N, K):
+    """TN weight gradients whose tile count ends in a nearly empty round (264 / 272 tiles on 256 CUs): the last tile rows / columns run as a
+    split-K strip (ops.peel_plan_256).  Same values as the single launch outside the strip (bit for bit), fp32-reference tolerance inside,
+    deterministic, accumulate honoured on both parts"""
+    ops = _ops()
+    plan = ops.peel_plan_256(M, N, K)
+    assert plan is not None and plan[0] == (0 if M > N else 1), plan
+    at = _rand((K, M), dev, 1.0, 1).to(BF)
+    bt = _rand((K, N), dev, 1.0, 2).to(BF)
+    one = ops.gemm(at, bt, trans_a=True, trans_b=True)
+    was, ops.PEEL_TAIL = ops.PEEL_TAIL, True   # opt-in (AFK_PEEL_TAIL=1): slower on the overlapped step, see ops.py
+    request.addfinalizer(lambda: setattr(ops, "PEEL_TAIL", was))
+    ops.kernel_counts(reset=True)
+    c = ops.gemm(at, bt, trans_a=True, trans_b=True)
+    cnt = ops.kernel_counts()
+    assert cnt["gemm_tn256"] == 2 and cnt["gemm_splitk"] == 1, cnt
+    axis, cut, _ = plan
+    main_c, main_1 = (c[:cut], one[:cut]) if axis == 0 else (c[:, :cut], one[:, :cut])
+    assert torch.equal(main_c, main_1), "rows / columns outside the strip must not change"
+    ref = at.float().T @ bt.float()
+    _cmp("tn peeled", c, ref, atol=K ** 0.5 * 2e-2, rtol=2e-2)
+    assert torch.equal(ops.gemm(at, bt, trans_a=True, trans_b=True), c), "peeled TN GEMM not deterministic"
+    acc = c.clone()
+    ops.gemm(at, bt, out=acc, trans_a=True, trans_b=True, accumulate=True)
+    _cmp("tn peeled accumulate", acc, 2 * ref, atol=K ** 0.5 * 4e-2, rtol=3e-2)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _attn_ref(qkv, B, S, Hq, Hkv, D, scale, causal, kv_len):
     q = qkv[:, : Hq * D].float().reshape(B, S, Hq, D).transpose(1, 2)
