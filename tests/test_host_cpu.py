@@ -265,3 +265,16 @@ def test_library_is_a_build_of_this_tree():
 
     lib = _lib.load()
     assert lib.afk_build_id().decode() == _lib.source_hash()
+
+
+def test_peel_plan_for_nearly_empty_last_rounds():
+    """the opt-in tail peel of the TN weight-gradient GEMMs: only shapes whose 256x256 tiles end in a nearly empty round get a plan, the
+    strip is cut on a tile boundary and runs as one round of split-K workgroups"""
+    from audio_flamingo_amd import ops
+
+    axis, cut, sp = ops.peel_plan_256(37888, 3584, 8192)        # gate|up wgrad: 2 072 tiles = 8.09 rounds
+    assert (axis, cut) == (0, 146 * 256) and 2 <= sp <= 16 and (37888 - cut) // 256 * 14 * sp <= 256
+    axis, cut, sp = ops.peel_plan_256(3584, 18944, 8192)        # down wgrad: 1 036 tiles = 4.05 rounds
+    assert (axis, cut) == (1, 73 * 256) and 14 * sp <= 256
+    for shape in [(4608, 3584, 8192), (3584, 3584, 8192), (8192, 3584, 3584), (12000, 5120, 1280), (1280, 1280, 12000)]:
+        assert ops.peel_plan_256(*shape) is None, shape
