@@ -244,7 +244,7 @@ extern "C" int afk_gemm_set_variant(int v) {
     g_gm = (v >> 8) & 255;
     g_wide = (v & 16) ? 0 : 1;
     v &= 15;
-    AFK_REQUIRE(v >= 0 && v <= 12, "afk_gemm_set_variant: 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
+    AFK_REQUIRE(v >= 0 && v <= 13, "afk_gemm_set_variant: 13 = 256x256 ping-pong as a persistent tile loop, 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
     g_variant = v;
     return AFK_OK;
 }
@@ -334,11 +334,12 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
     static const int env_impl = [] {
         const char* e = getenv("AFK_GEMM256");
-        return (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : (e && e[0] == 'f') ? 10 : 0;
+        return (e && e[0] == 'p' && e[1] == 'e') ? 13 : (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : (e && e[0] == 'f') ? 10 : 0;  // pp | persist | w4 | f8
     }();
     const int impl256 = g_variant >= 2 ? g_variant : (env_impl ? env_impl : g_256_impl);   // 2 pp | 3..9 w4 family | 10, 11 f8
     const bool w4 = use256 && !trans_b && impl256 >= 3 && impl256 <= 9;
-    const bool f8 = use256 && !trans_b && impl256 >= 10;
+    const bool f8 = use256 && !trans_b && impl256 >= 10 && impl256 <= 12;
+    const bool persist = use256 && !trans_b && impl256 == 13;
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -381,7 +382,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
         }
     } else if (use256) {
-        if (int e = f8 ? afk_launch_gemm256f8(p, impl256 - 10, st) : w4 ? afk_launch_gemm256w4(p, impl256 - 3, st) : afk_launch_gemm256(p, st)) return e;
+        if (int e = persist ? afk_launch_gemm256p(p, st) : f8 ? afk_launch_gemm256f8(p, impl256 - 10, st) : w4 ? afk_launch_gemm256w4(p, impl256 - 3, st) : afk_launch_gemm256(p, st)) return e;
     } else {
         hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg, (unsigned)splits), dim3(256), NSTAGE * STAGE_BYTES, st, p);
         if (splits > 1) {

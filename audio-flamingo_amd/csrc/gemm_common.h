@@ -27,8 +27,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 
 // workgroup -> tile: XCD-contiguous (bijective remap of the round-robin dispatch) then grouped along M so that
 // the tiles resident on one XCD share A and B panels through that XCD's private L2.
-__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, int& tn) {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+__device__ __forceinline__ void gemm_tile_of(const GemmArgs& p, int bid, int nwg, int& tm, int& tn) {
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
     const int swz = (p.gm & 0x80) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bit 7 of gm: raw dispatch order (experiment)
     const int GM = (p.gm & 0x7f) > 0 ? (p.gm & 0x7f) : 4;
@@ -39,6 +38,7 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, i
     tm = first_m + rem % gsz;
     tn = rem / gsz;
 }
+__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, int& tn) { gemm_tile_of(p, blockIdx.x, gridDim.x, tm, tn); }
 
 // epilogue for W (4 or 8) consecutive n of one row m (values already hold the fp32 accumulators)
 // order: *alpha, +bias[n] -> (round bf16, write preact, GELU-erf) -> (round bf16, +residual) -> (+C if ACCUM) -> store
@@ -162,6 +162,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
+int afk_launch_gemm256p(const GemmArgs& p, hipStream_t st);  // persistent tile loop (gemm256p.hip)
 // 256x256, K-step 32, eight free-running waves, ten-slot LDS ring (gemm256f8.hip); mode 1 = no-DMA timing probe
 int afk_launch_gemm256f8(const GemmArgs& p, int mode, hipStream_t st);
 // 256x256 four-wave kernel, 128x128 per wave, accumulators in AGPRs (gemm256w4.hip)

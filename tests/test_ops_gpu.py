@@ -47,7 +47,7 @@ def test_gemm_plain(dev, M, N, K):
     _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 6, 10, 13])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 260, 320), (1000, 1280, 1280), (8, 512, 4096),
                                    (777, 1028, 64), (2048, 256, 2048)])
 def test_gemm_variants(dev, variant, M, N, K):
@@ -67,6 +67,32 @@ def test_gemm_variants(dev, variant, M, N, K):
             assert torch.equal(ops.gemm_nt(a, b, bias=bias), c), "non-deterministic GEMM result (LDS race?)"
     finally:
         ops.gemm_set_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 8192, 512), (5120, 7680, 64), (5000, 7700, 192), (8192, 9472, 1280)])
+def test_gemm_persistent_tile_loop_matches_one_tile_per_workgroup(dev, M, N, K):
+    """variant 13 (gemm256p.hip: one workgroup per CU walks 2-5 tiles, next prologue issued behind the previous tile's stores) must give
+    the ping-pong kernel's result bit for bit - same per-tile arithmetic - with every epilogue the step uses, and stay so when repeated"""
+    ops = _ops()
+    a = _rand((M, K), dev, seed=31).to(BF)
+    b = _rand((N, K), dev, seed=32).to(BF)
+    bias = _rand((N,), dev, seed=33).to(BF)
+    res = _rand((M, N), dev, seed=34).to(BF)
+    outs = {}
+    for variant in (2, 13):
+        ops.gemm_set_variant(variant)
+        try:
+            pre = torch.empty((M, N), device=dev, dtype=BF)
+            outs[variant] = (ops.gemm_nt(a, b), ops.gemm_nt(a, b, bias=bias, gelu=True, preact_out=pre), pre,
+                             ops.gemm_nt(a, b, residual=res), ops.gemm_nt(a, b, out=res.clone(), accumulate=True))
+            if variant == 13:
+                for _ in range(3):
+                    assert torch.equal(ops.gemm_nt(a, b), outs[13][0]), "persistent GEMM not deterministic (LDS hand-over between tiles?)"
+        finally:
+            ops.gemm_set_variant(0)
+    for x, y in zip(outs[2], outs[13]):
+        assert torch.equal(x, y)
+    _cmp("persistent vs fp32", outs[13][0], a.float() @ b.float().t(), atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (304, 264, 320), (1000, 1280, 1280), (8, 512, 4096), (2048, 256, 2048)])
