@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 __device__ __forceinline__ void gemm_tile_of(const GemmArgs& p, int bid, int nwg, int& tm, int& tn) {
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
     const int swz = (p.gm & 0x80) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bit 7 of gm: raw dispatch order (experiment)
-    const int GM = (p.gm & 0x7f) > 0 ? (p.gm & 0x7f) : 4;
+    const int GM = (p.gm & 0x3f) > 0 ? (p.gm & 0x3f) : 4;  // bit 6: no-epilogue timing probe (gemm256p.hip)
     const int per_group = GM * p.ntn;
     const int g = swz / per_group, rem = swz - g * per_group;
     const int first_m = g * GM;
