@@ -45,6 +45,8 @@ constexpr int LDS_BYTES = 2 * BUF_BYTES;  // 128 KiB
         __builtin_amdgcn_sched_barrier(0);    \
     } while (0)
 
+// EPI: compile-time epilogue flags (gemm_common.h), -1 = runtime flags / narrow stores / split-K partials
+template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -216,19 +218,36 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
+        for (int j = 0; j < 2; ++j) gemm_store_block32<EPI>(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
 }  // namespace
 
+// the epilogues of the AF3 training step get their own instantiation; anything else (SwiGLU backward, fp32 output, narrow stores) the generic one
+#define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_BIAS) X(AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_GELU) \
+    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(-1)
+
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_k256, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
+#define AFK_SET(F)                                                                                                                       \
+    if (hipFuncSetAttribute((const void*)gemm_nt_bf16_k256<(F)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) \
+        return afk_set_error(AFK_ERR_LAUNCH, "gemm256: cannot reserve %d bytes of LDS", LDS_BYTES);
+        AFK_EPI_LIST(AFK_SET)
+#undef AFK_SET
         attr_set = true;
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
-    hipLaunchKernelGGL(gemm_nt_bf16_k256, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+    const int f = (p.wide && p.splits <= 1) ? p.flags : -1;
+    switch (f) {
+#define AFK_CASE(F)                                                                                          \
+    case (F):                                                                                                \
+        hipLaunchKernelGGL(gemm_nt_bf16_k256<(F)>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);        \
+        break;
+        AFK_EPI_LIST(AFK_CASE)
+#undef AFK_CASE
+        default:
+            hipLaunchKernelGGL(gemm_nt_bf16_k256<-1>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
+    }
     return AFK_OK;
 }

@@ -81,7 +81,8 @@ __device__ __forceinline__ TSrc tsrc(const bf16* mat, int unit, int col0, int nc
     return s;
 }
 
-template <bool AT>
+// EPI: compile-time epilogue flags (gemm_common.h: one small epilogue instead of every variant inlined at each store site), -1 = runtime
+template <bool AT, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -310,24 +311,40 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
+        for (int j = 0; j < 2; ++j) gemm_store_block32<EPI>(p, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
 }  // namespace
 
+// weight gradients write or accumulate plain bf16 (flags 0 / ACCUM); the generic instantiation serves split-K partials and the rest
+#define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_ACCUM) X(-1)
+
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_xt_bf16_k256<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_xt_bf16_k256<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            return afk_set_error(AFK_ERR_LAUNCH, "gemm256t: cannot reserve %d bytes of LDS", LDS_BYTES);
+#define AFK_SET(F)                                                                                                                                \
+    if (hipFuncSetAttribute((const void*)gemm_xt_bf16_k256<false, (F)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess || \
+        hipFuncSetAttribute((const void*)gemm_xt_bf16_k256<true, (F)>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)    \
+        return afk_set_error(AFK_ERR_LAUNCH, "gemm256t: cannot reserve %d bytes of LDS", LDS_BYTES);
+        AFK_EPI_LIST(AFK_SET)
+#undef AFK_SET
         attr_set = true;
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
     const unsigned ns = (unsigned)(p.splits > 1 ? p.splits : 1);
-    if (trans_a)
-        hipLaunchKernelGGL(gemm_xt_bf16_k256<true>, dim3((unsigned)nwg, ns), dim3(512), LDS_BYTES, st, p);
-    else
-        hipLaunchKernelGGL(gemm_xt_bf16_k256<false>, dim3((unsigned)nwg, ns), dim3(512), LDS_BYTES, st, p);
+    const int f = (p.wide && p.splits <= 1) ? p.flags : -1;
+    const dim3 grid((unsigned)nwg, ns);
+    switch (f) {
+#define AFK_CASE(F)                                                                                                   \
+    case (F):                                                                                                         \
+        if (trans_a) hipLaunchKernelGGL((gemm_xt_bf16_k256<true, (F)>), grid, dim3(512), LDS_BYTES, st, p);          \
+        else hipLaunchKernelGGL((gemm_xt_bf16_k256<false, (F)>), grid, dim3(512), LDS_BYTES, st, p);                 \
+        break;
+        AFK_EPI_LIST(AFK_CASE)
+#undef AFK_CASE
+        default:
+            if (trans_a) hipLaunchKernelGGL((gemm_xt_bf16_k256<true, -1>), grid, dim3(512), LDS_BYTES, st, p);
+            else hipLaunchKernelGGL((gemm_xt_bf16_k256<false, -1>), grid, dim3(512), LDS_BYTES, st, p);
+    }
     return AFK_OK;
 }

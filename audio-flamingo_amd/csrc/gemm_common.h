@@ -42,11 +42,15 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& p, int& tm, i
 
 // epilogue for W (4 or 8) consecutive n of one row m (values already hold the fp32 accumulators)
 // order: *alpha, +bias[n] -> (round bf16, write preact, GELU-erf) -> (round bf16, +residual) -> (+C if ACCUM) -> store
-template <int W>
+// F >= 0: the epilogue flags are a compile-time constant (one kernel instantiation per epilogue the training step uses) - the kernel then
+// carries ONLY that epilogue.  With the runtime form (F = -1) every one of the 16 store sites of a wave inlines all variants (erf GELU,
+// SwiGLU backward with its divides, fp32 / accumulate forms): ~30 000 instructions, ~200 KB of code behind a 350-instruction K loop, and the
+// plain path hops through it once per tile - the instruction cache (64 KB per two CUs) misses all the way (profiles/r02_gemm_probes.md §10).
+template <int W, int F = -1>
 __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& p, int m, int n, float* v) {
     typedef __attribute__((ext_vector_type(W))) __bf16 bvec;
     typedef __attribute__((ext_vector_type(W))) float fvec;
-    const int flags = p.flags;
+    const int flags = F >= 0 ? F : p.flags;
 #pragma unroll
     for (int e = 0; e < W; ++e) v[e] *= p.alpha;
     if (flags & AFK_GEMM_BIAS) {
@@ -118,15 +122,17 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& p, int m, in
         *(bvec*)cp = o;
     }
 }
-__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, int n, float v[4]) { gemm_epilogue_store<4>(p, m, n, v); }
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, int n, float v[4]) { gemm_epilogue_store<4, -1>(p, m, n, v); }
 
 // One 32 (m) x 32 (n) MFMA result block of a wave: lane (l31, hi) holds row m and, in accumulator registers 4q..4q+3, the columns
 // nb + 8q + 4hi + {0..3}.  Wide form (p.wide: every pointer / leading dimension of the epilogue keeps 16-byte alignment): the two lane
 // halves trade registers through v_permlane32_swap so that each lane owns 8 CONSECUTIVE columns (nb + 16t + 8hi + 0..7) - 16-byte stores
 // and 16-byte bias / residual loads, half as many memory instructions as the 8-byte form.  Split-K partials keep the 4-wide form.
+// F >= 0 (specialised instantiation): the launcher guarantees p.wide and p.splits <= 1.
+template <int F = -1>
 __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc) {
     if (m >= p.M) return;
-    if (p.splits > 1) {
+    if (F < 0 && p.splits > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nb + 8 * q + 4 * hi;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
         }
         return;
     }
-    if (p.wide) {
+    if (F >= 0 || p.wide) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v[8];
@@ -147,7 +153,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
                 v[4 + e] = __uint_as_float(r[1]);  // lo lanes: partner's q=2t ; hi lanes: own q=2t+1
             }
             const int n = nb + 16 * t + 8 * hi;
-            if (n < p.N) gemm_epilogue_store<8>(p, m, n, v);
+            if (n < p.N) gemm_epilogue_store<8, F>(p, m, n, v);
         }
         return;
     }
@@ -156,7 +162,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
         const int n = nb + 8 * q + 4 * hi;
         if (n >= p.N) continue;
         float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
-        gemm_epilogue_store<4>(p, m, n, v);
+        gemm_epilogue_store<4, F>(p, m, n, v);
     }
 }
 
