@@ -600,6 +600,49 @@ def test_attention_left_padded(dev, B, S, Hq, Hkv, D, lo, hi):
     _cmp("lpad dv", dqkv[:, nq + nk:], qr.grad[:, nq + nk:], atol=4e-2, rtol=3e-2)
 
 
+def test_attention_random_padding_sweep(dev):
+    """seeded sweep over ragged shapes and paddings of the causal LDS kernels: S not a multiple of 64 / 128, kv_lo and kv_len anywhere (incl.
+    lo == hi: a fully padded sample, and lo in the last tile), GQA groups 1 / 2 / 7, both head sizes - forward and all three gradients"""
+    import random
+
+    ops = _ops()
+    rng = random.Random(1234)
+    for case in range(10):
+        D = rng.choice((64, 128))
+        Hkv = rng.choice((1, 2))
+        Hq = Hkv * rng.choice((1, 2, 7))
+        B = rng.randint(1, 3)
+        S = rng.choice((70, 129, 200, 257, 333, 450))
+        hi = [rng.randint(1, S) for _ in range(B)]
+        lo = [rng.randint(0, h) for h in hi]
+        if case == 0:
+            lo[0] = hi[0]                         # a sample that is padding only
+        kv_lo = torch.tensor(lo, device=dev, dtype=torch.int32)
+        kv_len = torch.tensor(hi, device=dev, dtype=torch.int32)
+        qkv = _rand((B * S, (Hq + 2 * Hkv) * D), dev, 1.0, 100 + case).to(BF)
+        do = _rand((B * S, Hq * D), dev, 1.0, 200 + case).to(BF)
+        scale = D ** -0.5
+        o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=scale, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+        dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+        qr = qkv.float().requires_grad_(True)
+        q = qr[:, : Hq * D].reshape(B, S, Hq, D).transpose(1, 2)
+        k = qr[:, Hq * D: (Hq + Hkv) * D].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+        v = qr[:, (Hq + Hkv) * D:].reshape(B, S, Hkv, D).transpose(1, 2).repeat_interleave(Hq // Hkv, 1)
+        ar = torch.arange(S, device=dev)
+        dead = (ar[None, :] < kv_lo[:, None].long()) | (ar[None, :] >= kv_len[:, None].long())
+        mask = dead[:, None, None, :] | torch.triu(torch.ones(S, S, dtype=torch.bool, device=dev), 1)[None, None]
+        p_ = torch.nan_to_num(torch.softmax(((q @ k.transpose(-1, -2)) * scale).masked_fill(mask, float("-inf")), -1), nan=0.0)
+        ref = (p_ @ v).transpose(1, 2).reshape(B * S, Hq * D)
+        ref.backward(do.float())
+        tag = f"sweep {case} (B={B} S={S} Hq={Hq} Hkv={Hkv} D={D} lo={lo} hi={hi})"
+        assert torch.isfinite(o.float()).all() and torch.isfinite(dqkv.float()).all(), tag
+        nq, nk = Hq * D, Hkv * D
+        _cmp(tag + " fwd", o, ref, atol=2e-2, rtol=2e-2)
+        _cmp(tag + " dq", dqkv[:, :nq], qr.grad[:, :nq], atol=3e-2, rtol=3e-2)
+        _cmp(tag + " dk", dqkv[:, nq: nq + nk], qr.grad[:, nq: nq + nk], atol=4e-2, rtol=3e-2)
+        _cmp(tag + " dv", dqkv[:, nq + nk:], qr.grad[:, nq + nk:], atol=4e-2, rtol=3e-2)
+
+
 def test_attention_online_softmax_spike(dev):
     """force a late running-max jump (guide rule 26): one key row aligned with one query row at a late tile"""
     ops = _ops()
