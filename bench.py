@@ -565,13 +565,13 @@ def main():
         samples_per_s = world * args.batch * args.steps / dt
         achieved_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_detail = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
         if os.path.exists(tpath):  # PMC passes cannot run inside bench.py; the committed rocprofv3 --pmc result is quoted
             with open(tpath) as f:
                 tj = json.load(f)
             traffic = tj["hbm_bytes_per_launch"]  # HBM bytes of ONE launch of the kernel on the shape below (largest GEMM of the step)
             traffic_detail = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                              "shape": tj["shape"], "source": "profiles/r01_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+                              "shape": tj["shape"], "source": "profiles/r02_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
         model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
         hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
         # lm_head + loss (forward, dgrad, wgrad) run only on the rows that carry a label: identical loss and gradients, fewer executed FLOPs.
