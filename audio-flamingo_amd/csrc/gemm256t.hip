@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
 }  // namespace
 
 // weight gradients write or accumulate plain bf16 (flags 0 / ACCUM); the generic instantiation serves split-K partials and the rest
-#define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_ACCUM) X(-1)
+#define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_ACCUM) X(-2) X(-1)
 
 int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
     static bool attr_set = false;
@@ -332,7 +332,7 @@ int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
     const unsigned ns = (unsigned)(p.splits > 1 ? p.splits : 1);
-    const int f = (p.wide && p.splits <= 1) ? p.flags : -1;
+    const int f = p.splits > 1 ? -2 : (p.wide ? p.flags : -1);  // -2: split-K partial sums (the fold kernel applies the epilogue)
     const dim3 grid((unsigned)nwg, ns);
     switch (f) {
 #define AFK_CASE(F)                                                                                                   \

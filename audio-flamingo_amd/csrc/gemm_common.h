@@ -128,11 +128,11 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, i
 // nb + 8q + 4hi + {0..3}.  Wide form (p.wide: every pointer / leading dimension of the epilogue keeps 16-byte alignment): the two lane
 // halves trade registers through v_permlane32_swap so that each lane owns 8 CONSECUTIVE columns (nb + 16t + 8hi + 0..7) - 16-byte stores
 // and 16-byte bias / residual loads, half as many memory instructions as the 8-byte form.  Split-K partials keep the 4-wide form.
-// F >= 0 (specialised instantiation): the launcher guarantees p.wide and p.splits <= 1.
+// F >= 0 (specialised instantiation): the launcher guarantees p.wide and p.splits <= 1.  F = -2: split-K partial sums only.
 template <int F = -1>
 __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc) {
     if (m >= p.M) return;
-    if (F < 0 && p.splits > 1) {
+    if (F == -2 || (F == -1 && p.splits > 1)) {  // F = -2: split-K launch, fp32 partial sums only
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = nb + 8 * q + 4 * hi;
@@ -142,6 +142,7 @@ __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int
         }
         return;
     }
+    if constexpr (F == -2) return;
     if (F >= 0 || p.wide) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
