@@ -237,6 +237,13 @@ class FusedAdamW:
         # of the whole training step replays correctly after advance() has refreshed them
         self.hyper = torch.zeros(4, device=arena.device, dtype=torch.float32) if arena.device.type == "cuda" else None
         self._in_capture = False  # graphs.GraphedTrainStep: the capture pass records launches only
+        # global-norm gradient clipping (torch.nn.utils.clip_grad_norm_; HF Trainer default max_grad_norm = 1.0): the norm is one streaming
+        # pass over the flat gradient arena, the coefficient rides in hyper[3] and is applied inside the AdamW launches
+        self.clip_norm: Optional[float] = None
+        if self.hyper is not None:
+            self._sumsq = torch.zeros(len(arena.bucket_names), device=arena.device, dtype=torch.float32)  # one slot per gradient bucket
+            self.grad_norm = torch.zeros(1, device=arena.device, dtype=torch.float32)  # norm of the last clipped step (device scalar)
+            self._sumsq_ws = torch.empty(ops.sumsq_workspace_floats(), device=arena.device, dtype=torch.float32)
         # contiguous segments sharing a decay setting
         self.segments = []
         for b in arena.order:
@@ -271,7 +278,23 @@ class FusedAdamW:
             return
         self.t += 1
         if self.hyper is not None:
-            ops.set_f32(self.hyper, [self.lr, 1.0 - self.betas[0] ** self.t, (1.0 - self.betas[1] ** self.t) ** 0.5])
+            ops.set_f32(self.hyper, [self.lr, 1.0 - self.betas[0] ** self.t, (1.0 - self.betas[1] ** self.t) ** 0.5, 1.0])
+            if self.clip_norm:
+                self._sumsq.zero_()
+
+    # ------------------------------------------------------------------ global-norm clipping
+    def add_sumsq(self, i: int, gate=None, written_only: bool = True):
+        """sum(g^2) of bucket i's gradients (written_only: of the blocks written since zero_grad()) into the bucket's slot of the step's
+        norm.  One slot per bucket, folded in index order by set_clip_coef(): the plain step and the overlapped schedule (which fills
+        the slots in backward order, on a side stream) arrive at the same bits.  gate: device int32[1], dropped on the device when 0"""
+        a = self.arena
+        blocks = [b for b in a.bucket_blocks(i) if not (written_only and b.fresh)]
+        for s, e, _ in self._runs(blocks):
+            ops.sumsq_(a.grads[s:e], self._sumsq[i:i + 1], gate=gate, ws=self._sumsq_ws)
+
+    def set_clip_coef(self, grad_scale: float = 1.0):
+        """hyper[3] = min(1, clip_norm / (grad_scale * sqrt(sum g^2) + 1e-6)): the AdamW launches that follow scale every gradient by it"""
+        ops.clip_coef_(self._sumsq, self.hyper[3:4], max_norm=self.clip_norm, scale=grad_scale, norm_out=self.grad_norm)
 
     # ------------------------------------------------------------------ master <-> working copy
     def sync_master(self):
@@ -330,6 +353,10 @@ class FusedAdamW:
         self.advance()
         a = self.arena
         a.join_streams()
+        if self.clip_norm:
+            for i in range(len(a.bucket_names)):
+                self.add_sumsq(i, gate=gates[i:i + 1] if gates is not None else None, written_only=gates is None)
+            self.set_clip_coef(grad_scale)
         if gates is not None:
             for i in range(len(a.bucket_names)):
                 for s, e, wd in self.bucket_segments[i]:

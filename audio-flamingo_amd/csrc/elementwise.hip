@@ -501,6 +501,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         lr = hyper[0];
         bc1 = hyper[1];
         bc2_sqrt = hyper[2];
+        grad_scale *= hyper[3];  // global-norm clip coefficient of this step (afk_clip_coef), 1 when clipping is off
     }
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
@@ -874,6 +875,67 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
                        (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gate, hyper);
     AFK_LAUNCH_CHECK("afk_adamw_step");
+    return AFK_OK;
+}
+
+namespace {
+// ---- global gradient norm (torch.nn.utils.clip_grad_norm_, TORCH/nn/utils/clip_grad.py: total_norm = ||g||_2 over every gradient,
+// clip_coef = clamp(max_norm / (total_norm + 1e-6), max = 1)).  The gradient arena is flat, so the norm is ONE streaming pass (2 B/param)
+// instead of a foreach over ~700 tensors, and the coefficient is applied inside the AdamW launch (hyper[3]) instead of a read-modify-write
+// pass over the gradients.  Two stages with a fixed grid and a fixed fold order: bit-deterministic.
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const bf16* __restrict__ x, int64_t n, float* __restrict__ ws) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    const int64_t nv = n >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(x + 8 * i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)v[e] * (float)v[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+        const float t = (float)x[(nv << 3) + threadIdx.x];
+        acc += t * t;
+    }
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void sumsq_fold_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ acc, const int* __restrict__ gate) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += ws[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0 && (gate == nullptr || *gate != 0)) acc[0] += s;
+}
+__global__ void clip_coef_kernel(const float* sumsq, int n, float scale, float max_norm, float* coef, float* norm_out) {
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < n; ++i) tot += sumsq[i];  // per-bucket slots, always folded in index order: the schedule that filled them is irrelevant
+        const float norm = sqrtf(tot) * scale;
+        const float c = max_norm / (norm + 1e-6f);
+        coef[0] = c < 1.f ? c : 1.f;
+        if (norm_out) norm_out[0] = norm;
+    }
+}
+}  // namespace
+
+// acc[0] += sum x[i]^2 (fp32), skipped when *gate == 0.  workspace: afk_sumsq_workspace_floats() floats, private to this call until it ran.
+extern "C" int afk_sumsq_workspace_floats(void) { return SUMSQ_BLOCKS; }
+extern "C" int afk_sumsq_bf16(const void* x, int64_t n, float* acc, const int* gate, float* workspace, void* stream) {
+    AFK_REQUIRE(x && acc && workspace && n > 0, "afk_sumsq_bf16: bad args");
+    AFK_REQUIRE(((uintptr_t)x & 15) == 0, "afk_sumsq_bf16: x must be 16-byte aligned");
+    int grid = (int)afk_cdiv(afk_cdiv(n, 8), 256);
+    if (grid > SUMSQ_BLOCKS) grid = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, ST, (const bf16*)x, n, workspace);
+    hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(256), 0, ST, workspace, grid, acc, gate);
+    AFK_LAUNCH_CHECK("afk_sumsq_bf16");
+    return AFK_OK;
+}
+// coef[0] = min(1, max_norm / (sqrt(sum sumsq[0..n)) * scale + 1e-6)); norm_out[0] (may be NULL) = sqrt(sum sumsq) * scale
+extern "C" int afk_clip_coef(const float* sumsq, int n, float scale, float max_norm, float* coef, float* norm_out, void* stream) {
+    AFK_REQUIRE(sumsq && coef && n >= 1 && max_norm > 0.f && scale > 0.f, "afk_clip_coef: bad args");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, ST, sumsq, n, scale, max_norm, coef, norm_out);
+    AFK_LAUNCH_CHECK("afk_clip_coef");
     return AFK_OK;
 }
 

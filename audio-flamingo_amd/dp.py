@@ -262,7 +262,9 @@ class BackwardOverlap:
     Backward is MFMA-bound and leaves HBM mostly idle; AdamW is pure HBM traffic (28 B/param, 231 GB/step for AF3-7B =
     40 ms at 5.9 TB/s) and the all-reduce is xGMI traffic, so both hide almost completely in the GEMM shadow.  The
     arithmetic of the step is unchanged: every parameter is updated once, with its final (reduced) gradient.  Not usable
-    with global-norm gradient clipping or on non-final gradient-accumulation micro-steps (call the plain path there).
+    on non-final gradient-accumulation micro-steps (call the plain path there).
+    With global-norm clipping (``optimizer.clip_norm``) the coefficient needs every gradient, so only the all-reduces and the partial
+    sums of squares run inside backward; the AdamW launches (which apply the coefficient) and the shadow refreshes follow in finish().
     """
 
     def __init__(self, arena: Arena, optimizer, engine: Optional["DataParallelEngine"] = None):
@@ -275,6 +277,7 @@ class BackwardOverlap:
     def begin_step(self):
         self.opt.begin_step()
         self._done = [False] * len(self.arena.bucket_names)
+        self._clip_pending = []  # (bucket, gate, written_only) whose AdamW waits for the clip coefficient
         if self.engine is not None:
             self.engine.issued = []
         self.arena.begin_backward()
@@ -298,8 +301,26 @@ class BackwardOverlap:
                 if buf.numel():
                     self.engine.issued.append(i)
                     self.engine.allreduce_sum_(buf)  # ordered on the side stream
-            self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
-            self.arena.refresh_bucket_shadows(i)
+            self._step_or_defer(i, gate, written_only)
+
+    def _step_or_defer(self, i, gate, written_only):
+        """on the side stream, behind bucket i's reduction: AdamW + shadow refresh - or, with clipping, its share of the gradient norm"""
+        if getattr(self.opt, "clip_norm", None):
+            self.opt.add_sumsq(i, gate=gate, written_only=written_only)
+            self._clip_pending.append((i, gate, written_only))
+            return
+        self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
+        self.arena.refresh_bucket_shadows(i)
+
+    def _flush_clipped(self):
+        if not self._clip_pending:
+            return
+        with torch.cuda.stream(self.side):
+            self.opt.set_clip_coef(self.grad_scale)
+            for i, gate, written_only in self._clip_pending:
+                self.opt.step_bucket(i, self.grad_scale, 0, gate=gate, written_only=written_only)  # backward is over: full-width launches
+                self.arena.refresh_bucket_shadows(i)
+        self._clip_pending = []
 
     def finish(self):
         """buckets backward never completed (their part of the model did not run this step, e.g. the audio tower on a text-only batch):
@@ -335,8 +356,7 @@ class BackwardOverlap:
                     else:
                         dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
                 for i in deferred:
-                    self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate[i:i + 1])
-                    self.arena.refresh_bucket_shadows(i)
+                    self._step_or_defer(i, gate[i:i + 1], False)
             gate.record_stream(torch.cuda.current_stream())
             eng.bucket_gate = gate
         else:
@@ -345,6 +365,7 @@ class BackwardOverlap:
                     self._ready(i, written_only=True)
                 else:
                     self._done[i] = True
+        self._flush_clipped()
         self.arena.join_streams()
         torch.cuda.current_stream().wait_stream(self.side)
         self.opt.end_step()

@@ -595,10 +595,30 @@ def loss_reduce(row_loss, denom, loss, *, accumulate=False):
 # ---------------------------------------------------------------------------------------------- optimizer
 def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_blocks=0, gate=None, hyper=None):
     """gate: optional device int32[1]; the launch leaves every buffer untouched when it reads 0.
-    hyper: optional device float32[3] = (lr, 1 - beta1^t, sqrt(1 - beta2^t)) overriding lr / step (HIP-graph replay)"""
+    hyper: optional device float32[4] = (lr, 1 - beta1^t, sqrt(1 - beta2^t), gradient multiplier) overriding lr / step (HIP-graph replay);
+    hyper[3] multiplies every gradient (global-norm clip coefficient, 1 = off)"""
     _lib.call("afk_adamw_step", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), param.numel(),
               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
               int(max_blocks), _p(gate), _p(hyper), _stream())
+
+
+def sumsq_workspace_floats() -> int:
+    return int(_lib.load().afk_sumsq_workspace_floats())
+
+
+def sumsq_(x, acc, *, gate=None, ws=None):
+    """acc[0] += sum(x^2) over a bf16 range (fp32, deterministic); skipped on the device when gate (int32[1]) reads 0"""
+    _chk(x, BF16, "sumsq x")
+    if ws is None:
+        ws = torch.empty(_lib.load().afk_sumsq_workspace_floats(), device=x.device, dtype=torch.float32)
+    _lib.call("afk_sumsq_bf16", x.data_ptr(), x.numel(), _chk(acc, torch.float32).data_ptr(), _p(gate), ws.data_ptr(), _stream())
+    return acc
+
+
+def clip_coef_(sumsq, coef, *, max_norm, scale=1.0, norm_out=None):
+    """coef[0] = min(1, max_norm / (sqrt(sum(sumsq)) * scale + 1e-6))   (torch.nn.utils.clip_grad_norm_); norm_out[0] = the norm.
+    sumsq: float32 [n] partial sums, folded in index order"""
+    _lib.call("afk_clip_coef", _chk(sumsq, torch.float32).data_ptr(), sumsq.numel(), float(scale), float(max_norm), coef.data_ptr(), _p(norm_out), _stream())
 
 
 def set_f32(dst, values):

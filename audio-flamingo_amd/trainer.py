@@ -69,6 +69,22 @@ class AfkTrainer(_trainer_base()):
         self.accelerator.prepare_model = lambda model, device_placement=None, evaluation_mode=False: model
         self._afk_engine = None
         self._afk_scale = None
+        # max_grad_norm (HF default 1.0): the reference clips with torch.nn.utils.clip_grad_norm_ - a foreach norm over ~700 gradient tensors
+        # plus a read-modify-write pass.  Here the request is only RECORDED: the fused optimizer step takes the norm in one streaming pass over
+        # the flat gradient arena and applies the coefficient inside its AdamW launches (arena.FusedAdamW.clip_norm).  The returned device
+        # scalar is filled by that step, i.e. before the Trainer reads it for logging.
+        stock_clip = self.accelerator.clip_grad_norm_
+
+        def _clip(parameters, max_norm, norm_type=2):
+            opt = self.optimizer
+            while opt is not None and not isinstance(opt, AfkAdamW) and hasattr(opt, "optimizer"):
+                opt = opt.optimizer  # accelerate's AcceleratedOptimizer wrapper
+            if isinstance(opt, AfkAdamW) and opt.fused.hyper is not None and norm_type == 2:
+                opt.fused.clip_norm = float(max_norm)
+                return opt.fused.grad_norm
+            return stock_clip(parameters, max_norm, norm_type)
+
+        self.accelerator.clip_grad_norm_ = _clip
 
     def create_optimizer(self, model=None):
         if self.optimizer is None:

@@ -362,6 +362,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the unmodified reference model on this GPU (eager PyTorch-ROCm)")
     ap.add_argument("--eager-only", action="store_true", help="measure ONLY the unmodified reference model on this GPU (eager PyTorch-ROCm): for rocprofv3 kernel tables")
+    ap.add_argument("--clip", type=float, default=0.0, help="global-norm gradient clipping (HF Trainer default: 1.0); 0 = off, as the eager reference leg runs")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
     ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) of the default run")
     ap.add_argument("--no-overlap", action="store_true")
@@ -417,6 +418,8 @@ def main():
     if ckpt:
         model.gradient_checkpointing_enable()
     opt = FusedAdamW(model.arena, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    if args.clip > 0:
+        opt.clip_norm = args.clip  # norm in one pass over the gradient arena, coefficient applied inside the AdamW launches
     engine = None
     if use_dp:
         engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
@@ -589,7 +592,7 @@ def main():
                                       f"per-layer activation checkpointing {'ON' if ckpt else 'OFF'} (BASELINE configs[4])")) if full_model
                                     else f"DEPTH-REDUCED AF3 ({args.enc_layers} enc + {args.dec_layers} dec layers) - not the BASELINE config"),
                        "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": s_tok, "audio_tokens": n_audio_tok,
-                       "windows_per_sample": windows, "activation_checkpointing": ckpt,
+                       "windows_per_sample": windows, "activation_checkpointing": ckpt, "max_grad_norm": args.clip if args.clip > 0 else None,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,

@@ -269,12 +269,20 @@ int afk_logmel(const float* wav, int W, int64_t nsamp, const float* cosb, const 
 /* ---- optimizer: AdamW on a flat parameter arena (bf16 param + fp32 master/m/v, 28 B/param) -------------
  * gate (may be NULL): device int; when it reads 0 the launch leaves every buffer untouched (torch.optim skips parameters whose
  * grad is None; under data parallelism "did any rank produce a gradient for this bucket" is only known on the device).
- * hyper (may be NULL): device float[3] = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; when given it overrides lr and the bias corrections
- * derived from `step`, so that a captured HIP graph of the training step replays with the current values (afk_set_f32 writes them). */
+ * hyper (may be NULL): device float[4] = {lr, 1 - beta1^t, sqrt(1 - beta2^t), gradient multiplier}; when given it overrides lr and the bias
+ * corrections derived from `step`, so that a captured HIP graph of the training step replays with the current values (afk_set_f32 writes
+ * them), and hyper[3] multiplies every gradient (the global-norm clip coefficient written by afk_clip_coef; 1 = no clipping). */
 int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, const int* gate,
                    const float* hyper, void* stream);
 int afk_set_f32(float* dst, int n, float a, float b, float c, float d, void* stream);
+/* global-norm gradient clipping (torch.nn.utils.clip_grad_norm_, TORCH/nn/utils/clip_grad.py; HF Trainer default max_grad_norm = 1.0,
+ * TF/trainer.py): acc[0] += sum of squares of a bf16 range (skipped when *gate == 0; gate may be NULL), deterministic two-stage fold;
+ * workspace = afk_sumsq_workspace_floats() floats.  afk_clip_coef: sumsq[0..n) = partial sums (one slot per gradient bucket, folded in index
+ * order whatever schedule filled them), coef[0] = min(1, max_norm / (sqrt(sum) * scale + 1e-6)), norm_out[0] (may be NULL) = sqrt(sum) * scale. */
+int afk_sumsq_workspace_floats(void);
+int afk_sumsq_bf16(const void* x, int64_t n, float* acc, const int* gate, float* workspace, void* stream);
+int afk_clip_coef(const float* sumsq, int n, float scale, float max_norm, float* coef, float* norm_out, void* stream);
 
 /* ---- data-parallel gradient exchange: RCCL over xGMI behind the C ABI.
  * Replaces the C++ Reducer -> ncclAllReduce path of torch DistributedDataParallel (TORCH/nn/parallel/distributed.py:662-666, 828-834):

@@ -328,6 +328,62 @@ def test_optimizer_master_follows_load_state_dict(dev):
     assert torch.equal(m.arena.params, ref.arena.params)
 
 
+def test_global_norm_clipping_matches_torch_and_overlap(dev):
+    """optimizer.clip_norm = torch.nn.utils.clip_grad_norm_ + AdamW: the norm from one streaming pass over the gradient arena, the coefficient
+    applied inside the AdamW launches.  (i) norm and updated parameters against torch on fp32 copies of the same bf16 gradients;
+    (ii) the overlapped schedule (all-reduce / partial norms inside backward, AdamW in finish()) gives bit-identical parameters; (iii) a
+    text-only step only counts the gradients that exist"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import BackwardOverlap
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    ma, mb = _fresh_model(dev, seed=11), _fresh_model(dev, seed=11)
+    lr, wd, clip = 1e-3, 0.01, 0.05   # random-init gradient norm is O(1): the clip is active
+    oa, ob = FusedAdamW(ma.arena, lr=lr, weight_decay=wd), FusedAdamW(mb.arena, lr=lr, weight_decay=wd)
+    oa.clip_norm = ob.clip_norm = clip
+    mb.arena.enable_wgrad_stream(True)
+    ov = BackwardOverlap(mb.arena, ob)
+    # torch reference on fp32 copies of the flat arena (what the fp32 master is), split by decay class
+    A = ma.arena
+    dmask = torch.zeros(A.params.numel(), dtype=torch.bool, device=dev)
+    for blk in A.order:
+        if blk.decay:
+            dmask[blk.offset: blk.offset + blk.numel] = True
+    flat = A.params.detach().float()
+    pd, pn = flat[dmask].clone().requires_grad_(True), flat[~dmask].clone().requires_grad_(True)
+    topt = torch.optim.AdamW([{"params": [pd], "weight_decay": wd}, {"params": [pn], "weight_decay": 0.0}], lr=lr, betas=(0.9, 0.999), eps=1e-8)
+    for step in range(2):
+        ma.zero_grad()
+        ma(**kw).loss.backward()
+        assert all(not blk.fresh for blk in A.order)
+        gf = A.grads.detach().float()
+        pd.grad, pn.grad = gf[dmask].clone(), gf[~dmask].clone()
+        tnorm = torch.nn.utils.clip_grad_norm_([pd, pn], clip)
+        topt.step()
+        oa.step()
+        mb.zero_grad()
+        ov.begin_step()
+        mb(**kw).loss.backward()
+        ov.finish()
+        torch.cuda.synchronize()
+        assert abs(float(oa.grad_norm) - float(tnorm)) <= 1e-4 * float(tnorm), (float(oa.grad_norm), float(tnorm))
+        assert float(tnorm) > 2 * clip, "the clip must be active for this test to mean anything"
+        assert float(oa.grad_norm) == float(ob.grad_norm)
+        assert torch.equal(ma.arena.params, mb.arena.params), "overlapped schedule differs from the plain step under clipping"
+        want = torch.empty_like(flat)
+        want[dmask], want[~dmask] = pd.detach(), pn.detach()
+        assert float((oa.master - want).abs().max()) <= 1e-6, float((oa.master - want).abs().max())
+    # (iii) text-only: the audio tower has no gradient this step and must not enter the norm (its arena range still holds the old values)
+    ma.zero_grad()
+    ma(input_ids=g["ids"].to(dev).clamp(max=1000), labels=g["labels"].to(dev)).loss.backward()
+    sq = sum(float(A.grads[blk.offset: blk.offset + blk.numel].float().pow(2).sum()) for blk in A.order if not blk.fresh)
+    assert any(blk.fresh for blk in A.order)
+    oa.step()
+    torch.cuda.synchronize()
+    assert abs(float(oa.grad_norm) - sq ** 0.5) <= 1e-3 * sq ** 0.5, (float(oa.grad_norm), sq ** 0.5)
+
+
 def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
     """the two-stream backward (wgrad branch on its own stream) and the per-bucket optimizer-in-backward schedule must give
     bit-identical gradients / parameters to the serial schedule: same kernels, same order per tensor"""

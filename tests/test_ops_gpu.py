@@ -794,6 +794,30 @@ def test_adamw(dev):
     assert torch.equal(pb, master.to(BF))
 
 
+def test_sumsq_and_clip_coef(dev):
+    """global-norm clipping pieces: fp32 sum of squares of a bf16 range (odd length, gate, accumulate, deterministic) and the coefficient"""
+    ops = _ops()
+    x = _rand((1 << 22) + 5, dev, 1.0, 1).to(BF)
+    acc = torch.zeros(1, device=dev)
+    ops.sumsq_(x, acc)
+    ref = x.double().pow(2).sum().item()
+    assert abs(acc.item() - ref) <= 1e-5 * ref
+    first = acc.clone()
+    ops.sumsq_(x[:4096], acc)                                   # accumulates
+    assert abs(acc.item() - (ref + x[:4096].double().pow(2).sum().item())) <= 1e-5 * ref
+    ops.sumsq_(x, acc, gate=torch.zeros(1, device=dev, dtype=torch.int32))   # gated off on the device
+    again = torch.zeros(1, device=dev)
+    ops.sumsq_(x, again)
+    assert torch.equal(again, first), "sum of squares not deterministic"
+    coef, norm = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    parts = torch.cat([first * 0.25, first * 0.75])            # per-bucket slots are folded in index order
+    ops.clip_coef_(parts, coef, max_norm=1.0, scale=0.5, norm_out=norm)
+    n = 0.5 * ref ** 0.5
+    assert abs(norm.item() - n) <= 1e-5 * n and abs(coef.item() - 1.0 / (n + 1e-6)) <= 1e-6
+    ops.clip_coef_(first, coef, max_norm=1e9)
+    assert coef.item() == 1.0
+
+
 # ------------------------------------------------------------------------------------------------ log-mel
 def test_logmel(dev):
     """vs the reference feature extractor itself (transformers WhisperFeatureExtractor, feature_extraction_whisper.py:135-168 numpy path and
