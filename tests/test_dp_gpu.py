@@ -54,20 +54,26 @@ def rel(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20))
 
 report = {}
-for mode in ("overlap", "post"):
+CLIP = 1e-3   # far below the gradient norm: the global-norm clip (FusedAdamW.clip_norm) is active in the *_clip modes
+for mode in ("overlap", "post", "overlap_clip", "post_clip"):
     # ---- DP replica: different init per rank on purpose, rank 0's weights (the golden state) are broadcast
     m = model(seed=10 + rank)
     if rank == 0:
         m.load_state_dict(sd)
     opt = FusedAdamW(m.arena, lr=LR, weight_decay=WD)
+    clip = mode.endswith("_clip")
+    if clip:
+        opt.clip_norm = CLIP
     eng = DataParallelEngine(m.arena, overlap=True)
     eng.broadcast_parameters(0)
-    if mode == "overlap":
+    if mode.startswith("overlap"):
         m.arena.enable_wgrad_stream(True)
-    ov = BackwardOverlap(m.arena, opt, eng) if mode == "overlap" else None
+    ov = BackwardOverlap(m.arena, opt, eng) if mode.startswith("overlap") else None
     # ---- single-process reference on the concatenated batch (every rank computes it: cheap, and no extra communication)
     ref = model(seed=0); ref.load_state_dict(sd)
     ropt = FusedAdamW(ref.arena, lr=LR, weight_decay=WD)
+    if clip:
+        ropt.clip_norm = CLIP
     assert torch.equal(m.arena.params, ref.arena.params), "broadcast_parameters failed"
     mine = slice(rank, rank + 1)
     for step in range(3):
@@ -112,6 +118,13 @@ for mode in ("overlap", "post"):
         dp = (m.arena.params.float() - ref.arena.params.float()).abs()
         assert float(dp.max()) <= 2.5 * LR * (step + 1) + 2 ** -7, (mode, step, float(dp.max()))
         assert float(dp.mean()) <= 0.2 * LR, (mode, step, float(dp.mean()))
+        if clip:
+            # norm of the AVERAGED gradient (per-bucket partial sums gated on the all-rank flags) == the single-process norm, same on every rank
+            gn, rn = float(opt.grad_norm), float(ropt.grad_norm)
+            assert rn > 10 * CLIP and abs(gn - rn) <= 6e-2 * rn, (mode, step, gn, rn)
+            norms = [None] * world
+            dist.all_gather_object(norms, gn)
+            assert all(x == norms[0] for x in norms), ("clip norm differs across ranks", norms)
         # replicas stay identical
         chk = torch.stack([m.arena.params.float().sum(), m.arena.params.float().abs().sum()]).cpu()
         allc = [None] * world
