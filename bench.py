@@ -176,7 +176,7 @@ def cpu_baseline(budget_s=25.0):
     }
 
 
-def eager_rocm_baseline(dev, feats, ids, labels, steps=3):
+def eager_rocm_baseline(dev, feats, ids, labels, steps=3, clip=0.0):
     """The same-node "before" number (SURVEY.md §8d last row, BASELINE.md §2 "B-rocm-eager"): the UNMODIFIED reference model
     (transformers.AudioFlamingo3ForConditionalGeneration, attn_implementation sdpa, rocBLAS/hipBLASLt GEMMs, MIOpen convs) at full depth
     in bf16 on this MI355X with torch.optim.AdamW (fused), on the same synthetic batch (micro-batch halved until it fits).  1 warm-up +
@@ -201,6 +201,8 @@ def eager_rocm_baseline(dev, feats, ids, labels, steps=3):
                 opt.zero_grad(set_to_none=True)
                 loss = model(**kw).loss
                 loss.backward()
+                if clip > 0:
+                    torch.nn.utils.clip_grad_norm_(model.parameters(), clip)  # the reference recipe's clip (HF Trainer max_grad_norm)
                 opt.step()
                 torch.cuda.synchronize()
                 if it > 0:
@@ -209,7 +211,7 @@ def eager_rocm_baseline(dev, feats, ids, labels, steps=3):
             res = {"ms_per_step": ms, "micro_batch": B, "value": B * CLIP_SECONDS / (ms * 1e-3), "unit": "audio-s/s",
                    "decoder_tokens_per_s": B * ids.shape[1] / (ms * 1e-3), "loss_last": float(loss.detach()),
                    "model_tflops_per_gpu": train_flops_per_sample(ids.shape[1]) * B / (ms * 1e-3) / 1e12,
-                   "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+                   "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "max_grad_norm": clip if clip > 0 else None}
         except torch.OutOfMemoryError:
             opt.zero_grad(set_to_none=True)
             torch.cuda.empty_cache()
@@ -396,7 +398,7 @@ def main():
 
         waves, ids, labels = synthetic_batch(args.batch, 0, dev, 1)
         feats_b = LogMelFrontend(dev)(waves, out_dtype=torch.bfloat16)
-        print(json.dumps({"eager_rocm_baseline": eager_rocm_baseline(dev, feats_b, ids, labels, steps=args.steps)}), flush=True)
+        print(json.dumps({"eager_rocm_baseline": eager_rocm_baseline(dev, feats_b, ids, labels, steps=args.steps, clip=args.clip)}), flush=True)
         return
     if args.workload == "icl4":
         assert world == 1, "icl4 is a single-GPU measurement"
@@ -626,7 +628,7 @@ def main():
                 torch.cuda.empty_cache()
                 torch.cuda.reset_peak_memory_stats(dev)
                 still = torch.cuda.memory_allocated(dev) / 2 ** 30
-                eb = eager_rocm_baseline(dev, feats_b, ids, labels)
+                eb = eager_rocm_baseline(dev, feats_b, ids, labels, clip=args.clip)
                 eb["hbm_still_allocated_before_gib"] = round(still, 1)
                 res["eager_rocm_baseline"] = eb
                 if eb.get("value"):
