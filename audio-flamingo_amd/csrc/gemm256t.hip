@@ -147,11 +147,34 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
             dst[j] = unit * 1024;
         }
     }
+    // reduction-major pieces: per-lane base already at the piece's k-row, advanced per K-tile by a wave-uniform (scalar) offset - one 64-bit
+    // add per DMA.  The row clamp (k-rows beyond the reduction length) only exists in a ragged LAST tile: that one takes the general form.
+    // (The general form on every piece - per-lane min + 64-bit multiply, ~10 VALU between two MFMAs, eight times per K-tile - cost the TN
+    // kernel ~8 % against the NT kernel: profiles/r02_gemm_probes.md §12.)
+    const bf16* tbase[NX + NY];
+#pragma unroll
+    for (int j = 0; j < NX + NY; ++j) tbase[j] = (AT || j < 4) ? tr_src[j].base + (int64_t)tr_src[j].krow * tr_ld[j] : nullptr;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const bool ragged = (KL % BK) != 0;
+  // the whole pipeline twice: RAG = false (K a multiple of 64: every training shape) never clamps, RAG = true is the general form
+  auto pipeline = [&](auto rag_) {
+    constexpr bool RAG = decltype(rag_)::value;
     auto src_of = [&](int j, int t) -> const bf16* {
         const bool tr = AT || j < 4;  // compile-time after unrolling
         if (tr) {
-            const int row = min(t * BK + tr_src[j].krow, KL - 1);
-            return tr_src[j].base + (int64_t)row * tr_ld[j];
+            if constexpr (RAG) {
+                const int row = min(t * BK + tr_src[j].krow, KL - 1);
+                return tr_src[j].base + (int64_t)row * tr_ld[j];
+            } else {
+                return tbase[j] + (int64_t)t * BK * tr_ld[j];
+            }
         }
         return an_src[j] + (int64_t)t * BK;
     };
@@ -173,14 +196,6 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) koffb[s] = ((2 * s + hi) ^ swz_l) << 4;
     const int a_row0 = (wm * 128 + l31) * 128;
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ------------------------------------------------------------------ prologue: X0 Y0 X1
 #pragma unroll
@@ -307,6 +322,9 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
     }
     AFK_VMCNT(0);
     if (wm == 0) AFK_BARRIER();
+  };
+    if (ragged) pipeline(std::true_type{});
+    else pipeline(std::false_type{});
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
