@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void gemm_xt_bf16_k256(GemmArgs p) {
                     }
                 });
                 AFK_LGKMCNT0();
-                if (kvalid < BK) {  // block-uniform, last tile only: zero the A contribution of k >= K
+                if (RAG && kvalid < BK) {  // block-uniform, ragged last tile only (the RAG = false pipeline has no such tile): zero the A contribution of k >= K
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
