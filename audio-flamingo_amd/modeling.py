@@ -11,6 +11,8 @@ fused arena blocks (q|k|v and gate|up are stored contiguously so that each is on
 Deviations from the oracle surface (documented, not silent):
   * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``; lm_head and the
     loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
+  * ``forward(use_cache=True)`` / ``forward(past_key_values=cache)``: the reference's cache protocol for inference (prefill returns an
+    ``AfkKVCache``, later calls append one or several tokens); same kernels and cache layout as ``generate``;
   * ``generate``: prefill fills a KV cache, each new token is one HIP-graph replay; greedy by default, ``do_sample=True`` with
     ``temperature`` / ``top_k`` / ``top_p`` / ``seed`` (the reference's logits-warper order); no beam search;
   * ``attention_mask`` rows must be one contiguous run of ones (left padding - the reference processor's default -, right padding, or
@@ -30,6 +32,18 @@ from . import _lib, ops
 from ._lib import AfkError
 from .arena import Arena
 from . import functional as F_
+
+
+class AfkKVCache:
+    """KV cache handed between forward(use_cache=True) calls (the role of transformers' DynamicCache): per-layer post-RoPE keys
+    K [L, B, Smax, Hkv*D], values stored transposed Vt [L, B, Hkv, D, pad64(Smax)] (the layout the decode attention kernels read), the
+    number of filled positions and, for left-padded prompts, the first real position of every sample."""
+
+    def __init__(self, K, Vt, lo, length):
+        self.K, self.Vt, self.lo, self.length = K, Vt, lo, int(length)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.length
 
 
 @dataclass
@@ -409,11 +423,16 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     def forward(self, input_ids=None, input_features=None, input_features_mask=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, logits_to_keep=0, return_logits=None,
                 num_items_in_batch=None, **kwargs):
-        if past_key_values is not None:
-            raise AfkError("forward(past_key_values=...) is not supported: the KV-cache path is generate()")
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         self._require_hip()
+        if past_key_values is not None or use_cache:
+            # inference with the reference's cache protocol (modeling_qwen2.py:213-214, 360-364): prefill returns a cache, later calls
+            # append their tokens to it.  Same kernels and cache layout as generate(); no autograd graph.
+            if labels is not None:
+                raise AfkError("forward(labels=..., use_cache=True): the KV-cache path is inference only")
+            return self._forward_cached(input_ids, inputs_embeds, input_features, input_features_mask, attention_mask, past_key_values,
+                                        logits_to_keep)
         a, lm = self.arena, self._lm
         if inputs_embeds is not None:
             # the reference merges audio only when input_ids are given (modeling_audioflamingo3.py:532-545): precomputed embeddings pass through
@@ -508,6 +527,62 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 row = win * T3 + (r - (csum - n_tok)[win])
                 src = torch.where(src >= 0, row.to(torch.int32), src).contiguous()
         return ops.embed_scatter_fwd(ids_flat, src, a[lm + "embed_tokens.weight"].data, audio)
+
+    cache_headroom = 256  # forward(use_cache=True): positions reserved beyond the prompt; the cache grows by doubling when they run out
+
+    @torch.no_grad()
+    def _forward_cached(self, input_ids, inputs_embeds, input_features, input_features_mask, attention_mask, past, logits_to_keep):
+        dev = self.device_
+        if inputs_embeds is not None:
+            B, n = inputs_embeds.shape[:2]
+            x = inputs_embeds.to(dev, torch.bfloat16).reshape(B * n, self.H).contiguous()
+            ids = None
+        else:
+            ids = input_ids.to(dev)
+            B, n = ids.shape
+        L, nk = self.dec_layers, self.Hkv * self.D
+        if past is None:
+            lo = torch.zeros(B, device=dev, dtype=torch.int32)
+            padded = False
+            if attention_mask is not None:
+                am = attention_mask.to(dev)
+                if not bool(am.all()):
+                    lens = am.sum(-1)
+                    if not bool((am.flip(-1).cumsum(-1) == torch.minimum(torch.arange(1, n + 1, device=dev)[None], lens[:, None])).all()):
+                        raise AfkError("forward(use_cache=True): only LEFT-padded attention_mask is supported (pad the prompt on the left)")
+                    lo, padded = (n - lens).to(torch.int32), True
+            Smax = n + self.cache_headroom
+            Kc = torch.zeros((L, B, Smax, nk), device=dev, dtype=torch.bfloat16)
+            Vt = torch.zeros((L, B, self.Hkv, self.D, ops.pad64(Smax)), device=dev, dtype=torch.bfloat16)
+            if ids is not None:
+                x = self._merged_embeddings(ids, input_features, input_features_mask)
+            start = 0
+            fast = self.D in (64, 128) and ops.ATTN_IMPL == "lds" and (self.left_pad_on_lds_kernels or not padded)
+            kv_lo = lo if padded else None
+        else:
+            if not isinstance(past, AfkKVCache):
+                raise AfkError("forward(past_key_values=...): pass the AfkKVCache a previous forward(use_cache=True) returned")
+            if input_features is not None:
+                raise AfkError("forward(past_key_values=...): audio belongs to the prefill call (the reference merges it there too)")
+            Kc, Vt, lo, start = past.K, past.Vt, past.lo, past.length
+            if start + n > Kc.shape[2]:   # out of reserved positions: double the cache
+                Smax = max(2 * Kc.shape[2], start + n + self.cache_headroom)
+                K2 = torch.zeros((L, B, Smax, nk), device=dev, dtype=torch.bfloat16)
+                V2 = torch.zeros((L, B, self.Hkv, self.D, ops.pad64(Smax)), device=dev, dtype=torch.bfloat16)
+                K2[:, :, :start].copy_(Kc[:, :, :start])
+                V2[..., :start].copy_(Vt[..., :start])
+                Kc, Vt = K2, V2
+            if ids is not None:
+                x = ops.embed_scatter_fwd(ids.reshape(-1).contiguous(), None, self.arena[self._lm + "embed_tokens.weight"].data, None)
+            fast, kv_lo = False, None
+        ar = torch.arange(start, start + n, device=dev, dtype=torch.int32)
+        pos_rows = (ar[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()                       # position_ids = cumsum(mask) - 1
+        krange = torch.stack([lo[:, None].expand(B, n), torch.maximum(ar[None, :] + 1, lo[:, None])], -1).contiguous()   # [lo, i + 1)
+        y = self._decode_layers(x, B, n, start, (Kc, Vt), pos_rows, krange, fast, kv_lo=kv_lo)
+        keep = n if not logits_to_keep else min(int(logits_to_keep), n)
+        rows = y.reshape(B, n, -1)[:, n - keep:, :].reshape(B * keep, -1).contiguous()
+        logits = ops.gemm_nt(rows, self.arena["lm_head.weight"].data).reshape(B, keep, -1)
+        return AF3Output(logits=logits, past_key_values=AfkKVCache(Kc, Vt, lo, start + n))
 
     def _decode_layers(self, x, B, n, start, cache, pos_rows, krange, fast_prefill, start_dev=None, kv_lo=None):
         """all decoder layers on n new positions per sample (rows [B*n, H]) at cache offset `start` (or *start_dev: graph replay).

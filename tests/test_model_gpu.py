@@ -212,6 +212,47 @@ def test_generate_greedy_ids_bit_exact(dev, use_graph):
     assert ids.cpu().tolist() == g["generate"].tolist()
 
 
+def test_forward_with_past_key_values_reproduces_generate(dev):
+    """the reference's cache protocol through forward(): use_cache=True prefill returns a cache, forward(past_key_values=cache) appends -
+    one token at a time (greedy ids == the golden generate ids), several tokens at once (chunked), across a cache reallocation, and for
+    the processor's LEFT-padded batch; prefill logits == the no-cache forward's logits"""
+    from audio_flamingo_amd.modeling import AfkKVCache
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    m.cache_headroom = 8     # 24 new tokens: the cache is reallocated twice on the way
+    p = _gen_prompt(g).to(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev))
+    out = m(input_ids=p, use_cache=True, **kw)
+    assert isinstance(out.past_key_values, AfkKVCache) and out.past_key_values.get_seq_length() == p.shape[1]
+    plain = m(input_ids=p, **kw).logits
+    assert out.logits.shape == plain.shape and float((out.logits.float() - plain.float()).abs().max()) <= 3e-2 * float(plain.float().abs().max())
+    ids, cache, nxt = [p], out.past_key_values, out.logits[:, -1].float().argmax(-1)
+    for _ in range(N_GEN):
+        ids.append(nxt[:, None])
+        o = m(input_ids=nxt[:, None], past_key_values=cache, logits_to_keep=1)
+        cache, nxt = o.past_key_values, o.logits[:, -1].float().argmax(-1)
+    assert torch.cat(ids, 1).cpu().tolist() == g["generate"].tolist()
+    # chunked: prompt split in two calls == one call (last-position logits)
+    cut = p.shape[1] - 5
+    o1 = m(input_ids=p[:, :cut], use_cache=True, **kw)
+    o2 = m(input_ids=p[:, cut:], past_key_values=o1.past_key_values)
+    assert o2.logits.shape[1] == 5
+    assert torch.equal(o2.logits[:, -1].float().argmax(-1), out.logits[:, -1].float().argmax(-1))
+    assert float((o2.logits[:, -1].float() - out.logits[:, -1].float()).abs().max()) <= 3e-2 * float(plain.float().abs().max())
+    # left-padded processor batch (case C): stepwise greedy == the reference's generate
+    gc = torch.load(os.path.join(G, "tiny64_caseC.pt"))
+    S0 = gc["ids"].shape[1]
+    o = m(input_ids=gc["ids"].to(dev), input_features=gc["feats"].to(dev), input_features_mask=gc["fmask"].to(dev), attention_mask=gc["att"].to(dev),
+          use_cache=True, logits_to_keep=1)
+    cache, nxt, new = o.past_key_values, o.logits[:, -1].float().argmax(-1), []
+    for _ in range(N_GEN):
+        new.append(nxt[:, None])
+        o = m(input_ids=nxt[:, None], past_key_values=cache, logits_to_keep=1)
+        cache, nxt = o.past_key_values, o.logits[:, -1].float().argmax(-1)
+    assert torch.cat(new, 1).cpu().tolist() == gc["generate"][:, S0: S0 + N_GEN].tolist()
+
+
 def test_generate_sampling(dev):
     """do_sample: top_k = 1 is greedy; a seed reproduces the draw; tokens come from the top-k set of the reference distribution"""
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
