@@ -298,6 +298,9 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     AFK_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "afk_gemm_nt_bf16: leading dims must keep 16-B (A,B) / 8-B (C) alignment");
     AFK_REQUIRE(!(flags & AFK_GEMM_BIAS) || bias, "afk_gemm_nt_bf16: BIAS flag without bias");
     AFK_REQUIRE(!(flags & AFK_GEMM_RESIDUAL) || (residual && ldr % 4 == 0), "afk_gemm_nt_bf16: RESIDUAL flag without residual");
+    AFK_REQUIRE(!(flags & AFK_GEMM_SWIGLU_FWD) || (flags == AFK_GEMM_SWIGLU_FWD && !trans_a && !trans_b && preact_out && N % 256 == 0 && splits == 1 &&
+                                                     ldc % 8 == 0 && (uintptr_t)C % 16 == 0 && (uintptr_t)preact_out % 16 == 0),
+                "afk_gemm_nt_bf16: SWIGLU_FWD needs the NT form, preact_out, N = 2I with I %% 128 == 0 and no other flag");
     AFK_REQUIRE(!(flags & AFK_GEMM_SWIGLU_BWD) || (residual && ldr % 4 == 0 && ldc >= 2 * (int64_t)N && flags == AFK_GEMM_SWIGLU_BWD && splits == 1),
                 "afk_gemm: SWIGLU_BWD needs the gate|up tensor as `residual`, a [M, 2N] output and no other epilogue flag");
     AFK_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0), "afk_gemm_nt_bf16: misaligned pointer");
@@ -331,7 +334,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     }
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
-    const bool use256 = !gemv && (trans_b || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
+    const bool use256 = !gemv && (trans_b || (flags & AFK_GEMM_SWIGLU_FWD) || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
     static const int env_impl = [] {
         const char* e = getenv("AFK_GEMM256");
         return (e && e[0] == 'p' && e[1] == 'e') ? 13 : (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : (e && e[0] == 'f') ? 10 : 0;  // pp | persist | w4 | f8

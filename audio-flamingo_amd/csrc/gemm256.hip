@@ -76,7 +76,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
             const int rl = unit * 8 + lrow;
             const int chunk = pos ^ ((rl >> 1) & 7);
             if (isB) {
-                const int r = min(n0 + rl, p.N - 1);
+                // SWIGLU_FWD: N-tile tn = 128 gate rows [128 tn, +128) followed by the 128 up rows [I + 128 tn, +128) of the fused weight,
+                // so that one workgroup holds gate AND up of the same 128 intermediate features
+                const int r = (EPI == AFK_GEMM_SWIGLU_FWD) ? (rl < 128 ? tn * 128 + rl : (p.N >> 1) + tn * 128 + rl - 128) : min(n0 + rl, p.N - 1);
                 xsrc[j] = p.B + (int64_t)r * p.ldb + chunk * 8;
             } else {
                 const int r = min(m0 + rl, p.M - 1);
@@ -214,6 +216,60 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 #undef AFK_MFMA4
     if (wm == 0) AFK_BARRIER();  // equalise barrier counts
 
+    if constexpr (EPI == AFK_GEMM_SWIGLU_FWD) {
+        // waves wn = 0, 1 hold gate columns, wn = 2, 3 the up columns of the SAME 64 features and rows: the up waves park their
+        // bf16 pieces in the (now idle) operand buffers, the gate waves pick them up and write h = bf16(bf16(silu(g)) * u) beside g
+        // (same arithmetic as silu_mul_fwd_kernel on the bf16-rounded GEMM results: bit-identical to the two-kernel form).
+        typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+        const int I = p.N >> 1;
+        const bool up = wn >= 2;
+        const int feat0 = tn * 128 + (wn & 1) * 64;                 // first of this wave's 64 intermediate features
+        char* xch = smem + (wm * 2 + (wn & 1)) * 16384 + lane * 16;  // piece q of the pair at + q * 1024
+        b8 pc[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    b8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t + e]), __float_as_uint(acc[i][j][8 * t + 4 + e]), false, false);
+                        o[e] = (bf16)(__uint_as_float(r[0]) * p.alpha);
+                        o[4 + e] = (bf16)(__uint_as_float(r[1]) * p.alpha);
+                    }
+                    pc[(i * 2 + j) * 2 + t] = o;
+                }
+        if (up) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(b8*)(xch + q * 1024) = pc[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q = (i * 2 + j) * 2 + t;
+                    const int f = feat0 + j * 32 + 16 * t + 8 * hi;   // feature (= column of h) of this piece
+                    if (!up) {
+                        const b8 u = *(const b8*)(xch + q * 1024);
+                        b8 h;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float gf = (float)pc[q][e];
+                            h[e] = (bf16)(rbf(gf * sigmoid_f(gf)) * (float)u[e]);
+                        }
+                        if (m < p.M) *(b8*)((bf16*)p.C2 + (int64_t)m * I + f) = h;
+                    }
+                    if (m < p.M) *(b8*)((bf16*)p.C + (int64_t)m * p.ldc + (up ? I : 0) + f) = pc[q];
+                }
+        }
+        return;
+    }
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
     if (p.gm & 0x40) return;  // timing probe (afk_gemm_set_variant(2 + 256 * 0x40), wrong results): the kernel without its epilogue
 #pragma unroll
@@ -226,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
 // the epilogues of the AF3 training step get their own instantiation; anything else (SwiGLU backward, fp32 output, narrow stores) the generic one
 #define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_BIAS) X(AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_GELU) \
-    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(-1)
+    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(AFK_GEMM_SWIGLU_FWD) X(-1)
 
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;

@@ -55,6 +55,10 @@ def _tiles256(m, n):
 # layer, but MEASURED SLOWER on the full step (446-450 vs 435 ms): the epilogue's per-lane row-strided 8-byte gate|up loads cost more
 # than the separate 5.3 TB/s elementwise pass.  Kept as an ABI feature (tests/test_ops_gpu.py), off in the model.
 FUSE_SWIGLU_BWD = os.environ.get("AFK_FUSE_SWIGLU", "0") == "1"
+# SwiGLU forward inside the gate|up GEMM (AFK_GEMM_SWIGLU_FWD): a workgroup computes 128 gate and the matching 128 up features, the up
+# waves hand their bf16 tile to the gate waves through the idle operand buffers, and silu(g) * u is stored beside g|u - bit-identical to
+# the separate silu_mul_fwd pass, whose 0.93 GB of HBM traffic per layer disappears.
+FUSE_SWIGLU_FWD = os.environ.get("AFK_FUSE_SWIGLU_FWD", "1") == "1"
 
 
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
@@ -326,8 +330,13 @@ class DecoderLayerFn(torch.autograd.Function):
             o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
         x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
         h2, rstd2 = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
-        gu = ops.gemm_nt(h2, A("mlp.gate_up.weight").data)
-        a = ops.silu_mul_fwd(gu)
+        wgu = A("mlp.gate_up.weight").data
+        if FUSE_SWIGLU_FWD and wgu.shape[0] % 256 == 0:
+            a = torch.empty((h2.shape[0], wgu.shape[0] // 2), device=h2.device, dtype=torch.bfloat16)
+            gu = ops.gemm_nt(h2, wgu, swiglu_fwd_out=a)   # gate|up and silu(gate) * up from one launch
+        else:
+            gu = ops.gemm_nt(h2, wgu)
+            a = ops.silu_mul_fwd(gu)
         x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
         # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
         ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo)

@@ -15,7 +15,7 @@ from ._lib import AfkError
 
 BF16 = torch.bfloat16
 
-GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ACCUM, GEMM_SWIGLU_BWD = 1, 2, 4, 8, 16, 32
+GEMM_BIAS, GEMM_GELU, GEMM_RESIDUAL, GEMM_OUT_F32, GEMM_ACCUM, GEMM_SWIGLU_BWD, GEMM_SWIGLU_FWD = 1, 2, 4, 8, 16, 32, 64
 
 
 def _stream() -> int:
@@ -40,14 +40,25 @@ def pad64(n: int) -> int:
 
 # ---------------------------------------------------------------------------------------------- GEMM
 def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None, out_f32=False,
-            accumulate=False, alpha=1.0, M=None, N=None, K=None, swiglu_bwd=None):
-    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b: 2-D bf16 with unit inner stride (row stride free)."""
+            accumulate=False, alpha=1.0, M=None, N=None, K=None, swiglu_bwd=None, swiglu_fwd_out=None):
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b: 2-D bf16 with unit inner stride (row stride free).
+    swiglu_fwd_out: b is the fused gate|up weight [2I, K]; out [M, 2I] = gate|up as usual and swiglu_fwd_out [M, I] (contiguous) receives
+    bf16(bf16(silu(gate)) * up) from the same launch (AFK_GEMM_SWIGLU_FWD; I % 128 == 0)"""
     _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b")
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     M = a.shape[0] if M is None else M
     N = b.shape[0] if N is None else N
     K = a.shape[1] if K is None else K
     assert K <= a.shape[1] and K <= b.shape[1]
+    if swiglu_fwd_out is not None:
+        assert bias is None and residual is None and not gelu and not accumulate and not out_f32 and preact_out is None and swiglu_bwd is None
+        _chk(swiglu_fwd_out, BF16, "gemm swiglu_fwd_out")
+        assert N % 256 == 0 and swiglu_fwd_out.is_contiguous() and tuple(swiglu_fwd_out.shape) == (M, N // 2)
+        if out is None:
+            out = torch.empty((M, N), device=a.device, dtype=BF16)
+        _lib.call("afk_gemm_nt_bf16", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K, 0, 0, 0, 0,
+                  swiglu_fwd_out.data_ptr(), float(alpha), GEMM_SWIGLU_FWD, _stream())
+        return out
     if swiglu_bwd is not None:
         # fused SwiGLU backward epilogue: out [M, 2N] = (dgate | dup), swiglu_bwd = saved gate|up [M, 2N]
         assert bias is None and residual is None and not gelu and not accumulate and not out_f32 and swiglu_bwd.shape[1] == 2 * N

@@ -71,6 +71,7 @@ int afk_gemm_set_variant(int variant);
 #define AFK_GEMM_OUT_F32 8
 #define AFK_GEMM_ACCUM 16
 #define AFK_GEMM_SWIGLU_BWD 32 /* C is [M, 2N]: (dgate | dup) = SwiGLU backward of the product, `residual` = saved gate|up [M, 2N] (Qwen2MLP, modeling_qwen2.py:46-48) */
+#define AFK_GEMM_SWIGLU_FWD 64 /* NT only, B = the fused gate|up weight [2I, K] (N = 2I, I % 128 == 0): C [M, 2I] = gate|up pre-activations as without the flag, and preact_out [M, I] = bf16(bf16(silu(gate)) * up) - Qwen2MLP's activation (modeling_qwen2.py:46-48) from the same launch; no other flag */
 int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                      int res_mod, void* preact_out, float alpha, int flags, void* stream);

@@ -464,6 +464,22 @@ def test_gemm_swiglu_bwd_epilogue(dev):
     assert got.shape == ref.shape and torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("M,I,K", [(700, 512, 256), (8192, 1024, 192), (1000, 128, 64), (2048, 18944, 128)])
+def test_gemm_swiglu_fwd_epilogue(dev, M, I, K):
+    """gate|up GEMM with the SwiGLU forward in its epilogue (paired gate / up tiles per workgroup) == GEMM followed by silu_mul_fwd, bit for
+    bit, on both outputs; ragged M, one and many N tiles, the AF3 intermediate size"""
+    ops = _ops()
+    x = _rand((M, K), dev, 1.0, 1).to(BF)
+    w = _rand((2 * I, K), dev, 0.5, 2).to(BF)
+    gu_ref = ops.gemm_nt(x, w)
+    h_ref = ops.silu_mul_fwd(gu_ref)
+    h = torch.full((M, I), float("nan"), device=dev, dtype=BF)
+    gu = ops.gemm_nt(x, w, swiglu_fwd_out=h)
+    assert torch.equal(gu, gu_ref), "gate|up pre-activations differ"
+    assert torch.equal(h, h_ref), "fused silu(gate) * up differs from the two-kernel form"
+    assert torch.equal(ops.gemm_nt(x, w, swiglu_fwd_out=torch.empty_like(h)), gu)
+
+
 def test_gemm_tn_splitk(dev):
     """narrow weight gradients (encoder: 1280 x 1280 from 12 000 rows) on the TN kernel with split-K: values, determinism, accumulate"""
     ops = _ops()
