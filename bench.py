@@ -612,7 +612,8 @@ def main():
                          "timed_region_overlapped": {"achieved": (ov_flops / (ov_ms * 1e-3) / 1e12) if ov_ms > 0 else None, "launches": ov_launches,
                                                      "note": "same brackets inside the timed region; inflated when two streams share the chip"},
                          "note": ("HIP events around every GEMM launch on its launch stream; measured on one extra untimed step with the wgrad stream "
-                                  "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")},
+                                  "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")
+                                 + "; the gate|up launches carry the fused SwiGLU forward: its elementwise work counts as GEMM time, not as flops"},
         }
         if not args.no_eager_baseline and world == 1 and args.workload == "clip30":
             # the reference's own model on this GPU: free our replica first (the two do not fit side by side)
