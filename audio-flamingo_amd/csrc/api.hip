@@ -36,3 +36,11 @@ extern "C" int afk_version(void) { return 1; }
 #define AFK_SRC_HASH "unknown"
 #endif
 extern "C" const char* afk_build_id(void) { return AFK_SRC_HASH; }
+// 1 when this library was built with -DAFK_PROBES (timing probes with wrong results + rejected GEMM schedules compiled in); the shipped build returns 0
+extern "C" int afk_has_probes(void) {
+#ifdef AFK_PROBES
+    return 1;
+#else
+    return 0;
+#endif
+}

@@ -19,6 +19,14 @@
 #include "common.h"
 #include "../../include/afk.h"
 
+// Timing probes (tools/attn_waits.py, profiles/r02_attn_probes.md) produce WRONG results on purpose (skipped kernels, skipped MFMA bodies).
+// They exist only in -DAFK_PROBES builds (make PROBES=1); the default build compiles every probe branch away.
+#ifdef AFK_PROBES
+#define AFK_DBG(p) ((p).dbg)
+#else
+#define AFK_DBG(p) 0
+#endif
+
 namespace {
 
 struct AttnArgs2 {
@@ -37,7 +45,7 @@ struct AttnArgs2 {
     int B, Hq, Hkv, S, Spad;
     float scale;
     int causal;
-    int dbg;          // AFK_ATTN_DBG experiments (0 in production)
+    int dbg;          // AFK_ATTN_DBG experiments: read only in -DAFK_PROBES builds (AFK_DBG below), ignored otherwise
     int split_heads;  // dK/dV sweep: one block per QUERY head, partial dK/dV per query head (GQA), reduced afterwards
 };
 
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     constexpr int KS = T::KS, DT = T::DT;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 bufs][Q image | dO image]
     uint64_t rt_entry = 0, rt1 = 0;
-    if (p.dbg & 4) asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
+    if (AFK_DBG(p) & 4) asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     // the MFMA chains the register allocator kept the 128 dK/dV accumulators of each copy in different AGPRs and moved all of them
     // back at the end of every tile (128 v_accvgpr_mov + the MFMA-drain s_nops in front of them, ~15 % of the tile).
     uint64_t c_start = 0, ts0 = 0, ts1 = 0, ts2 = 0, tsm = 0, sum_body = 0, sum_ph1 = 0, sum_bar = 0, rt0 = 0;
-    const bool probe = (p.dbg & 4) != 0;
+    const bool probe = (AFK_DBG(p) & 4) != 0;
     uint32_t qrow[KS];  // Q row-fragment addresses in buffer 0 (kt2 = 1: + 32 rows, dO: + T::BYTES)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qrow[ks] = lds0 + offs.row[ks];
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
             if constexpr (G >= NG / 2)
                 afk_static_for<PCH>([&](auto i_) { p_chunk(std::integral_constant<int, (G - NG / 2) * PCH + decltype(i_)::value>{}); });
         });
-        if (p.dbg & 8) {
+        if (AFK_DBG(p) & 8) {
             asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tsm)::"memory");
             sum_ph1 += tsm - ts0;
         }
@@ -754,12 +762,12 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
                 const bool wrap = qt + 1 == qt_end;
                 const bool last = wrap && gi + 1 == g_count;
                 const int nh = (wrap && !last) ? h + 1 : h, nqt = last ? qt : (wrap ? qt_begin : qt + 1);
-                if (!(p.dbg & 1) || t < 1) stage((t + 1) & 1, nh, nqt);
+                if (!(AFK_DBG(p) & 1) || t < 1) stage((t + 1) & 1, nh, nqt);
             }
             const bool interior = qt >= qt_int0 && qt < qt_int1;
             if (probe) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
             // wave-uniform: causal tiles entirely before this wave's keys contribute nothing
-            if (!(p.dbg & 2) && (interior || (wave_live && !(p.causal && qt * 64 + 63 < key0)))) body(t, qt, !interior);
+            if (!(AFK_DBG(p) & 2) && (interior || (wave_live && !(p.causal && qt * 64 + 63 < key0)))) body(t, qt, !interior);
             if (probe) asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory");
             AFK_ATTN_BARRIER();
             if (probe) {
@@ -949,10 +957,12 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     // Given a scratch of 2 * B*S*Hq*D bf16 the sweep runs one block per QUERY head and a reduce folds the group.
     const int group = Hq / Hkv;
     const bool split = gqa_scratch != nullptr && group > 1;
+#ifdef AFK_PROBES
     {
         static const char* dbg = getenv("AFK_ATTN_DBG");
         if (dbg) p.dbg = atoi(dbg);
     }
+#endif
     AttnArgs2 pk = p;
     if (split) {
         pk.split_heads = 1;
@@ -971,15 +981,15 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), LKV, st, pk);
-        if (!(p.dbg & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
+        if (!(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
     } else {
         constexpr int L = 4 * Tile<64>::BYTES, LKV = L + 2048;
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
         (void)once;
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
-        if (!(p.dbg & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+        if (!(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
     }
-    if (split && !(p.dbg & 4)) {
+    if (split && !(AFK_DBG(p) & 4)) {
         AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
                     "afk_attn2_bwd: GQA split path expects dK/dV inside one [B*S, ld] buffer with contiguous heads");
         const int64_t rows = (int64_t)B * S;

@@ -223,7 +223,7 @@ struct ProfState {
 };
 ProfState g_prof;
 int g_variant = 0;  // 0 auto, 1 force 128x128, 2 force 256x256 (8-wave ping-pong), 3 force 256x256 (4-wave, 128x128 per wave)
-int g_256_impl = 2; // which 256x256 NT kernel "auto" uses: 2 = 8-wave ping-pong (gemm256.hip), 3 = 4-wave (gemm256w4.hip), 10 = free-running 8-wave BK=32
+[[maybe_unused]] int g_256_impl = 2; // which 256x256 NT kernel "auto" uses: 2 = 8-wave ping-pong (gemm256.hip), 3 = 4-wave (gemm256w4.hip), 10 = free-running 8-wave BK=32
                     // (gemm256f8.hip); env AFK_GEMM256 = pp | w4 | f8
 int g_gm = 0;       // rasterization group height override (0 = default 8)
 int g_wide = 1;     // 16-byte epilogue form allowed (afk_gemm_set_variant bit 4 clears it: A/B experiments)
@@ -240,12 +240,19 @@ hipEvent_t prof_next_event() {
 }  // namespace
 
 extern "C" int afk_gemm_set_variant(int v) {
-    // v = base + 256*gm : the rasterization group height is a tuning knob of tools/exp_gemm.py
-    g_gm = (v >> 8) & 255;
+    // v = base + 256*gm : base 0 auto, 1 = 128x128 kernel, 2 = 256x256 ping-pong kernel; bit 4 (16) = 8-byte epilogue stores (A/B knob, same results);
+    // gm bits 0..5 = rasterization group height.  Everything else selects a timing probe or a rejected schedule and exists in
+    // -DAFK_PROBES builds only (gm bit 6: no epilogue = WRONG results, bit 7: raw dispatch order; base 3..13: gemm256w4 / f8 / p.hip).
+    const int gm = (v >> 8) & 255, base = v & 15;
+#ifdef AFK_PROBES
+    AFK_REQUIRE(base >= 0 && base <= 13, "afk_gemm_set_variant: 13 = 256x256 ping-pong as a persistent tile loop, 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
+#else
+    AFK_REQUIRE(base >= 0 && base <= 2, "afk_gemm_set_variant: variant %d is a probe / rejected schedule; this libafk.so was built without -DAFK_PROBES (make PROBES=1)", base);
+    AFK_REQUIRE((gm & 0xc0) == 0, "afk_gemm_set_variant: gm bits 6 / 7 are timing probes (wrong results); this libafk.so was built without -DAFK_PROBES");
+#endif
+    g_gm = gm;
     g_wide = (v & 16) ? 0 : 1;
-    v &= 15;
-    AFK_REQUIRE(v >= 0 && v <= 13, "afk_gemm_set_variant: 13 = 256x256 ping-pong as a persistent tile loop, 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
-    g_variant = v;
+    g_variant = base;
     return AFK_OK;
 }
 
@@ -335,14 +342,22 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
     const bool use256 = !gemv && (trans_b || (flags & AFK_GEMM_SWIGLU_FWD) || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
+#ifdef AFK_PROBES
     static const int env_impl = [] {
         const char* e = getenv("AFK_GEMM256");
         return (e && e[0] == 'p' && e[1] == 'e') ? 13 : (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : (e && e[0] == 'f') ? 10 : 0;  // pp | persist | w4 | f8
     }();
-    const int impl256 = g_variant >= 2 ? g_variant : (env_impl ? env_impl : g_256_impl);   // 2 pp | 3..9 w4 family | 10, 11 f8
+    // the fused SwiGLU forward exists in the ping-pong kernel only: it never takes a probe schedule
+    const int impl256 = (flags & AFK_GEMM_SWIGLU_FWD) ? 2 : g_variant >= 2 ? g_variant : (env_impl ? env_impl : g_256_impl);   // 2 pp | 3..9 w4 family | 10, 11 f8
     const bool w4 = use256 && !trans_b && impl256 >= 3 && impl256 <= 9;
     const bool f8 = use256 && !trans_b && impl256 >= 10 && impl256 <= 12;
     const bool persist = use256 && !trans_b && impl256 == 13;
+#endif
+    // SWIGLU_FWD is implemented by gemm_nt_bf16_k256<AFK_GEMM_SWIGLU_FWD> alone, which needs the 16-byte epilogue form: refuse instead of
+    // falling through to an instantiation that would leave preact_out unwritten
+    if ((flags & AFK_GEMM_SWIGLU_FWD) && !p.wide)
+        return afk_set_error(AFK_ERR_UNSUPPORTED, "afk_gemm_nt_bf16: SWIGLU_FWD needs the 16-byte epilogue form (aligned C / preact_out, ldc %% 8 == 0, "
+                                                  "afk_gemm_set_variant bit 4 clear)");
     p.ntm = (int)afk_cdiv(M, use256 ? 256 : BM);
     p.ntn = (int)afk_cdiv(N, use256 ? 256 : BN);
     static bool attr_set = false;
@@ -385,7 +400,11 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(g), dim3(256), 0, st, p);
         }
     } else if (use256) {
+#ifdef AFK_PROBES
         if (int e = persist ? afk_launch_gemm256p(p, st) : f8 ? afk_launch_gemm256f8(p, impl256 - 10, st) : w4 ? afk_launch_gemm256w4(p, impl256 - 3, st) : afk_launch_gemm256(p, st)) return e;
+#else
+        if (int e = afk_launch_gemm256(p, st)) return e;
+#endif
     } else {
         hipLaunchKernelGGL(gemm_nt_bf16_k128, dim3((unsigned)nwg, (unsigned)splits), dim3(256), NSTAGE * STAGE_BYTES, st, p);
         if (splits > 1) {

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         return;
     }
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
-    if (p.gm & 0x40) return;  // timing probe (afk_gemm_set_variant(2 + 256 * 0x40), wrong results): the kernel without its epilogue
+    if (AFK_GM_NOEPI(p)) return;  // -DAFK_PROBES builds only: timing probe (afk_gemm_set_variant(2 + 256 * 0x40), wrong results): the kernel without its epilogue
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

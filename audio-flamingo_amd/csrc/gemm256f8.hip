@@ -1,3 +1,4 @@
+#ifdef AFK_PROBES  // rejected schedule, kept for the probe tables of profiles/r02_gemm_probes.md: not part of the default libafk.so (make PROBES=1)
 // bf16 NT GEMM, 256x256 output tile, K-step 32, EIGHT free-running waves of 128x64, ten-slot LDS ring (round 2).
 //
 // What the round-2 probes showed (tools/bench_gemm.py variants 2..9, profiles/r02_gemm_probes.md), on random operands where the chip is
@@ -228,3 +229,5 @@ int afk_launch_gemm256f8(const GemmArgs& p, int mode, hipStream_t st) {
     else hipLaunchKernelGGL(gemm_nt_bf16_f8<0>, grid, dim3(512), LDS_BYTES, st, p);
     return AFK_OK;
 }
+
+#endif  // AFK_PROBES

@@ -1,3 +1,4 @@
+#ifdef AFK_PROBES  // rejected schedule, kept for the probe tables of profiles/r02_gemm_probes.md: not part of the default libafk.so (make PROBES=1)
 // bf16 NT GEMM, 256x256x64 ping-pong kernel of gemm256.hip as a PERSISTENT tile loop: one workgroup per CU walks the rasterised tile list
 // (tile = blockIdx.x + i * gridDim.x) instead of one workgroup per tile.
 //
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256p(GemmArgs p_in) {
     const GemmArgs& pe = *kp;     // epilogue arguments: loaded here, not held across the K loop
 
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
-    if (!(pe.gm & 0x40))  // bit 6 of gm (afk_gemm_set_variant(13 + 256 * 0x40)): timing probe WITHOUT the epilogue (wrong results) - profiles/r02_gemm_probes.md §9
+    if (!AFK_GM_NOEPI(pe))  // bit 6 of gm (afk_gemm_set_variant(13 + 256 * 0x40)): timing probe WITHOUT the epilogue (wrong results) - profiles/r02_gemm_probes.md §9
     afk_static_for<8>([&](auto ij_) {  // compile-time indices: inside the tile loop a #pragma unroll was not honoured and acc went through scratch
         constexpr int i = decltype(ij_)::value >> 1, j = decltype(ij_)::value & 1;
         gemm_store_block32(pe, m0 + wm * 128 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
@@ -230,3 +231,5 @@ int afk_launch_gemm256p(const GemmArgs& p, hipStream_t st) {
     hipLaunchKernelGGL(gemm_nt_bf16_k256p, dim3((unsigned)(nwg < ncu ? nwg : ncu)), dim3(512), LDS_BYTES, st, p);
     return AFK_OK;
 }
+
+#endif  // AFK_PROBES

@@ -1,3 +1,4 @@
+#ifdef AFK_PROBES  // rejected schedule, kept for the probe tables of profiles/r02_gemm_probes.md: not part of the default libafk.so (make PROBES=1)
 // bf16 NT GEMM, 256x256x64 tile, FOUR waves of 128x128 each - one wave per SIMD, accumulators in AGPRs (round 2).
 //
 // Why a second 256x256 kernel.  gemm256.hip (8 waves, two ping-pong groups of 128x64 per wave) keeps each SIMD's matrix pipe 70 % busy:
@@ -265,3 +266,5 @@ int afk_launch_gemm256w4(const GemmArgs& p, int mode, hipStream_t st) {
     }
     return AFK_OK;
 }
+
+#endif  // AFK_PROBES

@@ -22,6 +22,17 @@ struct GemmArgs {
     int wide;    // 16-byte epilogue accesses are legal (N % 8 == 0 and every epilogue pointer / leading dimension 16-byte aligned)
 };
 
+// Probe bits of GemmArgs::gm (bit 6 = kernel WITHOUT its epilogue: wrong results; bit 7 = raw dispatch order) and the three rejected 256x256
+// schedules (gemm256w4 / gemm256f8 / gemm256p.hip, profiles/r02_gemm_probes.md) exist only in -DAFK_PROBES builds (make PROBES=1).  The
+// default library compiles the branches away and afk_gemm_set_variant() rejects the values that select them.
+#ifdef AFK_PROBES
+#define AFK_GM_NOEPI(p) (((p).gm & 0x40) != 0)
+#define AFK_GM_RAW(p) (((p).gm & 0x80) != 0)
+#else
+#define AFK_GM_NOEPI(p) false
+#define AFK_GM_RAW(p) false
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -29,8 +40,8 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // the tiles resident on one XCD share A and B panels through that XCD's private L2.
 __device__ __forceinline__ void gemm_tile_of(const GemmArgs& p, int bid, int nwg, int& tm, int& tn) {
     const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
-    const int swz = (p.gm & 0x80) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bit 7 of gm: raw dispatch order (experiment)
-    const int GM = (p.gm & 0x3f) > 0 ? (p.gm & 0x3f) : 4;  // bit 6: no-epilogue timing probe (gemm256p.hip)
+    const int swz = AFK_GM_RAW(p) ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bit 7 of gm (probe builds): raw dispatch order
+    const int GM = (p.gm & 0x3f) > 0 ? (p.gm & 0x3f) : 4;
     const int per_group = GM * p.ntn;
     const int g = swz / per_group, rem = swz - g * per_group;
     const int first_m = g * GM;

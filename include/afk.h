@@ -25,6 +25,8 @@ int afk_version(void);
 const char* afk_last_error(void);
 /* sha256 prefix (16 hex digits) of csrc/*.hip + the headers this library was built from */
 const char* afk_build_id(void);
+/* 1 if the library was built with -DAFK_PROBES (make PROBES=1: timing probes that give WRONG results, rejected GEMM schedules); 0 for the shipped build */
+int afk_has_probes(void);
 
 /* ---- launch counters per kernel family: host_out[i] = launches of family i since the last reset (i < n <= AFK_CNT_MAX).
  * Test infrastructure: lets a parity test assert WHICH kernel served a shape (256x256 ping-pong GEMM, TN wgrad, GQA-split dK/dV...). */
@@ -63,7 +65,9 @@ int afk_prof_dump(const char* host_path);
  * residual row index is m, or m % res_mod when res_mod > 0 (broadcast table: embed_positions add, :385).
  * epilogue order: +bias[n] -> (round bf16, write preact_out, GELU-erf) -> (round bf16, +residual[m,n]) -> (+C if ACCUM)
  */
-/* kernel variant override for tests/benchmarks: 0 auto (by tile count), 1 = 128x128x64 kernel, 2 = 256x256x64 ping-pong kernel */
+/* kernel variant override for tests/benchmarks: 0 auto (by tile count), 1 = 128x128x64 kernel, 2 = 256x256x64 ping-pong kernel; + 16 = 8-byte epilogue
+ * stores (same results); + 256 * g (g = 1..63) = rasterization group height.  Any other value selects a timing probe or a rejected schedule: those
+ * exist only in -DAFK_PROBES builds (make PROBES=1) and are refused (AFK_ERR_ARG) by the default library. */
 int afk_gemm_set_variant(int variant);
 #define AFK_GEMM_BIAS 1
 #define AFK_GEMM_GELU 2

@@ -47,12 +47,34 @@ def test_gemm_plain(dev, M, N, K):
     _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
+def _need_probes(variant):
+    """variants 3..13 are the rejected 256x256 schedules: they exist only in a `make PROBES=1` build of libafk.so"""
+    from audio_flamingo_amd import _lib
+    if variant > 2 and not _lib.has_probes():
+        pytest.skip("rejected GEMM schedule: needs a -DAFK_PROBES build (make -C audio-flamingo_amd/csrc PROBES=1)")
+
+
+def test_default_build_has_no_probe_paths(dev):
+    """the shipped libafk.so refuses every probe selector of afk_gemm_set_variant (wrong-result timing probes, rejected schedules) and
+    ignores AFK_ATTN_DBG: a stray value cannot corrupt results"""
+    from audio_flamingo_amd import _lib
+    if _lib.has_probes():
+        pytest.skip("probe build")
+    ops = _ops()
+    for bad in (3, 6, 10, 13, 2 + 256 * 0x40, 2 + 256 * 0x80):
+        with pytest.raises(_lib.AfkError, match="AFK_PROBES"):
+            ops.gemm_set_variant(bad)
+    ops.gemm_set_variant(2 + 256 * 8)   # rasterization group height stays a legal knob
+    ops.gemm_set_variant(0)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 6, 10, 13])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 260, 320), (1000, 1280, 1280), (8, 512, 4096),
                                    (777, 1028, 64), (2048, 256, 2048)])
 def test_gemm_variants(dev, variant, M, N, K):
-    """all NT kernels (1: 128x128; 2: 256x256 8-wave ping-pong; 3: 256x256 4-wave x 128x128; 6: 256x256 8-wave free-running) on every edge shape: K-tiles 1/2/3/many (prologue + tail
-    waits), M/N tails, tiny M"""
+    """all NT kernels (1: 128x128; 2: 256x256 8-wave ping-pong; probe builds only - 3: 256x256 4-wave x 128x128; 6 / 10: 256x256 8-wave free-running;
+    13: persistent tile loop) on every edge shape: K-tiles 1/2/3/many (prologue + tail waits), M/N tails, tiny M"""
+    _need_probes(variant)
     ops = _ops()
     ops.gemm_set_variant(variant)
     try:
@@ -73,6 +95,7 @@ def test_gemm_variants(dev, variant, M, N, K):
 def test_gemm_persistent_tile_loop_matches_one_tile_per_workgroup(dev, M, N, K):
     """variant 13 (gemm256p.hip: one workgroup per CU walks 2-5 tiles, next prologue issued behind the previous tile's stores) must give
     the ping-pong kernel's result bit for bit - same per-tile arithmetic - with every epilogue the step uses, and stay so when repeated"""
+    _need_probes(13)
     ops = _ops()
     a = _rand((M, K), dev, seed=31).to(BF)
     b = _rand((N, K), dev, seed=32).to(BF)
@@ -478,6 +501,27 @@ def test_gemm_swiglu_fwd_epilogue(dev, M, I, K):
     assert torch.equal(gu, gu_ref), "gate|up pre-activations differ"
     assert torch.equal(h, h_ref), "fused silu(gate) * up differs from the two-kernel form"
     assert torch.equal(ops.gemm_nt(x, w, swiglu_fwd_out=torch.empty_like(h)), gu)
+
+
+def test_gemm_swiglu_fwd_refuses_unsupported_forms(dev):
+    """the fused SwiGLU forward exists in ONE kernel instantiation; any dispatch state that cannot reach it (narrow-epilogue A/B
+    knob, forced 128x128 variant) must raise - never return with swiglu_fwd_out unwritten - and variant 2 / auto must still serve it"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    x = _rand((512, 128), dev, 1.0, 1).to(BF)
+    w = _rand((512, 128), dev, 0.5, 2).to(BF)
+    ref_h = ops.silu_mul_fwd(ops.gemm_nt(x, w))
+    try:
+        ops.gemm_set_variant(16)                      # 8-byte epilogue knob
+        with pytest.raises(_lib.AfkError, match="SWIGLU_FWD"):
+            ops.gemm_nt(x, w, swiglu_fwd_out=torch.empty((512, 256), device=dev, dtype=BF))
+        for v in (0, 1, 2):                           # a forced small-tile variant still routes the flag to the ping-pong kernel
+            ops.gemm_set_variant(v)
+            h = torch.full((512, 256), float("nan"), device=dev, dtype=BF)
+            ops.gemm_nt(x, w, swiglu_fwd_out=h)
+            assert torch.equal(h, ref_h), v
+    finally:
+        ops.gemm_set_variant(0)
 
 
 def test_gemm_tn_splitk(dev):
