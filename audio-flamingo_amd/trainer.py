@@ -56,6 +56,15 @@ class AfkAdamW(torch.optim.Optimizer):
         self.arena.refresh_shadows(force=True)
 
 
+def unwrap_optimizer(opt):
+    """peel accelerate's AcceleratedOptimizer (and any other `.optimizer`-holding wrapper) off: the HF Trainer loop never hands out the
+    optimizer it was given, it hands out the wrapper (the DP gates / master sync must reach the AfkAdamW underneath)"""
+    seen = 0
+    while opt is not None and not isinstance(opt, AfkAdamW) and hasattr(opt, "optimizer") and seen < 8:
+        opt, seen = opt.optimizer, seen + 1
+    return opt if isinstance(opt, AfkAdamW) else None
+
+
 def _trainer_base():
     from transformers import Trainer
 
@@ -76,10 +85,8 @@ class AfkTrainer(_trainer_base()):
         stock_clip = self.accelerator.clip_grad_norm_
 
         def _clip(parameters, max_norm, norm_type=2):
-            opt = self.optimizer
-            while opt is not None and not isinstance(opt, AfkAdamW) and hasattr(opt, "optimizer"):
-                opt = opt.optimizer  # accelerate's AcceleratedOptimizer wrapper
-            if isinstance(opt, AfkAdamW) and opt.fused.hyper is not None and norm_type == 2:
+            opt = unwrap_optimizer(self.optimizer)
+            if opt is not None and opt.fused.hyper is not None and norm_type == 2:
                 opt.fused.clip_norm = float(max_norm)
                 return opt.fused.grad_norm
             return stock_clip(parameters, max_norm, norm_type)
@@ -99,8 +106,9 @@ class AfkTrainer(_trainer_base()):
 
             self._afk_engine = DataParallelEngine(self.model.arena, overlap=True)
             self._afk_engine.broadcast_parameters(0)
-            if isinstance(self.optimizer, AfkAdamW):
-                self.optimizer.fused.sync_master()
+            opt = unwrap_optimizer(self.optimizer)
+            if opt is not None:
+                opt.fused.sync_master()
             self._afk_scale = torch.full((1,), 1.0 / self._afk_engine.world, device=self.model.arena.device, dtype=torch.float32)
         return self._afk_engine
 
@@ -117,8 +125,11 @@ class AfkTrainer(_trainer_base()):
                 eng.finish()
                 g = self.model.arena.grads
                 ops.scale_add_(g, g, self._afk_scale, accumulate=False)  # averaged gradients: clipping / logging see the DDP convention
-                if isinstance(self.optimizer, AfkAdamW):
-                    self.optimizer.gates = eng.bucket_gate
+                opt = unwrap_optimizer(self.optimizer)
+                if opt is not None:
+                    # a bucket NO rank touched this step (e.g. the audio tower on an all-text step) must keep parameters AND moments, as
+                    # torch.optim does for `grad is None`: the AdamW launches of the coming optimizer.step() are gated on these flags
+                    opt.gates = eng.bucket_gate
         finally:
             eng.enabled = True
         return loss

@@ -76,10 +76,21 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         ropt.clip_norm = CLIP
     assert torch.equal(m.arena.params, ref.arena.params), "broadcast_parameters failed"
     mine = slice(rank, rank + 1)
-    for step in range(3):
-        uneven = step == 2   # last step: rank 1 trains on text only (no audio tower on that rank)
+    names = m.arena.bucket_names
+    audio_buckets = [i for i, n in enumerate(names) if n == "stem" or n.startswith("enc")]
+    a_lo, a_hi = m.arena.bucket_range(audio_buckets[0])[0], m.arena.bucket_range(audio_buckets[-1])[1]
+    for step in range(4):
+        uneven = step == 2   # rank 1 trains on text only (no audio tower on that rank)
+        all_text = step == 3  # NO rank runs the audio tower: its buckets must keep parameters, m and v (torch: grad is None -> skipped)
         ref.zero_grad()
-        if uneven:
+        if all_text:
+            texts = [g["ids"][r:r + 1, -40:].to(dev) for r in range(world)]
+            for tx in texts:
+                ((1.0 / world) * ref(input_ids=tx, labels=tx).loss).backward()
+            text = texts[rank]
+            before = [t[a_lo:a_hi].clone() for t in (m.arena.params, opt.master, opt.m, opt.v)]
+            rbefore = [t[a_lo:a_hi].clone() for t in (ref.arena.params, ropt.master, ropt.m, ropt.v)]
+        elif uneven:
             # mean over ranks of per-rank mean losses: rank 0 = audio sample 0, rank 1 = text-only tail of sample 1
             text = g["ids"][1:2, -40:].to(dev)
             (0.5 * ref(**batch(slice(0, 1))).loss).backward()       # one forward / backward at a time: weight gradients accumulate in the arena
@@ -87,13 +98,14 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         else:
             ref(**batch(slice(0, 2))).loss.backward()
         ref_grads = ref.arena.grads.clone()
+        ref_params_before = m.arena.params.clone()
         ropt.step()
         m.zero_grad()
         if ov is not None:
             ov.begin_step()
         else:
             eng.begin_backward()
-        if uneven and rank == 1:
+        if all_text or (uneven and rank == 1):
             out = m(input_ids=text, labels=text)
         else:
             out = m(**batch(mine))
@@ -108,16 +120,26 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         dist.all_gather_object(issued, list(eng.issued))
         assert all(o == issued[0] for o in issued), ("collective order differs across ranks", issued)
         assert sorted(issued[0]) == list(range(len(m.arena.bucket_names))), issued[0]
-        assert eng.bucket_gate.tolist() == [1] * len(m.arena.bucket_names), eng.bucket_gate.tolist()
+        want_gate = [0 if (all_text and i in audio_buckets) else 1 for i in range(len(names))]
+        assert eng.bucket_gate.tolist() == want_gate, (eng.bucket_gate.tolist(), want_gate)
+        if all_text:
+            # ADVICE r02: an all-text step leaves the audio tower exactly as it was - parameters, fp32 master and both Adam moments - on the DP
+            # replica (device-gated launches) and on the single-process reference (untouched blocks are never launched)
+            for t, b in zip((m.arena.params, opt.master, opt.m, opt.v), before):
+                assert torch.equal(t[a_lo:a_hi], b), (mode, "audio tower state moved on an all-text DP step")
+            for t, b in zip((ref.arena.params, ropt.master, ropt.m, ropt.v), rbefore):
+                assert torch.equal(t[a_lo:a_hi], b), (mode, "audio tower state moved on an all-text single-process step")
+            assert not torch.equal(m.arena.params[a_hi:], ref_params_before[a_hi:]), "the text tower did not train"
         # averaged DP gradient == single-process gradient of the global mean loss
-        gr = rel(m.arena.grads.float() * eng.grad_scale, ref_grads)
-        # step 0 starts from bit-identical parameters (summation-order noise only: 2e-2); later steps start from parameters that already
-        # differ by AdamW's sign-flip noise (next assert), which the gradient inherits
-        assert gr <= (2e-2 if step == 0 else 6e-2), (mode, step, "grad rel-L2", gr)
-        # AdamW normalises the update (|m/sqrt(v)| ~ 1): a bf16-noise sign flip of a near-zero gradient moves a weight by up to 2*lr
+        sel = slice(a_hi, None) if all_text else slice(None)   # all-text step: the audio slices hold zeros on both sides
+        gr = rel(m.arena.grads[sel].float() * eng.grad_scale, ref_grads[sel])
+        # Bars = 4x the figures measured in round 2 (profiles/r02_dp_equivalence_gloo.json: gradient rel-L2 1.25e-3 at step 0 from bit-identical
+        # parameters - summation order only -, 2.5e-2 / 2.1e-2 afterwards, when the parameters already differ by AdamW's sign-flip noise and the
+        # gradient inherits it; parameter max |d| 2^-9 / 2^-8 / 2^-8 = one / two bf16 ulps of the largest weights; mean |d| 3.2e-7 / 7.3e-6 / 1.8e-5)
+        assert gr <= (5e-3 if step == 0 else 6e-2), (mode, step, "grad rel-L2", gr)
         dp = (m.arena.params.float() - ref.arena.params.float()).abs()
-        assert float(dp.max()) <= 2.5 * LR * (step + 1) + 2 ** -7, (mode, step, float(dp.max()))
-        assert float(dp.mean()) <= 0.2 * LR, (mode, step, float(dp.mean()))
+        assert float(dp.max()) <= min(2.5 * LR * (step + 1) + 2 ** -7, (2 ** -7, 2 ** -6, 2 ** -6, 2 ** -6)[step]) * 1.0001, (mode, step, float(dp.max()))
+        assert float(dp.mean()) <= (1.5e-6, 3e-5, 8e-5, 1.6e-4)[step], (mode, step, float(dp.mean()))
         if clip:
             # norm of the AVERAGED gradient (per-bucket partial sums gated on the all-rank flags) == the single-process norm, same on every rank
             gn, rn = float(opt.grad_norm), float(ropt.grad_norm)

@@ -278,3 +278,23 @@ def test_peel_plan_for_nearly_empty_last_rounds():
     assert (axis, cut) == (1, 73 * 256) and 14 * sp <= 256
     for shape in [(4608, 3584, 8192), (3584, 3584, 8192), (8192, 3584, 3584), (12000, 5120, 1280), (1280, 1280, 12000)]:
         assert ops.peel_plan_256(*shape) is None, shape
+
+
+def test_trainer_unwraps_accelerate_optimizer_wrappers():
+    """inside the HF Trainer loop `self.optimizer` is accelerate's AcceleratedOptimizer around AfkAdamW; the DP gates, the master
+    sync and the clip request must reach the AfkAdamW underneath, through any depth of `.optimizer` wrappers"""
+    from audio_flamingo_amd.trainer import AfkAdamW, unwrap_optimizer
+
+    class Wrap:  # the shape of accelerate.optimizer.AcceleratedOptimizer that matters here
+        def __init__(self, o):
+            self.optimizer = o
+
+    inner = AfkAdamW.__new__(AfkAdamW)   # no arena needed for the identity check
+    assert unwrap_optimizer(inner) is inner
+    assert unwrap_optimizer(Wrap(inner)) is inner
+    assert unwrap_optimizer(Wrap(Wrap(inner))) is inner
+    assert unwrap_optimizer(torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)) is None
+    assert unwrap_optimizer(None) is None
+    from accelerate.optimizer import AcceleratedOptimizer
+
+    assert hasattr(AcceleratedOptimizer, "__init__") and "optimizer" in AcceleratedOptimizer.__init__.__code__.co_varnames
