@@ -34,10 +34,12 @@ def _hf_model(cfg_dict, dev, state=None, seed=0):
 def test_reference_model_with_afk_attention_vs_golden(dev, case):
     """the reference's own bf16 model on this device, attention through libafk.so, against the fp32 golden - beside the SAME model with its
     stock sdpa attention (the bf16 noise floor of these trained, sharp-softmax goldens): the plugin run may deviate from the golden by the
-    bars of tests/_tol.py or by the floor rule of that file (4x what the stock run deviates), whichever is larger"""
+    bars of tests/_tol.py or by the floor rule of that file (2 x the LARGEST deviation of the stock run over the floor batches of
+    tests/test_model_gpu.py::_floor_distribution + this batch; gradient bars capped, noise-dominated tensors reported only), whichever is larger"""
     from audio_flamingo_amd import hf_plugin
-    from tests._tol import FLOOR_FACTOR, LOSS_ATOL, grad_bar, logit_tol
+    from tests._tol import GRAD_CAP, GRAD_REL_L2, LOSS_ATOL, NOISE_DOMINATED, floor_bar, logit_tol
     from tests.test_host_cpu import TINY
+    from tests.test_model_gpu import _floor_distribution
 
     name = hf_plugin.register()
     g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
@@ -61,9 +63,18 @@ def test_reference_model_with_afk_attention_vs_golden(dev, case):
                          logit=float((out.logits.float().cpu()[sel] - g["logits_bf16"].float()).abs().max()),
                          grads={k: _rel(params[k].grad, v) for k, v in g["grads"].items()})
     floor, got = res["sdpa"], res[name]
-    assert got["loss"] <= max(LOSS_ATOL, FLOOR_FACTOR * floor["loss"]), (got, floor)
-    assert got["logit"] <= max(logit_tol(g["logits_absmax"]), FLOOR_FACTOR * floor["logit"]), (got["logit"], floor["logit"])
-    bad = {k: (v, floor["grads"][k]) for k, v in got["grads"].items() if v > grad_bar(floor["grads"][k])}
+    dist = _floor_distribution(dev, case)   # the stock-attention reference model in bf16 on this device, over the floor batches
+    fl_loss = [floor["loss"]] + [abs(f["loss"] - o["loss_ref"]) for f, o in zip(dist["floor"], dist["ours"])]
+    fl_logit = [floor["logit"]] + [f["logits"]["max"] for f in dist["floor"]]
+    assert got["loss"] <= floor_bar(LOSS_ATOL, fl_loss), (got, fl_loss)
+    assert got["logit"] <= floor_bar(logit_tol(g["logits_absmax"]), fl_logit), (got["logit"], fl_logit)
+    bad = {}
+    for k, v in got["grads"].items():
+        fl = [floor["grads"][k]] + [f["grad_rel_l2"][k] for f in dist["floor"]]
+        if min(fl) > NOISE_DOMINATED:
+            continue   # bf16 cannot resolve this tensor on the sharp goldens (tests/_tol.py); pinned by the smooth cases
+        if v > floor_bar(GRAD_REL_L2, fl, cap=GRAD_CAP):
+            bad[k] = (v, max(fl))
     assert not bad, bad
 
 

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "tests", "golden")
-from tests._tol import AUDIO_REL_L2, FLOOR_FACTOR, GRAD_REL_L2, LOSS_ATOL, grad_bar, logit_tol
+from tests._tol import (AUDIO_REL_L2, FLOOR_FACTOR, GRAD_CAP, GRAD_REL_L2, LOSS_ATOL, N_FLOOR_SEEDS, NOISE_DOMINATED, floor_bar, logit_tol,
+                         median)
 
 LOGIT_TOL = 4e-2  # absolute bar used only where the logits are O(1) (random-init comparisons against the oracle)
 REPORT = {}
@@ -109,35 +110,31 @@ def _golden_compare(g, out, m):
     return rep
 
 
-def _golden_assert(rep, floor):
-    """absolute bars of tests/_tol.py, each relaxed to a small multiple of the reference's own bf16 noise floor where that is higher
-    (rule and factors: tests/_tol.py)"""
-    assert abs(rep["loss"] - rep["loss_ref"]) <= max(LOSS_ATOL, FLOOR_FACTOR * abs(floor["loss"] - rep["loss_ref"])), (rep, floor)
-    assert rep["logits"]["rms"] <= 2 * floor["logits"]["rms"] + 1e-3, (rep["logits"], floor["logits"])
-    assert rep["logits"]["max"] <= max(rep["logit_tol"], FLOOR_FACTOR * floor["logits"]["max"]), (rep["logits"], floor["logits"], rep["logit_tol"])
-    assert rep["n_confident"] >= 0.95 * rep["n_valid"], rep          # the token-id check covers (nearly) every position
-    assert rep["argmax_mismatch_confident"] == 0, rep
-    assert rep["argmax_mismatch_all_valid"] <= floor["argmax_mismatch_all_valid"] + 1, (rep, floor)
-    assert rep["audio_rel_l2"] <= AUDIO_REL_L2, rep
-    bad = {k: (v, floor["grad_rel_l2"][k]) for k, v in rep["grad_rel_l2"].items() if v > grad_bar(floor["grad_rel_l2"][k])}
-    assert not bad, (bad, rep)
+_FLOOR_CACHE = {}
 
 
-@pytest.mark.parametrize("case", ["A", "B", "C", "C-interval"])
-def test_forward_backward_vs_reference_golden(dev, case):
-    """A: full windows; B: padded window + RIGHT-padded row (kv_len path); C: the batch the reference's own AudioFlamingo3Processor
-    builds - LEFT padded, labels from output_labels=True - handed over as the processor hands it (CPU tensors): the decoder's causal
-    LDS-staged kernels with kv_lo; C-interval: the same batch on the interval kernels (what head sizes other than 64 / 128 take).
-    Every figure is reported beside the reference's own bf16-on-device run against the same fp32 golden (noise floor)."""
-    from audio_flamingo_amd import ops
+def _live_golden(ref32, inp):
+    """what oracle/make_golden.py::golden_case stores, computed live from the reference's fp32 CPU run on a fresh seeded batch"""
+    from oracle.make_golden import PICK
 
-    interval = case == "C-interval"
-    case = case[0]
-    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
-    m = _model(dev)
-    m.left_pad_on_lds_kernels = not interval
+    fe_b = inp["feats"].to(torch.bfloat16).float()
+    ref32.zero_grad()
+    out = ref32(input_ids=inp["ids"], input_features=fe_b, input_features_mask=inp["fmask"], attention_mask=inp["att"], labels=inp["labels"])
+    out.loss.backward()
+    grads = {n: p.grad.clone() for n, p in ref32.named_parameters() if p.grad is not None}
+    with torch.no_grad():
+        audio = ref32.get_audio_features(fe_b, inp["fmask"]).pooler_output
+    keep = inp["labels"] != -100
+    logits = out.logits.detach()
+    top2 = logits.topk(2, -1).values
+    return dict(feats=inp["feats"].to(torch.bfloat16), fmask=inp["fmask"].to(torch.int32), ids=inp["ids"], att=inp["att"], labels=inp["labels"],
+                loss=out.loss.detach(), logits_bf16=logits[keep].to(torch.bfloat16), argmax=logits.argmax(-1), top_gap=(top2[..., 0] - top2[..., 1]),
+                logits_absmax=float(logits.abs().max()), audio_bf16=audio.to(torch.bfloat16), grads={k: grads[k].to(torch.bfloat16) for k in PICK},
+                grad_norms={k: float(v.norm()) for k, v in grads.items()})
+
+
+def _run_ours(m, g, dev, case):
     m.zero_grad()
-    ops.kernel_counts(reset=True)
     if case == "C":
         out = m(input_ids=g["ids"], input_features=g["feats"], input_features_mask=g["fmask"], attention_mask=g["att"], labels=g["labels"],
                 return_logits=True)
@@ -147,6 +144,111 @@ def test_forward_backward_vs_reference_golden(dev, case):
                 attention_mask=att, labels=g["labels"].to(dev), return_logits=True)
     out.loss.backward()
     torch.cuda.synchronize()
+    return out
+
+
+def _floor_distribution(dev, case):
+    """the reference-bf16 noise floor as a DISTRIBUTION.  N_FLOOR_SEEDS fresh batches of the golden's kind (same
+    generator as oracle/make_golden.py, other seeds); per batch the reference's fp32 CPU run is the truth, and both the reference's own bf16
+    run on this device and ours are compared against it with the same statistics as the stored golden.  -> {"floor": [...], "ours": [...]}"""
+    if case in _FLOOR_CACHE:
+        return _FLOOR_CACHE[case]
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    from oracle.make_golden import make_inputs, make_inputs_processor
+
+    ref32 = AudioFlamingo3ForConditionalGeneration(_cfg())
+    ref32.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    ref32 = ref32.float().eval()
+    refb, m = _ref_bf16(dev), _model(dev)
+    floors, ours = [], []
+    for i in range(N_FLOOR_SEEDS):
+        seed = 9000 + 17 * i
+        inp = make_inputs_processor(seed) if case == "C" else make_inputs(case, seed)
+        g = _live_golden(ref32, inp)
+        floors.append(_floor(refb, g, dev))
+        ours.append(_golden_compare(g, _run_ours(m, g, dev, case), m))
+    _FLOOR_CACHE[case] = {"floor": floors, "ours": ours}
+    return _FLOOR_CACHE[case]
+
+
+def _stat_table(rep, floor):
+    """-> {statistic name: (ours, reference bf16)} for the scalar statistics both sides report"""
+    t = {"loss_abs_err": (abs(rep["loss"] - rep["loss_ref"]), abs(floor["loss"] - rep["loss_ref"])),
+         "logits_max": (rep["logits"]["max"], floor["logits"]["max"]), "logits_rms": (rep["logits"]["rms"], floor["logits"]["rms"]),
+         "logits_p999": (rep["logits"]["p999"], floor["logits"]["p999"])}
+    for k, v in rep["grad_rel_l2"].items():
+        t["grad:" + k] = (v, floor["grad_rel_l2"][k])
+    return t
+
+
+def _abs_bar(name, rep):
+    return {"loss_abs_err": LOSS_ATOL, "logits_max": rep["logit_tol"], "logits_rms": rep["logit_tol"] / 8, "logits_p999": rep["logit_tol"]}.get(name, GRAD_REL_L2)
+
+
+def _golden_assert(rep, floor, dist):
+    """tests/_tol.py: every statistic of ours on the stored golden <= max(absolute bar, 2 x the LARGEST reference-bf16 value of that statistic
+    over the floor batches + the golden batch itself); gradient bars capped at GRAD_CAP; tensors the reference's bf16 never resolves
+    (floor > NOISE_DOMINATED on every batch) are reported, not asserted.  -> the table of (ours, bar, floor max) per statistic"""
+    table, bad = {}, {}
+    mine = _stat_table(rep, floor)
+    per_batch = [_stat_table(o, f) for o, f in zip(dist["ours"], dist["floor"])]
+    for name, (v, fl0) in mine.items():
+        fl = [fl0] + [t[name][1] for t in per_batch]
+        is_grad = name.startswith("grad:")
+        if is_grad and min(fl) > NOISE_DOMINATED:
+            table[name] = {"ours": v, "floor_min": min(fl), "floor_max": max(fl), "bar": None, "note": "noise-dominated at bf16 on this golden; pinned by cases D/E"}
+            continue
+        bar = floor_bar(_abs_bar(name, rep), fl, cap=GRAD_CAP if is_grad else None)
+        table[name] = {"ours": v, "bar": bar, "floor_max": max(fl), "floor_median": median(fl), "ratio_to_floor_max": v / max(max(fl), 1e-12)}
+        if v > bar:
+            bad[name] = table[name]
+    assert not bad, (bad, rep)
+    assert rep["n_confident"] >= 0.95 * rep["n_valid"], rep          # the token-id check covers (nearly) every position
+    assert rep["argmax_mismatch_confident"] == 0, rep
+    assert rep["argmax_mismatch_all_valid"] <= floor["argmax_mismatch_all_valid"] + 1, (rep, floor)
+    assert rep["audio_rel_l2"] <= AUDIO_REL_L2, rep
+    return table
+
+
+def _distribution_assert(dist):
+    """the robust half of the rule: the MEDIAN over the floor batches of every statistic of ours <= max(absolute bar, 2 x the median of the
+    reference's bf16 run), and the worst batch of ours <= 2 x the worst batch of the reference.  -> summary table"""
+    per = [_stat_table(o, f) for o, f in zip(dist["ours"], dist["floor"])]
+    summary, bad = {}, {}
+    for name in per[0]:
+        o, f = [t[name][0] for t in per], [t[name][1] for t in per]
+        is_grad = name.startswith("grad:")
+        ab = _abs_bar(name, dist["ours"][0])
+        row = {"ours_median": median(o), "ours_max": max(o), "floor_median": median(f), "floor_max": max(f), "floor_min": min(f)}
+        summary[name] = row
+        if is_grad and min(f) > NOISE_DOMINATED:
+            row["note"] = "noise-dominated at bf16 on this golden; pinned by cases D/E"
+            continue
+        cap = GRAD_CAP if is_grad else float("inf")
+        if median(o) > min(cap, max(ab, FLOOR_FACTOR * median(f))) or max(o) > min(2 * cap, max(ab, FLOOR_FACTOR * max(f))):
+            bad[name] = row
+    assert not bad, bad
+    assert all(o["argmax_mismatch_confident"] == 0 for o in dist["ours"]), [o["argmax_mismatch_confident"] for o in dist["ours"]]
+    return summary
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "C-interval"])
+def test_forward_backward_vs_reference_golden(dev, case):
+    """A: full windows; B: padded window + RIGHT-padded row (kv_len path); C: the batch the reference's own AudioFlamingo3Processor
+    builds - LEFT padded, labels from output_labels=True - handed over as the processor hands it (CPU tensors): the decoder's causal
+    LDS-staged kernels with kv_lo; C-interval: the same batch on the interval kernels (what head sizes other than 64 / 128 take).
+    Every figure is held against the reference's own bf16-on-device run (noise floor) measured over N_FLOOR_SEEDS + 1 batches of the same
+    kind (tests/_tol.py: FLOOR_FACTOR = 2)."""
+    from audio_flamingo_amd import ops
+
+    interval = case == "C-interval"
+    case = case[0]
+    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
+    m = _model(dev)
+    m.left_pad_on_lds_kernels = not interval
+    ops.kernel_counts(reset=True)
+    out = _run_ours(m, g, dev, case)
     cnt = ops.kernel_counts()
     if interval:
         assert cnt["xattn_fwd"] >= 2 and cnt["xattn_bwd"] >= 2, cnt
@@ -154,9 +256,72 @@ def test_forward_backward_vs_reference_golden(dev, case):
         assert cnt["xattn_fwd"] == 0 and cnt["attn2_fwd_d64"] >= 2 and cnt["attn2_bwd_d64"] >= 2, cnt   # tiny64 decoder: head_dim 64
     rep = _golden_compare(g, out, m)
     floor = _floor(_ref_bf16(dev), g, dev)
-    REPORT[f"case{case}" + ("_interval_kernels" if interval else "")] = {"ours": rep, "reference_bf16_on_device": floor}
+    dist = _floor_distribution(dev, case)
+    key = f"case{case}" + ("_interval_kernels" if interval else "")
+    REPORT[key] = {"ours": rep, "reference_bf16_on_device": floor}
     _dump()
-    _golden_assert(rep, floor)
+    REPORT[key]["bars"] = _golden_assert(rep, floor, dist)
+    _dump()
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C"])
+def test_noise_floor_distribution(dev, case):
+    """the floor itself, on record: N_FLOOR_SEEDS fresh batches per golden kind, reference-bf16-on-device and ours against the reference's
+    fp32 run; median / worst-batch rule of tests/_tol.py; the distribution goes to the parity report"""
+    dist = _floor_distribution(dev, case)
+    REPORT[f"floor_distribution_case{case}"] = {"n_batches": len(dist["floor"]), "seeds": [9000 + 17 * i for i in range(N_FLOOR_SEEDS)]}
+    REPORT[f"floor_distribution_case{case}"]["summary"] = _distribution_assert(dist)
+    _dump()
+
+
+@pytest.mark.parametrize("case", ["D", "E"])
+def test_smooth_goldens_every_parameter_gradient(dev, case):
+    """the SMOOTH goldens (random-init reference, 2 + 2 layers, a label on every text position; D = full windows,
+    E = padded window + right-padded row): loss, logits, audio rows and the gradient of EVERY parameter tensor against the live reference's
+    fp32 run, at the FIXED bars of tests/_tol.py - no noise-floor relaxation.  The reference's own bf16 run on this device is reported
+    beside ours for context only."""
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    g = torch.load(os.path.join(G, f"tiny64_case{case}.pt"))
+    sd = torch.load(os.path.join(G, "tiny64_smooth_state_bf16.pt"))
+    m = Mine(_cfg(), device=dev)
+    m.load_state_dict(sd)
+    m.zero_grad()
+    att = g["att"].to(dev) if case == "E" else None
+    out = m(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), attention_mask=att,
+            labels=g["labels"].to(dev), return_logits=True)
+    out.loss.backward()
+    torch.cuda.synchronize()
+    sel = torch.nn.functional.pad(g["labels"], (0, 1), value=-100)[:, 1:] != -100
+    params = dict(m.named_parameters())
+    assert set(g["grads"]) == {k for k, p in params.items() if p.requires_grad}, "the golden must cover every trainable tensor"
+    rel = {k: _rel(params[k].grad, v) for k, v in g["grads"].items()}
+    cos = {k: float(torch.nn.functional.cosine_similarity(params[k].grad.float().cpu().flatten(), v.float().flatten(), dim=0)) for k, v in g["grads"].items()}
+    n_tok = ((g["fmask"].sum(-1) - 1) // 2 + 1 - 2) // 2 + 1
+    rows = torch.cat([out.audio_hidden_states.float().cpu()[w * 750: w * 750 + int(n)] for w, n in enumerate(n_tok)])
+    # context: the reference itself in bf16 on this device
+    refb = AudioFlamingo3ForConditionalGeneration(_cfg())
+    refb.load_state_dict(sd)
+    refb = refb.to(dev).to(torch.bfloat16).train()
+    ro = refb(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), attention_mask=g["att"].to(dev),
+              labels=g["labels"].to(dev))
+    ro.loss.backward()
+    rp = dict(refb.named_parameters())
+    ref_rel = {k: _rel(rp[k].grad, v) for k, v in g["grads"].items()}
+    rep = {"loss": float(out.loss), "loss_ref": float(g["loss"]), "logits": _stats(out.logits.float().cpu()[sel] - g["logits_bf16"].float()),
+           "logits_ref_absmax": g["logits_absmax"], "audio_rel_l2": _rel(rows, g["audio_bf16"]), "grad_bar": GRAD_REL_L2, "n_gradient_tensors": len(rel),
+           "grad_rel_l2_worst": dict(sorted(rel.items(), key=lambda kv: -kv[1])[:8]), "grad_cosine_worst": dict(sorted(cos.items(), key=lambda kv: kv[1])[:4]),
+           "grad_rel_l2": rel, "reference_bf16_on_device": {"loss": float(ro.loss.detach()), "grad_rel_l2_worst": dict(sorted(ref_rel.items(), key=lambda kv: -kv[1])[:8]),
+                                                            "grad_rel_l2": ref_rel}}
+    REPORT[f"case{case}_smooth"] = rep
+    _dump()
+    assert abs(rep["loss"] - rep["loss_ref"]) <= LOSS_ATOL, rep
+    assert rep["logits"]["max"] <= LOGIT_TOL, rep["logits"]
+    assert rep["audio_rel_l2"] <= AUDIO_REL_L2, rep["audio_rel_l2"]
+    bad = {k: (v, cos[k]) for k, v in rel.items() if v > GRAD_REL_L2}
+    assert not bad, bad
 
 
 def test_against_cpu_oracle_fresh_inputs(dev):
@@ -601,8 +766,21 @@ def test_on_device_audio_preprocessing_matches_reference_processor(dev):
     chunks = [clips[0], clips[1][:480000], clips[1][480000:960000], clips[1][960000:]]
     ref = fe(chunks, sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="pt")
     assert torch.equal(ref["attention_mask"].to(torch.int32), out["input_features_mask"].cpu())
-    err = (out["input_features"].cpu() - ref["input_features"]).abs()
-    assert err.max() < 2e-4 and err.median() < 1e-5, (float(err.max()), float(err.median()))
+    # the reference-relative bar of tests/test_ops_gpu.py::test_logmel: the reference's two own paths (numpy / torch)
+    # differ by d_ref on these clips; ours must lie within 4 x max(d_ref, 1e-5) of either path, median below 1e-5
+    import numpy as _np
+    batch = _np.zeros((4, 480000), _np.float32)
+    for i, c in enumerate(chunks):
+        batch[i, : len(c)] = c
+    ref_np = torch.from_numpy(_np.asarray(fe._np_extract_fbank_features(batch, "cpu"), _np.float32))
+    ref_t = torch.from_numpy(_np.asarray(fe._torch_extract_fbank_features(batch, "cpu"), _np.float32))
+    d_ref = float((ref_np - ref_t).abs().max())
+    mine = out["input_features"].cpu()
+    e_t, e_np = (mine - ref_t).abs(), (mine - ref_np).abs()
+    err = torch.minimum(e_t, e_np)
+    msg = f"processor log-mel: ours vs torch path {float(e_t.max()):.3g}, vs numpy path {float(e_np.max()):.3g}, reference's own two paths {d_ref:.3g}"
+    assert float(err.max()) <= 4.0 * max(d_ref, 1e-5), msg
+    assert float(e_t.median()) < 1e-5 and float((mine - ref["input_features"]).abs().median()) < 1e-5, msg
     assert expand_sound_tokens([5, 1023, 7], 1023, 3) == [5, 1023, 1023, 1023, 7]
     # and the whole thing drives the model: ragged windows -> encoder -> scatter
     m = _model(dev)
