@@ -9,7 +9,8 @@ fused arena blocks (q|k|v and gate|up are stored contiguously so that each is on
 ``load_state_dict`` from an oracle checkpoint and ``state_dict`` round-trip unchanged.
 
 Deviations from the oracle surface (documented, not silent):
-  * training forward with ``labels`` fuses lm_head + loss and returns ``logits=None`` unless ``return_logits=True``; lm_head and the
+  * training forward with ``labels`` fuses lm_head + loss; ``output.logits`` is still there, as in the reference, but LAZY: the [B, S, V]
+    tensor is built on first access (``return_logits=True`` builds it eagerly, inside the autograd graph of the step); lm_head and the
     loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
   * ``forward(use_cache=True)`` / ``forward(past_key_values=cache)``: the reference's cache protocol for inference (prefill returns an
     ``AfkKVCache``, later calls append one or several tokens); same kernels and cache layout as ``generate``;
@@ -22,7 +23,6 @@ Deviations from the oracle surface (documented, not silent):
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
 from typing import Optional
 
 import torch
@@ -46,17 +46,67 @@ class AfkKVCache:
         return self.length
 
 
-@dataclass
 class AF3Output:
-    loss: Optional[torch.Tensor] = None
-    logits: Optional[torch.Tensor] = None
-    past_key_values: Optional[object] = None
-    hidden_states: Optional[tuple] = None
-    attentions: Optional[tuple] = None
-    audio_hidden_states: Optional[torch.Tensor] = None
+    """The reference's ModelOutput surface (AudioFlamingo3CausalLMOutputWithPast, modeling_audioflamingo3.py:635-642): attribute, key, index and
+    slice access, ``to_tuple()``, ``keys()`` / ``items()``.
+
+    ``logits`` is ALWAYS available, as in the reference (which returns it whenever it returns a loss, :625-642) - but when ``labels`` were
+    given the fused lm_head + loss path never built the [B, S, V] tensor, so it is materialised on FIRST ACCESS (one lm_head GEMM on the
+    final hidden states the output keeps): a training loop that only reads ``out.loss`` / ``out[0]`` never pays for it, ``Trainer.evaluate``
+    / ``compute_metrics`` (which read ``outputs[1:]``) get what they expect."""
+
+    _FIELDS = ("loss", "logits", "past_key_values", "hidden_states", "attentions", "audio_hidden_states")
+
+    def __init__(self, loss=None, logits=None, past_key_values=None, hidden_states=None, attentions=None, audio_hidden_states=None, logits_fn=None):
+        self.loss, self._logits, self._logits_fn = loss, logits, logits_fn
+        self.past_key_values, self.hidden_states, self.attentions, self.audio_hidden_states = past_key_values, hidden_states, attentions, audio_hidden_states
+
+    @property
+    def logits(self):
+        if self._logits is None and self._logits_fn is not None:
+            self._logits, self._logits_fn = self._logits_fn(), None
+        return self._logits
+
+    @logits.setter
+    def logits(self, v):
+        self._logits, self._logits_fn = v, None
+
+    @property
+    def logits_materialized(self) -> bool:
+        return self._logits is not None
+
+    def _present(self, name):
+        return (self._logits is not None or self._logits_fn is not None) if name == "logits" else getattr(self, name) is not None
+
+    def keys(self):
+        return [f for f in self._FIELDS if self._present(f)]
+
+    def items(self):
+        return [(f, getattr(self, f)) for f in self.keys()]
+
+    def to_tuple(self):
+        return tuple(getattr(self, f) for f in self.keys())
+
+    def get(self, k, default=None):
+        return getattr(self, k) if k in self._FIELDS and self._present(k) else default
+
+    def __contains__(self, k):
+        return k in self._FIELDS and self._present(k)
 
     def __getitem__(self, k):
-        return getattr(self, k) if isinstance(k, str) else tuple(v for v in (self.loss, self.logits) if v is not None)[k]
+        if isinstance(k, str):
+            if k not in self._FIELDS:
+                raise KeyError(k)
+            return getattr(self, k)
+        if isinstance(k, int):
+            return getattr(self, self.keys()[k])   # out[0] is the loss: nothing else is touched (no logits materialisation)
+        return self.to_tuple()[k]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
 
 
 class _Holder(nn.Module):
@@ -502,13 +552,16 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             else:
                 denom = ops.count_valid(shift)
             loss = F_.LMHeadLossFn.apply(x, self._anchor("lm_head.weight"), a, "lm_head.weight", shift, denom, rows)
-        if labels is None or return_logits:
-            xs = x
+        def _logits(xh=x):
+            xs = xh
             if isinstance(logits_to_keep, int) and logits_to_keep > 0:
-                xs = x.reshape(B, S, -1)[:, -logits_to_keep:, :].reshape(-1, x.shape[-1]).contiguous()
-            lg = F_.LMHeadFn.apply(xs, self._anchor("lm_head.weight"), a, "lm_head.weight")
-            logits = lg.reshape(B, -1, self.V)
-        return AF3Output(loss=loss, logits=logits, audio_hidden_states=audio_hidden)
+                xs = xh.reshape(B, S, -1)[:, -logits_to_keep:, :].reshape(-1, xh.shape[-1]).contiguous()
+            return F_.LMHeadFn.apply(xs, self._anchor("lm_head.weight"), a, "lm_head.weight").reshape(B, -1, self.V)
+
+        if labels is None or return_logits:
+            return AF3Output(loss=loss, logits=_logits(), audio_hidden_states=audio_hidden)
+        # labels given: the reference returns logits beside the loss (modeling_audioflamingo3.py:625-642); here they are built on first access
+        return AF3Output(loss=loss, logits_fn=_logits, audio_hidden_states=audio_hidden)
 
     # ------------------------------------------------------------------ generate (greedy; KV cache - SURVEY.md 8(f)-4)
     def _merged_embeddings(self, ids, input_features, input_features_mask):

@@ -35,21 +35,27 @@ class MusicFlamingoForConditionalGeneration(AudioFlamingo3ForConditionalGenerati
         pos = torch.arange(int(self.mf_max_len), dtype=torch.float32, device=dev) / self.mf_max_len * (2 * math.pi)
         self.mf_pos_angles = torch.repeat_interleave(pos.unsqueeze(-1) * self.mf_inv_freq, 2, dim=-1)                       # MF:121-126
 
-    # MF:331-372 - which window of its sample every encoder window is, from the <sound> runs of input_ids
     def _audio_timestamps(self, input_ids, post_lengths, T3):
+        """seconds [W, T3] of every encoder output row: (index of the window INSIDE its sample) * window length + 40 ms per row - what the
+        reference derives from the <sound> runs of input_ids (MF:331-372).  Derivation used here (sync-free, no run extraction): windows are
+        consumed in placeholder order, so window w owns the placeholder ranks [r_w, r_w + post_w) with r_w the exclusive prefix sum of the
+        per-window token counts; the flat position of rank r is where the running placeholder count first reaches r + 1.  A window opens a
+        new sample exactly when the token in front of its first placeholder is not a placeholder of the same row; its index inside the
+        sample is the distance to the latest such opening window (a running maximum)."""
         dev = self.device_
-        m = (input_ids == self.audio_token_id).int()
-        diff = torch.diff(torch.nn.functional.pad(m, (1, 1), value=0), dim=1)
-        _, starts = torch.where(diff == 1)
-        _, ends = torch.where(diff == -1)
-        sample_lengths = (ends - starts).long()
-        step = self.mf_frame_step * 4
-        offs = torch.arange(T3, device=dev, dtype=torch.float32) * step
-        cum_post = torch.cat([torch.zeros(1, device=dev), torch.cumsum(post_lengths, 0)[:-1]])
-        sample_idx = torch.searchsorted(torch.cumsum(sample_lengths, 0), cum_post, right=True)
-        first_row = torch.searchsorted(sample_idx, torch.arange(sample_lengths.shape[0], device=dev))
-        win_idx = torch.arange(post_lengths.shape[0], device=dev) - first_row[sample_idx]
-        return win_idx.unsqueeze(1) * T3 * step + offs
+        S = input_ids.shape[1]
+        flat = input_ids.reshape(-1)
+        snd = flat == self.audio_token_id
+        running = torch.cumsum(snd.to(torch.int64), 0)                      # placeholders seen up to and including each position
+        W = post_lengths.shape[0]
+        first_rank = torch.cumsum(post_lengths, 0) - post_lengths           # exclusive prefix sum
+        pos = torch.searchsorted(running, first_rank + 1).clamp_max(flat.numel() - 1)
+        continues = (pos % S != 0) & snd[(pos - 1).clamp_min(0)]           # the same <sound> run carries on: same sample as window w - 1
+        w = torch.arange(W, device=dev)
+        opener = torch.cummax(torch.where(continues, torch.zeros_like(w), w), 0).values
+        step = self.mf_frame_step * 4                                       # conv2 stride 2, avg-pool 2: 40 ms per encoder output row
+        rows = torch.arange(T3, device=dev, dtype=torch.float32) * step
+        return (w - opener).unsqueeze(1) * T3 * step + rows
 
     # MF:97-118
     def _tables(self, ts, T3):

@@ -220,6 +220,18 @@ def test_music_flamingo_time_tables_match_oracle():
     ref_ts = O.music_audio_timestamps(ids, post, 750, 1023)
     assert torch.equal(ts, ref_ts)
     assert float(ts[1, 0]) == 30.0 and float(ts[2, 0]) == 0.0   # second window of sample 0 starts at 30 s; sample 1 restarts at 0
+    # the window-index derivation (running placeholder count + "does the run continue" test) against the reference's run extraction on
+    # layouts that stress it: a run ending at the last position of a row followed by a run starting at position 0 of the next row (two
+    # samples, NOT one run), three windows in one sample, a sample without audio in between, ragged last windows
+    S2 = 2000
+    ids2 = torch.randint(0, 1000, (4, S2))
+    ids2[0, S2 - 875:] = 1023            # sample 0: 750 + 125, run touches the END of its row
+    ids2[1, :1750] = 1023                # sample 1: 750 + 750 + 250, run starts at position 0 of the next row
+    ids2[3, 5:755] = 1023                # sample 2 (row 3; row 2 is text only): one full window
+    post2 = torch.tensor([750, 125, 750, 750, 250, 750])
+    ts2 = m._audio_timestamps(ids2, post2, 750)
+    assert torch.equal(ts2, O.music_audio_timestamps(ids2, post2, 750, 1023))
+    assert [float(x) for x in ts2[:, 0]] == [0.0, 30.0, 0.0, 30.0, 60.0, 0.0]
     cos, sin = m._tables(ts, 750)
     rc, rs = O.rotary_time_tables(ref_ts, 750, 128)
     assert cos.shape == rc.shape == (3, 750, 52)
