@@ -31,6 +31,26 @@ import torch.distributed as dist
 from .arena import Arena
 
 
+def _flags_on_device(flags, device) -> torch.Tensor:
+    """int32 device vector of 0/1 host flags, written by FILL kernels on the current stream (no host-to-device copy: a pageable H2D copy
+    cannot be recorded into a HIP graph, fill launches can - the step's flags are constants of a captured static-shape step)"""
+    t = torch.zeros(len(flags), device=device, dtype=torch.int32)
+    if all(flags):
+        t.fill_(1)
+    else:
+        i, n = 0, len(flags)
+        while i < n:          # one fill per run of ones
+            if flags[i]:
+                j = i
+                while j < n and flags[j]:
+                    j += 1
+                t[i:j].fill_(1)
+                i = j
+            else:
+                i += 1
+    return t
+
+
 class NativeComm:
     """The RCCL communicator behind the C ABI (include/afk.h afk_comm_*): what a non-Python host of libafk.so would use, and - with
     AFK_DP_COMM=native - what DataParallelEngine uses instead of torch.distributed's collectives.  One communicator per process / GPU."""
@@ -120,6 +140,10 @@ class DataParallelEngine:
         self.issued: List[int] = []  # bucket indices in the order their collectives were issued this step (tests compare ranks)
         self.bucket_gate: Optional[torch.Tensor] = None  # device int32 [n_buckets] after finish(): 1 where ANY rank touched the bucket
         self.enabled = True  # set False inside a no_sync() region (gradient accumulation micro-steps)
+        # world == 1 normally issues no collective at all.  force_collectives (bench.py --force-dp, env AFK_DP_FORCE=1) issues them anyway - a
+        # sum over one rank is the identity - so that the WHOLE multi-rank code path (side-stream ordering, RCCL launches, the touched-flag MAX,
+        # device-gated AdamW, RCCL inside a HIP-graph capture) can be executed and checked bit for bit on a 1-GPU box
+        self.force_collectives = _os.environ.get("AFK_DP_FORCE", "0") == "1"
         arena.on_bucket_ready = self._on_bucket_ready
         self._native_bf16 = True
         if not self.cuda:
@@ -225,7 +249,7 @@ class DataParallelEngine:
             t = t.to(self.arena.device)
         elif self.cuda:
             with torch.cuda.stream(self.comm_stream):
-                t = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
+                t = _flags_on_device(touched, self.arena.device)
                 if self.native is not None:
                     self.native.allreduce_(t, op_max=True)
                 else:
@@ -284,7 +308,7 @@ class BackwardOverlap:
         self.arena.on_bucket_ready = self._ready
 
     def _multi(self) -> bool:
-        return self.engine is not None and self.engine.world > 1
+        return self.engine is not None and (self.engine.world > 1 or self.engine.force_collectives)
 
     def _ready(self, i: int, gate=None, written_only: bool = False):
         if self._done[i]:
@@ -350,7 +374,7 @@ class BackwardOverlap:
                     dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
                     gate = gate.to(self.arena.device)
                 else:
-                    gate = torch.tensor(touched, dtype=torch.int32).to(self.arena.device, non_blocking=True)
+                    gate = _flags_on_device(touched, self.arena.device)
                     if eng.native is not None:
                         eng.native.allreduce_(gate, op_max=True)
                     else:

@@ -447,6 +447,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return lo, hi
 
     _rows_cache = None  # (weakref(labels tensor), version, rows) - see _valid_rows
+    # True: the POSITIONS of the labelled rows never change for a given labels tensor object, only the token values written into it do
+    # (a static input buffer refilled in place every step: bench.py's rotating synthetic batches, a HIP-graph-replayed step).  The row
+    # indices are then remembered per tensor object regardless of its version - no device scan, no host sync per step.
+    label_rows_static = False
 
     def _valid_rows(self, labels):
         """-> (shift_labels [B*S] on the device, rows) with rows = int64 indices (device) of the positions whose SHIFTED label is not -100,
@@ -463,7 +467,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             rows = rows.to(dev) if 0 < rows.numel() < sh.numel() else None
             return shift, rows
         c = self._rows_cache
-        if c is not None and c[0]() is labels and c[1] == labels._version:
+        if c is not None and c[0]() is labels and (c[1] == labels._version or self.label_rows_static):
             return sh.contiguous(), c[2]
         rows = (sh != -100).nonzero().reshape(-1)  # host sync: the count sizes the GEMMs
         rows = rows if 0 < rows.numel() < sh.numel() else None

@@ -37,6 +37,8 @@ CLIP_SECONDS = 30.0
 # BASELINE.json configs[1]/[2] ("clip30": one 30 s window per sample, micro-batch 8) and configs[4] ("long5min": one 5-minute clip =
 # 10 full windows per sample, 7 500 <sound> tokens, S = 7 774, micro-batch 1, per-layer activation checkpointing on both towers).
 WORKLOADS = {"clip30": dict(windows=1, batch=8, checkpoint=False), "long5min": dict(windows=10, batch=1, checkpoint=True),
+             # AF3's stated maximum ("up to 10 minutes", /root/reference README.md:109): 20 windows, 15 000 <sound> rows, S = 15 274
+             "long10min": dict(windows=20, batch=1, checkpoint=True),
              # BASELINE configs[3]: AF1/AF2-style ICL step (Perceiver resampler + gated cross-attention, 4 clips per sample); shapes are
              # builder-declared (audio_flamingo_amd/flamingo_icl.py ICL4), parity w.r.t. AF1/AF2 UNPINNED
              "icl4": dict(windows=0, batch=8, checkpoint=False)}
@@ -314,6 +316,82 @@ def run_icl4(args, dev):
     }
 
 
+def decode_leg(model, frontend, waves, ids, dev):
+    """generate() throughput on the resident AF3-7B replica (greedy, KV cache, HIP-graph-replayed decode step)"""
+    feats = frontend(waves, out_dtype=torch.bfloat16)
+    prompt = ids[:, : 9 + N_AUDIO_TOK + 9]
+    weight_bytes = 2.0 * (28 * (3584 * 4608 + 3584 * 3584 + 3 * 3584 * 18944) + 152064 * 3584)   # decoder Linears + lm_head, bf16, read once per token
+    out = {"prompt_tokens": int(prompt.shape[1]), "weight_bytes_per_token": weight_bytes, "hbm_roofline_ms_per_token": weight_bytes / 8e12 * 1e3}
+    for B in (1, 8):
+        t = {}
+        for new in (1, 33):
+            model.generate(prompt[:B], input_features=feats[:B], max_new_tokens=new)  # warm (allocator, one-time library init)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.generate(prompt[:B], input_features=feats[:B], max_new_tokens=new)
+            torch.cuda.synchronize()
+            t[new] = time.perf_counter() - t0
+        ms = 1e3 * (t[33] - t[1]) / 32
+        out[f"B{B}"] = {"prefill_plus_first_token_ms": 1e3 * t[1], "decode_ms_per_token": ms, "decode_tokens_per_s": B / (ms * 1e-3),
+                        "frac_of_weight_streaming_roofline": out["hbm_roofline_ms_per_token"] / ms}
+    return out
+
+
+def dry_run_cpu(args):
+    """CONTROL-FLOW TEST ONLY - no GPU, no kernel, no throughput (value = null).  Runs the N > 1 sequence of main() over gloo on the host:
+    process group -> replica = the real model class on the CPU (layout / arena / buckets only) -> DataParallelEngine + parameter broadcast ->
+    K steps whose "backward" is a stub that writes rank-dependent gradients and reports the blocks in the order the real backward does ->
+    bucket all-reduces issued from the arena's ready callbacks -> a stub SGD update (torch, host) in place of the fused AdamW kernel ->
+    replica checksum all-gather -> ONE JSON line from rank 0.  tests/test_host_cpu.py::test_bench_multi_rank_control_flow_gloo launches it with
+    2 processes through torch.distributed.run exactly as the driver launches the real thing."""
+    import torch.distributed as dist
+
+    from audio_flamingo_amd.dp import DataParallelEngine
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration
+    from transformers import AudioFlamingo3Config
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tiny = dict(audio_config=dict(num_mel_bins=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=256, hidden_size=128, max_source_positions=1500),
+                text_config=dict(vocab_size=1024, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                                 max_position_embeddings=4096), audio_token_id=1023)
+    model = AudioFlamingo3ForConditionalGeneration(AudioFlamingo3Config(**tiny), device="cpu", init_seed=10 + rank)   # replicas differ until the broadcast
+    arena = model.arena
+    engine = DataParallelEngine(arena, overlap=True)
+    engine.broadcast_parameters(0)
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        arena.zero_grad()
+        engine.begin_backward()
+        g = torch.Generator().manual_seed(1000 * k + rank)
+        for blk in reversed(arena.order):                      # the real backward completes blocks in reverse layout order
+            blk.grad.copy_(torch.randn(blk.shape, generator=g).to(torch.bfloat16))
+            arena.grad_written(blk)                             # -> on_bucket_ready -> all-reduce of the finished bucket
+        engine.finish()
+        assert sorted(engine.issued) == list(range(len(arena.bucket_names))), engine.issued
+        arena.params.add_((arena.grads.float() * engine.grad_scale).to(torch.bfloat16), alpha=-1e-3)   # stub update on the averaged gradients
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    p32 = arena.params.float()
+    chk = torch.stack([p32.sum().double(), p32.abs().sum().double()])
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    identical = all(bool(torch.equal(c, allc[0])) for c in allc)
+    assert identical, f"replicas diverged: {[c.tolist() for c in allc]}"
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train", "dry_run": True, "value": None, "unit": "audio-s/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "bf16", "data": "synthetic", "config": {"workload": "CONTROL-FLOW DRY RUN on the host (gloo): no kernels ran, nothing was measured"},
+                          "replicas_identical_after_steps": identical, "collective_backend": "gloo", "buckets": len(arena.bucket_names),
+                          "collectives_per_step": len(engine.issued) + 1}), flush=True)
+
+
 def settle_hbm(dev, quiet_s=8.0, timeout_s=60.0):
     """The amdgpu driver releases and scrubs a dead process's VRAM asynchronously (measured here: `mem_info_vram_used` falls from 215 GB
     to 0.3 GB over ~7 s after a 185 GB replica exits).  A replica that starts allocating inside or right behind that window gets
@@ -356,7 +434,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="clip30", help="clip30 = BASELINE configs[1]/[2] (the headline); long5min = configs[4]; icl4 = configs[3] (AF1/AF2-style ICL step)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="clip30", help="clip30 = BASELINE configs[1]/[2] (the headline); long5min = configs[4]; long10min = AF3's stated maximum clip length; icl4 = configs[3] (AF1/AF2-style ICL step)")
     ap.add_argument("--batch", type=int, default=0, help="micro-batch (samples) per GPU; default 8 for clip30 (BASELINE config), 1 for long5min")
     ap.add_argument("--no-checkpoint", action="store_true", help="long5min only: keep all activations instead of per-layer recompute")
     ap.add_argument("--enc-layers", type=int, default=32)
@@ -366,12 +444,22 @@ def main():
     ap.add_argument("--eager-only", action="store_true", help="measure ONLY the unmodified reference model on this GPU (eager PyTorch-ROCm): for rocprofv3 kernel tables")
     ap.add_argument("--clip", type=float, default=0.0, help="global-norm gradient clipping (HF Trainer default: 1.0); 0 = off, as the eager reference leg runs")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
-    ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) of the default run")
+    ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) and the 10-minute leg of the default run")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the decode leg (KV-cache generate, B = 1 and 8) and the configs[3] ICL leg of the default run")
+    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches resident in HBM, rotated one per step (1 = the same batch every step)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 / --force-dp: nccl = RCCL (production); "
+                    "gloo = host-staged exchange, for running the N > 1 control flow with several ranks on ONE GPU (tests/test_dp_gpu.py)")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-opt-overlap", action="store_true", help="run AdamW after backward instead of bucket-by-bucket inside it")
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient branch on the compute stream")
-    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel engine even with one rank (exercises the RCCL path)")
+    ap.add_argument("--force-dp", action="store_true", help="run the data-parallel engine even with one rank AND issue its collectives (identity at world 1): the whole RCCL path on a 1-GPU box")
+    ap.add_argument("--dp-graph", action="store_true", help="data parallel: capture the step - RCCL collectives included - into the HIP graph (default for N > 1: eager enqueue)")
+    ap.add_argument("--no-settle", action="store_true", help="do not wait for the driver to release a previous process's VRAM (tests)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="CONTROL-FLOW TEST ONLY (tests/test_host_cpu.py): no GPU, no kernels - the N > 1 sequence of this script "
+                    "(process group, parameter broadcast, per-bucket exchange in backward order, replica checksum, one JSON line on rank 0) with a stub in place of the step")
     args = ap.parse_args()
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
     wl = WORKLOADS[args.workload]
     args.batch = args.batch or wl["batch"]
     windows, ckpt = wl["windows"], wl["checkpoint"] and not args.no_checkpoint
@@ -390,9 +478,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local_rank %= max(torch.cuda.device_count(), 1)  # --backend gloo: several ranks may share one GPU (control-flow tests on 1-GPU boxes)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    waited = settle_hbm(dev)
+    waited = 0.0 if args.no_settle else settle_hbm(dev)
     if args.eager_only:
         from audio_flamingo_amd.frontend import LogMelFrontend
 
@@ -412,7 +501,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the script's own tiny collectives (timings, checksums) live
 
     full_model = args.enc_layers == 32 and args.dec_layers == 28
     model = AudioFlamingo3ForConditionalGeneration(af3_7b_config(args.enc_layers, args.dec_layers), device=dev, init_seed=0)
@@ -425,6 +515,7 @@ def main():
     engine = None
     if use_dp:
         engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
+        engine.force_collectives = engine.force_collectives or args.force_dp
         engine.broadcast_parameters(0)
         opt.sync_master()
     from audio_flamingo_amd import functional as F_
@@ -433,13 +524,27 @@ def main():
     model.arena.enable_wgrad_stream(not args.no_wgrad_stream)
     model.arena.thin_blocks = int(os.environ.get("AFK_THIN_TRANSPOSE", "0"))
     frontend = LogMelFrontend(dev)
-    waves, ids, labels = synthetic_batch(args.batch, rank * args.batch, dev, windows)
+    # `--batches` distinct synthetic batches live in HBM; every step trains on the next one (copied into the static input tensors the step -
+    # and its HIP graph - reads).  Training the SAME batch every step (round 2) drives the loss to ~0 within the timed region: saturated
+    # softmax, vanishing gradients - and on a power-limited chip operand statistics move the clock.
+    nb = max(1, args.batches)
+    pool = [synthetic_batch(args.batch, (rank + k * world) * args.batch, dev, windows) for k in range(nb)]
+    waves, ids, labels = (t.clone() for t in pool[0])
+    model.label_rows_static = True   # the labelled POSITIONS are the same in every synthetic batch; only the token values change
 
     overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
     if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
         overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
 
     data = {"waves": waves, "ids": ids, "labels": labels}
+    step_no = [0]
+
+    def load_next():
+        """next synthetic batch into the static input tensors (three device-to-device copies, inside the timed region)"""
+        if nb > 1:
+            w_, i_, l_ = pool[step_no[0] % nb]
+            data["waves"].copy_(w_), data["ids"].copy_(i_), data["labels"].copy_(l_)
+        step_no[0] += 1
 
     def step(serial=False):
         feats = frontend(data["waves"], out_dtype=torch.bfloat16)
@@ -468,7 +573,8 @@ def main():
 
     # N = 1: the step (static shapes) is captured once into a HIP graph - three streams, ~3 000 launches -> one hipGraphLaunch per step.
     # N > 1 keeps the eager enqueue (RCCL inside a capture is not validated on this pool's 1-GPU boxes; the host keeps ahead of the GPU there).
-    use_graph = (not args.no_graph) and not use_dp and overlap is not None and not ckpt
+    use_graph = (not args.no_graph) and (not use_dp or args.dp_graph) and overlap is not None and not ckpt
+    load_next()
     first_loss = float(step().detach())  # ~ ln(152064) = 11.9 for random-init weights: the line checks itself (the last loss is lower)
     run = step
     if use_graph:
@@ -477,18 +583,21 @@ def main():
         run = GraphedTrainStep(model, opt, overlap, step, warmup=1)
     loss = None
     for i in range(args.warmup):
+        load_next()
         loss = run()
     fence()
     ops.prof_reset()
     ops.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        load_next()
         loss = run()
     host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside; includes queue back-pressure once the GPU lags)
     fence()
     dt = time.perf_counter() - t0
     # the same WITHOUT back-pressure: one more (untimed) step enqueued onto an idle GPU - what the host really needs per step
     t1 = time.perf_counter()
+    load_next()
     loss = run()
     host_enqueue_idle = time.perf_counter() - t1
     fence()
@@ -520,13 +629,13 @@ def main():
         first_loss = final_loss
     rank_losses, replicas_identical = [final_loss], None
     if use_dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # every replica must hold bit-identical parameters after the timed steps (same reduced gradients, same AdamW): checksum per rank
         model.arena.join_streams()
         p32 = model.arena.params.float()
-        chk = torch.stack([p32.sum().double(), p32.abs().sum().double(), torch.tensor(final_loss, device=dev, dtype=torch.float64)])
+        chk = torch.stack([p32.sum().double(), p32.abs().sum().double(), torch.tensor(final_loss, device=dev, dtype=torch.float64)]).to(coll_dev)
         allc = [torch.zeros_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
         replicas_identical = all(bool(torch.equal(c[:2], allc[0][:2])) for c in allc)
@@ -535,11 +644,20 @@ def main():
         del p32
     peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
 
+    # parameter checksum of this replica after the timed steps (every run prints it: two schedules of the same code - eager / HIP graph, with /
+    # without the RCCL path - must agree on it bit for bit, tests/test_dp_gpu.py)
+    model.arena.join_streams()
+    torch.cuda.synchronize()
+    _p32 = model.arena.params.float()
+    param_checksum = [float(_p32.sum().double()), float(_p32.abs().sum().double())]
+    del _p32
+
     # BASELINE configs[4] (long audio) beside the headline: a few steps of the 5-minute workload on the same replica, so that the
-    # driver's plain `bench.py --gpus N` run records it too (one sample = 10 windows, S = 7 774, per-layer activation checkpointing)
-    long_audio = None
-    if args.workload == "clip30" and full_model and not args.no_long_audio:
-        lw = WORKLOADS["long5min"]
+    # driver's plain `bench.py --gpus N` run records it too (one sample = 10 windows, S = 7 774, per-layer activation checkpointing);
+    # then the same at AF3's stated maximum clip length (10 minutes = 20 windows, S = 15 274; /root/reference README.md:109)
+    def long_leg(name, label):
+        lw = WORKLOADS[name]
+        torch.cuda.reset_peak_memory_stats(dev)
         data["waves"], data["ids"], data["labels"] = synthetic_batch(lw["batch"], rank * lw["batch"], dev, lw["windows"])
         model.gradient_checkpointing_enable()
         for _ in range(2):
@@ -551,32 +669,59 @@ def main():
         fence()
         ldt = time.perf_counter() - t0
         if use_dp:
-            t = torch.tensor([ldt], device=dev, dtype=torch.float64)
+            t = torch.tensor([ldt], device=coll_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
         model.gradient_checkpointing_disable()
         ls = 9 + N_AUDIO_TOK * lw["windows"] + 9 + N_ANSWER
         sps = world * lw["batch"] * 3 / ldt
-        long_audio = {"workload": f"AF3-7B bf16 train step, 5-min clips = {lw['windows']} windows/sample, S={ls}, micro-batch {lw['batch']}/GPU, per-layer "
-                                  "activation checkpointing ON (BASELINE configs[4])", "ms_per_step": 1000.0 * ldt / 3, "steps": 3, "warmup": 2,
-                      "value": sps * CLIP_SECONDS * lw["windows"], "unit": "audio-s/s", "decoder_tokens_per_s": sps * ls,
-                      "model_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"]) * sps / world / 1e12,
-                      "hardware_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"], True) * sps / world / 1e12,
-                      "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+        res_ = {"workload": f"AF3-7B bf16 train step, {label} = {lw['windows']} windows/sample, S={ls}, micro-batch {lw['batch']}/GPU, per-layer "
+                            "activation checkpointing ON", "ms_per_step": 1000.0 * ldt / 3, "steps": 3, "warmup": 2,
+                "value": sps * CLIP_SECONDS * lw["windows"], "unit": "audio-s/s", "decoder_tokens_per_s": sps * ls,
+                "model_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"]) * sps / world / 1e12,
+                "hardware_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"], True) * sps / world / 1e12,
+                "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
         data["waves"], data["ids"], data["labels"] = waves, ids, labels
+        return res_
+
+    long_audio = long_10min = None
+    if args.workload == "clip30" and full_model and not args.no_long_audio:
+        long_audio = long_leg("long5min", "5-min clips (BASELINE configs[4])")
+        long_10min = long_leg("long10min", "10-min clips (AF3's stated maximum, /root/reference README.md:109)")
+
+    # KV-cache decode on the same replica: generate() from a 768-token prompt (9 + 750 <sound> + 9), B = 1 and B = 8;
+    # per-token time = (33 new tokens - 1 new token) / 32, i.e. the graph-replayed decode step incl. its one-time capture, against the
+    # weight-streaming roofline (every decoder weight + lm_head read once per token: 15.2 GB bf16 at 8 TB/s)
+    decode = None
+    if args.workload == "clip30" and full_model and not args.no_extra_legs and world == 1:
+        try:
+            decode = decode_leg(model, frontend, waves, ids, dev)
+        except Exception as e:
+            decode = {"error": repr(e)[:300]}
 
     if rank == 0:
         ms_per_step = 1000.0 * dt / args.steps
         samples_per_s = world * args.batch * args.steps / dt
         achieved_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic, traffic_detail = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_gemm_traffic.json")
-        if os.path.exists(tpath):  # PMC passes cannot run inside bench.py; the committed rocprofv3 --pmc result is quoted
+        # roofline.traffic: PMC passes cannot run inside bench.py, so the committed rocprofv3 --pmc result (tools/measure_gemm_traffic.py) is
+        # quoted - but ONLY when it was measured on THIS build of the kernels (afk_build_id stamp); a figure from other sources is refused
+        import glob
+
+        from audio_flamingo_amd import _lib as _afk_lib
+
+        build_id = _afk_lib.load().afk_build_id().decode()
+        traffic, traffic_detail = None, {"this_build": build_id, "note": "no PMC measurement of this build under profiles/ (python tools/measure_gemm_traffic.py)"}
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_traffic*.json")), reverse=True):
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic = tj["hbm_bytes_per_launch"]  # HBM bytes of ONE launch of the kernel on the shape below (largest GEMM of the step)
-            traffic_detail = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
-                              "shape": tj["shape"], "source": "profiles/r02_gemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
+            if tj.get("afk_build_id") == build_id:
+                traffic = tj["hbm_bytes_per_launch"]  # HBM bytes of ONE launch of the kernel on the shape below (largest GEMM of the step)
+                traffic_detail = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                                  "shape": tj["shape"], "afk_build_id": build_id, "l2_hit_rate": tj.get("l2_hit_rate"),
+                                  "source": os.path.relpath(tpath, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; stamped with the build it ran on)"}
+                break
+            traffic_detail.setdefault("stale", []).append({"file": os.path.relpath(tpath, ROOT), "measured_on_build": tj.get("afk_build_id", "unstamped (round 2)"),
+                                                            "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")})
         model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
         hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
         # lm_head + loss (forward, dgrad, wgrad) run only on the rows that carry a label: identical loss and gradients, fewer executed FLOPs.
@@ -598,7 +743,13 @@ def main():
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
-            "replicas_identical_after_steps": replicas_identical, "long_audio_configs4": long_audio,
+            "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb,
+            "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind, "form": engine.form if engine.native is not None else "allreduce",
+                                               "collectives_forced_at_world_1": bool(engine.force_collectives and world == 1),
+                                               "buckets": len(model.arena.bucket_names), "bucket_bytes_max": 2 * max(e - s_ for s_, e in model.arena._bucket_ranges),
+                                               "bucket_bytes_total": 2 * model.arena.total, "overlapped_with_backward": overlap is not None or engine.overlap,
+                                               "collectives_per_step": len(model.arena.bucket_names) + 1},
+            "long_audio_configs4": long_audio, "long_audio_10min": long_10min, "decode": decode,
             "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
             "host_enqueue_ms_idle_gpu": round(1000.0 * host_enqueue_idle, 1),
             "waited_for_free_hbm_s": waited,
@@ -615,18 +766,38 @@ def main():
                                   "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")
                                  + "; the gate|up launches carry the fused SwiGLU forward: its elementwise work counts as GEMM time, not as flops"},
         }
-        if not args.no_eager_baseline and world == 1 and args.workload == "clip30":
-            # the reference's own model on this GPU: free our replica first (the two do not fit side by side)
-            try:
-                feats_b = frontend(waves, out_dtype=torch.bfloat16)
-                model.arena.on_bucket_ready = None
-                loss = None
-                data.clear()
-                del model, opt, overlap, engine, step, run
-                import gc
+        want_eager = not args.no_eager_baseline and world == 1 and args.workload == "clip30"
+        want_icl = not args.no_extra_legs and world == 1 and args.workload == "clip30" and full_model
+        if want_eager or want_icl:
+            # both need the HBM of our replica (the ICL model: 4.3 B parameters + fp32 AdamW state; the reference model: 125 GiB): free it first
+            feats_b = frontend(waves, out_dtype=torch.bfloat16)
+            model.arena.on_bucket_ready = None
+            loss = None
+            data.clear()
+            pool.clear()
+            del model, opt, overlap, engine, step, run, long_leg
+            import gc
 
+            gc.collect()
+            torch.cuda.empty_cache()
+        if want_icl:
+            # BASELINE configs[3] (AF1/AF2-style ICL step) in the driver-visible line: builder-declared shapes, parity UNPINNED (no AF1/AF2 code
+            # exists in the mount: SURVEY.md §0) - see run_icl4
+            try:
+                torch.cuda.reset_peak_memory_stats(dev)
+                ia = argparse.Namespace(batch=WORKLOADS["icl4"]["batch"], dec_layers=28, warmup=2, steps=5)
+                r4 = run_icl4(ia, dev)
+                res["icl4_configs3"] = {k: r4[k] for k in ("metric", "value", "unit", "decoder_tokens_per_s", "ms_per_step", "steps", "warmup", "loss", "loss_first_step",
+                                                           "peak_mem_gib", "config")}
+                res["icl4_configs3"]["roofline_gemm_frac"] = r4["roofline"]["frac"]
+                res["icl4_configs3"]["parity"] = "UNPINNED (stand-in oracle: Idefics blocks; oracle/flamingo_oracle.py)"
                 gc.collect()
                 torch.cuda.empty_cache()
+            except Exception as e:
+                res["icl4_configs3"] = {"value": None, "error": repr(e)[:300]}
+        if want_eager:
+            # the reference's own model on this GPU
+            try:
                 torch.cuda.reset_peak_memory_stats(dev)
                 still = torch.cuda.memory_allocated(dev) / 2 ** 30
                 eb = eager_rocm_baseline(dev, feats_b, ids, labels, clip=args.clip)

@@ -231,3 +231,54 @@ def test_native_comm_single_rank(dev):
     torch.cuda.synchronize()
     assert f.tolist() == list(range(10))
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's own multi-rank paths
+_BENCH_TINY = ["--enc-layers", "1", "--dec-layers", "1", "--batch", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-eager-baseline",
+               "--no-long-audio", "--no-extra-legs", "--no-settle"]
+
+
+def _bench(extra, nproc=1, timeout=900):
+    import json
+
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + _BENCH_TINY + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_world1_rccl_path_eager_and_inside_hip_graph(dev):
+    """the RCCL path of the step on the ONE GPU of this box: --force-dp issues every collective of the multi-rank step (per-bucket sum
+    all-reduce on the side stream inside backward, the touched-flag MAX, device-gated AdamW) over a 1-rank RCCL communicator, where a sum is
+    the identity.  (i) eager: parameters after the run are BIT-IDENTICAL to the run without the engine; (ii) the same step captured into the
+    HIP graph WITH the RCCL launches inside (--dp-graph) is bit-identical to the graphed step without them - so N > 1 can replay a graph too."""
+    plain_eager = _bench(["--no-graph"])
+    dp_eager = _bench(["--no-graph", "--force-dp"])
+    assert dp_eager["rccl_ranks"] == 1 and dp_eager["dp"]["collectives_forced_at_world_1"] and dp_eager["dp"]["backend"] == "nccl", dp_eager["dp"]
+    assert dp_eager["step_enqueue"] == "eager_python" and dp_eager["replicas_identical_after_steps"] is True
+    assert dp_eager["param_checksum"] == plain_eager["param_checksum"] and dp_eager["loss"] == plain_eager["loss"], (dp_eager["param_checksum"], plain_eager["param_checksum"])
+    plain_graph = _bench([])
+    dp_graph = _bench(["--force-dp", "--dp-graph"])
+    assert plain_graph["step_enqueue"] == dp_graph["step_enqueue"] == "hip_graph_replay"
+    assert dp_graph["param_checksum"] == plain_graph["param_checksum"] and dp_graph["loss"] == plain_graph["loss"], (dp_graph["param_checksum"], plain_graph["param_checksum"])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    import json
+    with open(os.path.join(ROOT, "gpurun_out", "dp_world1_rccl_graph.json"), "w") as f:
+        json.dump({k: {"param_checksum": v["param_checksum"], "loss": v["loss"], "ms_per_step": v["ms_per_step"], "step_enqueue": v["step_enqueue"], "dp": v["dp"]}
+                   for k, v in (("plain_eager", plain_eager), ("dp_eager", dp_eager), ("plain_graph", plain_graph), ("dp_graph", dp_graph))}, f, indent=1)
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(dev):
+    """bench.py --gpus 2 through torch.distributed.run, both ranks on this box's one GPU, exchange staged over gloo: the REAL step (kernels,
+    BackwardOverlap, per-bucket exchange inside backward) under the N > 1 control flow - broadcast, different batches per rank, replica
+    checksum assertion, max-over-ranks timing, one JSON line from rank 0"""
+    d = _bench(["--backend", "gloo"], nproc=2)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["replicas_identical_after_steps"] is True and d["dp"]["backend"] == "gloo", d
+    assert len(d["rank_losses"]) == 2 and d["rank_losses"][0] != d["rank_losses"][1], d["rank_losses"]   # the ranks trained on different samples
+    assert d["config"]["global_batch"] == 4 and d["step_enqueue"] == "eager_python"

@@ -132,6 +132,7 @@ def _attn_ref(q, k, v, do, scale, causal):
 @pytest.mark.parametrize("B,S,Hq,Hkv,D,causal,samples", [
     (8, 1024, 28, 4, 128, True, (0, 5)),        # decoder, bench shape: GQA group 7, split-head sweep + gqa_reduce
     (1, 7774, 28, 4, 128, True, (0,)),          # long-audio decoder: ragged last tile, 61 query blocks heavy-first
+    (1, 15274, 28, 4, 128, True, (0,)),         # AF3's stated maximum: 10 min = 20 windows, 15 000 <sound> rows (/root/reference/README.md:109)
     (8, 1500, 20, 20, 64, False, (3,)),         # encoder, bench shape (S not a multiple of 64)
 ])
 def test_attention_values_at_af3_shapes(dev, B, S, Hq, Hkv, D, causal, samples):

@@ -310,3 +310,28 @@ def test_trainer_unwraps_accelerate_optimizer_wrappers():
     from accelerate.optimizer import AcceleratedOptimizer
 
     assert hasattr(AcceleratedOptimizer, "__init__") and "optimizer" in AcceleratedOptimizer.__init__.__code__.co_varnames
+
+
+def test_bench_multi_rank_control_flow_gloo():
+    """bench.py's N > 1 control flow, launched exactly as the driver launches it (python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 ... bench.py --gpus 2 ...), over gloo on the host with a stub in place of the
+    step (bench.py --dry-run-cpu): process group -> replica + parameter broadcast -> per-bucket all-reduces issued from the arena's ready
+    callbacks in backward order -> replica checksum all-gather -> exactly ONE JSON line, from rank 0, as the LAST line of the output"""
+    import json
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    jl = [ln for ln in lines if ln.startswith("{")]
+    assert len(jl) == 1 and lines[-1] == jl[0], lines[-5:]
+    d = json.loads(jl[0])
+    assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 2 and d["replicas_identical_after_steps"] is True
+    assert d["buckets"] == 8 and d["collectives_per_step"] == 9    # stem, enc0, enc1, enc_out, embed, dec0, dec1, head + the touched-flag MAX
