@@ -59,6 +59,10 @@ FUSE_SWIGLU_BWD = os.environ.get("AFK_FUSE_SWIGLU", "0") == "1"
 # waves hand their bf16 tile to the gate waves through the idle operand buffers, and silu(g) * u is stored beside g|u - bit-identical to
 # the separate silu_mul_fwd pass, whose 0.93 GB of HBM traffic per layer disappears.
 FUSE_SWIGLU_FWD = os.environ.get("AFK_FUSE_SWIGLU_FWD", "1") == "1"
+# GELU outputs (encoder fc1, projector linear_1, conv1) are KEPT for backward instead of being recomputed from the saved pre-activation by a
+# separate gelu_fwd pass (round 2): 123 MB per encoder layer at B = 8 (3.9 GB for the tower, of 288 GB) buys back 34 launches and
+# 1.6 ms per step; bit-identical (the same kernel produced the same values either way).  AFK_SAVE_GELU=0 restores the recompute.
+SAVE_GELU = os.environ.get("AFK_SAVE_GELU", "1") == "1"
 
 
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
@@ -129,19 +133,20 @@ class ConvStemFn(torch.autograd.Function):
         w2 = arena.shadow(k2w)
         pre2 = torch.empty((W * T2, E), device=feats.device, dtype=torch.bfloat16)
         x0 = ops.gemm_nt(col2, w2, bias=arena[k2b].data, gelu=True, preact_out=pre2, residual=pos, res_mod=T2)
-        ctx.save_for_backward(col1, pre1, pre2)
+        ctx.save_for_backward(col1, pre1, pre2, col2 if SAVE_GELU else None)   # col2 = im2col(gelu(pre1)): kept, or rebuilt in backward
         ctx.meta = (arena, keys, W, T, T2, E)
         return x0
 
     @staticmethod
     def backward(ctx, dx0):
-        col1, pre1, pre2 = ctx.saved_tensors
+        col1, pre1, pre2, col2 = ctx.saved_tensors
         arena, (k1w, k1b, k2w, k2b), W, T, T2, E = ctx.meta
         dx0 = dx0.contiguous()
         dpre2 = ops.gelu_bwd(dx0, pre2)
-        h1 = ops.gelu_fwd(pre1)
-        col2 = ops.im2col_conv2(h1, W, T, E)
-        del h1
+        if col2 is None:
+            h1 = ops.gelu_fwd(pre1)
+            col2 = ops.im2col_conv2(h1, W, T, E)
+            del h1
         dyt = ops.transpose(dpre2)
         xt = ops.transpose(col2)
         del col2
@@ -188,18 +193,19 @@ class EncoderLayerFn(torch.autograd.Function):
         pre = torch.empty((x.shape[0], A("fc1.weight").shape[0]), device=x.device, dtype=torch.bfloat16)
         f = ops.gemm_nt(h2, A("fc1.weight").data, bias=A("fc1.bias").data, gelu=True, preact_out=pre)
         x3 = ops.gemm_nt(f, A("fc2.weight").data, bias=A("fc2.bias").data, residual=x2)
-        ctx.save_for_backward(x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len)
+        ctx.save_for_backward(x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len, f if SAVE_GELU else None)
         ctx.meta = (arena, pfx, W, S, H, D)
         return x3
 
     @staticmethod
     def backward(ctx, dx3):
-        x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len = ctx.saved_tensors
+        x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len, f = ctx.saved_tensors
         arena, pfx, W, S, H, D = ctx.meta
         E = x.shape[1]
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
-        f = ops.gelu_fwd(pre)
+        if f is None:
+            f = ops.gelu_fwd(pre)
         df = linear_bwd(arena, dx3, f, pfx + "fc2.weight", bkey=pfx + "fc2.bias")
         del f
         dpre = ops.gelu_bwd(df, pre)
@@ -270,16 +276,17 @@ class ProjectorFn(torch.autograd.Function):
         pre = torch.empty((x.shape[0], A("linear_1.weight").shape[0]), device=x.device, dtype=torch.bfloat16)
         a = ops.gemm_nt(x, A("linear_1.weight").data, bias=A("linear_1.bias").data, gelu=True, preact_out=pre)
         y = ops.gemm_nt(a, A("linear_2.weight").data, bias=A("linear_2.bias").data)
-        ctx.save_for_backward(x, pre)
+        ctx.save_for_backward(x, pre, a if SAVE_GELU else None)
         ctx.meta = (arena, pfx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pre = ctx.saved_tensors
+        x, pre, a = ctx.saved_tensors
         arena, pfx = ctx.meta
         dy = dy.contiguous()
-        a = ops.gelu_fwd(pre)
+        if a is None:
+            a = ops.gelu_fwd(pre)
         da = linear_bwd(arena, dy, a, pfx + "linear_2.weight", bkey=pfx + "linear_2.bias")
         dpre = ops.gelu_bwd(da, pre)
         dx = linear_bwd(arena, dpre, x, pfx + "linear_1.weight", bkey=pfx + "linear_1.bias")
