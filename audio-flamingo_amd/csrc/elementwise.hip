@@ -539,6 +539,80 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
 }
 
 
+// AdamW on ONE 2-D weight [N, K] that also writes the K-major copy of the updated bf16 weight (the W^T shadow the dgrad GEMM reads,
+// arena.py): the optimizer already holds every new value in registers, so the shadow costs its 2 B/param of writes and nothing else -
+// the separate afk_transpose_bf16 pass per weight (2 B read + 2 B write per parameter, 15.4 GB of reads and ~245 launches per AF3-7B step)
+// disappears.  64x64 tiles: a row of a tile is 256 contiguous bytes of each fp32 state (8 lanes x 32 B) and 128 B of bf16 gradient /
+// parameter; the transposed tile goes through LDS exactly as in transpose_kernel (2-byte column writes into a +2-padded tile, 16-byte row
+// reads) and leaves as 128-byte rows of the shadow.  Same arithmetic, element for element, as adamw_kernel: parameters are bit-identical to
+// the unfused step and shadow == transpose(param) (tests/test_ops_gpu.py::test_adamw_fused_transposed_shadow).  N % 64 == 0 and K % 64 == 0.
+__global__ __launch_bounds__(256) void adamw_t_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
+                                                      const bf16* __restrict__ g, bf16* __restrict__ p, bf16* __restrict__ shadow, int N, int K,
+                                                      int64_t ld_shadow, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                      float bc2_sqrt, float grad_scale, const int* __restrict__ gate, const float* __restrict__ hyper) {
+    if (gate != nullptr && *gate == 0) return;
+    if (hyper != nullptr) {
+        lr = hyper[0];
+        bc1 = hyper[1];
+        bc2_sqrt = hyper[2];
+        grad_scale *= hyper[3];
+    }
+    __shared__ bf16 tile[64][66];  // tile[k][n]
+    const int t = threadIdx.x;
+    const int tiles_x = K >> 6;
+    const int64_t ntiles = (int64_t)tiles_x * (N >> 6);
+    for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+        const int n0 = (int)(tix / tiles_x) * 64, k0 = (int)(tix % tiles_x) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = t + 256 * j;
+            const int r = idx >> 3, ch = idx & 7;
+            const int64_t off = (int64_t)(n0 + r) * K + k0 + ch * 8;
+            f32x4 w[2], mm[2], vv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                w[h] = *(const f32x4*)(master + off + 4 * h);
+                mm[h] = *(const f32x4*)(m + off + 4 * h);
+                vv[h] = *(const f32x4*)(v + off + 4 * h);
+            }
+            const bf16x8 gg = *(const bf16x8*)(g + off);
+            bf16x8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gr = (float)gg[4 * h + e] * grad_scale;
+                    w[h][e] *= 1.f - lr * wd;
+                    mm[h][e] = b1 * mm[h][e] + (1.f - b1) * gr;
+                    vv[h][e] = b2 * vv[h][e] + (1.f - b2) * gr * gr;
+                    const float denom = sqrtf(vv[h][e]) / bc2_sqrt + eps;
+                    w[h][e] -= (lr / bc1) * (mm[h][e] / denom);
+                    o[4 * h + e] = (bf16)w[h][e];
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *(f32x4*)(master + off + 4 * h) = w[h];
+                *(f32x4*)(m + off + 4 * h) = mm[h];
+                *(f32x4*)(v + off + 4 * h) = vv[h];
+            }
+            *(bf16x8*)(p + off) = o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tile[ch * 8 + e][r] = o[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = t + 256 * j;
+            const int c = idx >> 3, ch = idx & 7;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = tile[c][ch * 8 + e];
+            *(bf16x8*)(shadow + (int64_t)(k0 + c) * ld_shadow + n0 + ch * 8) = o;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ Flamingo glue (BASELINE config 4; stand-in oracle: Idefics)
 // ReLU (IdeficsMLP of the Perceiver resampler, perceiver.py:171-187)
 __global__ __launch_bounds__(256) void relu_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t nvec) {
@@ -875,6 +949,27 @@ extern "C" int afk_adamw_step(float* master, float* m, float* v, const void* gra
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad,
                        (bf16*)param, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gate, hyper);
     AFK_LAUNCH_CHECK("afk_adamw_step");
+    return AFK_OK;
+}
+
+
+// AdamW on one 2-D weight [N, K] (row-major views of the arena) that also writes its K-major copy `shadow` [K, ld_shadow] (ld_shadow >= N)
+extern "C" int afk_adamw_step_t(float* master, float* m, float* v, const void* grad, void* param, void* shadow, int N, int K, int64_t ld_shadow,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks,
+                                const int* gate, const float* hyper, void* stream) {
+    AFK_REQUIRE(master && m && v && grad && param && shadow && step >= 1, "afk_adamw_step_t: bad args");
+    AFK_REQUIRE(N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0 && ld_shadow >= N && ld_shadow % 8 == 0, "afk_adamw_step_t: N=%d, K=%d must be multiples of 64", N, K);
+    AFK_REQUIRE(((uintptr_t)master % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0) && ((uintptr_t)grad % 16 == 0) &&
+                    ((uintptr_t)param % 16 == 0) && ((uintptr_t)shadow % 16 == 0),
+                "afk_adamw_step_t: misaligned buffer");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    int64_t grid = (int64_t)(N / 64) * (K / 64);
+    if (grid > 16384) grid = 16384;
+    if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+    hipLaunchKernelGGL(adamw_t_kernel, dim3((unsigned)grid), dim3(256), 0, ST, master, m, v, (const bf16*)grad, (bf16*)param, (bf16*)shadow, N, K,
+                       ld_shadow, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale, gate, hyper);
+    AFK_LAUNCH_CHECK("afk_adamw_step_t");
     return AFK_OK;
 }
 

@@ -165,7 +165,13 @@ def cpu_baseline(budget_s=25.0):
         del model
     scale = (31 * fe + 27 * fd) / (fe + fd)
     full = {k: times[(1, k)] + max(times[(2, k)] - times[(1, k)], 0.0) * scale for k in ("fp32", "bf16")}
+    cfg1 = None
+    try:
+        cfg1 = config1_generate_cpu()
+    except Exception as e:
+        cfg1 = {"error": repr(e)[:200]}
     return {
+        "config1_generate": cfg1,
         "value": CLIP_SECONDS / full["bf16"], "unit": "audio-s/s", "cores": threads, "kind": "reference",
         "decoder_tokens_per_s": S_TOK / full["bf16"], "dtype": "bf16",
         "fp32": {"value": CLIP_SECONDS / full["fp32"], "decoder_tokens_per_s": S_TOK / full["fp32"], "s_per_sample_extrapolated": round(full["fp32"], 2)},
@@ -176,6 +182,34 @@ def cpu_baseline(budget_s=25.0):
                    f"T(1,1)={times[(1, 'fp32')]:.2f}s; EXTRAPOLATED linearly in layer count (FLOP-weighted enc/dec split) to 32+28 layers: "
                    f"{full['bf16']:.1f}s (bf16) / {full['fp32']:.1f}s (fp32) per sample, no optimizer step"),
     }
+
+
+def config1_generate_cpu():
+    """SURVEY.md §8(d) CPU protocol step (1) = BASELINE configs[0]: the reference's end-to-end generate() on the host - 1 x 5 s synthetic wav, batch 1,
+    PyTorch CPU eager, the tiny preset of SURVEY Appendix B-1 (plumbing: feature extractor -> encoder -> projector -> <sound> scatter -> decoder with
+    KV cache -> greedy ids).  1 warm-up + 3 timed calls of feature extraction + generate(max_new_tokens=16)."""
+    from transformers import AudioFlamingo3Config, AudioFlamingo3ForConditionalGeneration, WhisperFeatureExtractor
+
+    torch.manual_seed(0)
+    cfg = AudioFlamingo3Config(audio_config=dict(num_mel_bins=128, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128, hidden_size=64,
+                                                 max_source_positions=1500),
+                               text_config=dict(vocab_size=1000, hidden_size=96, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                                                num_key_value_heads=2, max_position_embeddings=4096), audio_token_id=999)
+    model = AudioFlamingo3ForConditionalGeneration(cfg).eval()
+    wav = np.random.default_rng(0).standard_normal(80000).astype(np.float32) * 0.1
+    fe = WhisperFeatureExtractor(feature_size=128)
+    ids = torch.tensor([[1, 2, 3] + [999] * 125 + [4, 5, 6, 7]])
+    ts, new = [], 16
+    for it in range(4):
+        t0 = time.perf_counter()
+        f = fe(wav, sampling_rate=16000, return_attention_mask=True, padding="max_length", return_tensors="pt")
+        with torch.no_grad():
+            out = model.generate(input_ids=ids, input_features=f["input_features"], input_features_mask=f["attention_mask"], max_new_tokens=new, do_sample=False)
+        if it > 0:
+            ts.append(time.perf_counter() - t0)
+    t = sum(ts) / len(ts)
+    return {"what": "BASELINE configs[0]: reference AF3 generate(), 1 x 5 s synthetic wav, batch 1, PyTorch CPU eager, tiny preset (SURVEY Appendix B-1): plumbing only",
+            "seconds_per_call": t, "new_tokens": int(out.shape[1] - ids.shape[1]), "audio_s_per_s": 5.0 / t, "new_tokens_per_s": new / t, "timed_calls": len(ts)}
 
 
 def eager_rocm_baseline(dev, feats, ids, labels, steps=3, clip=0.0):

@@ -280,6 +280,12 @@ int afk_logmel(const float* wav, int W, int64_t nsamp, const float* cosb, const 
 int afk_adamw_step(float* master, float* m, float* v, const void* grad, void* param, int64_t n, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, const int* gate,
                    const float* hyper, void* stream);
+/* the same update on ONE 2-D weight [N, K] (N, K multiples of 64) that also writes the K-major copy of the new bf16 weight, shadow [K, ld_shadow]:
+ * the W^T operand of the dgrad GEMM comes out of the optimizer instead of a separate afk_transpose_bf16 pass; parameters bit-identical to
+ * afk_adamw_step, shadow == transpose(param). */
+int afk_adamw_step_t(float* master, float* m, float* v, const void* grad, void* param, void* shadow, int N, int K, int64_t ld_shadow, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, int max_blocks, const int* gate,
+                     const float* hyper, void* stream);
 int afk_set_f32(float* dst, int n, float a, float b, float c, float d, void* stream);
 /* global-norm gradient clipping (torch.nn.utils.clip_grad_norm_, TORCH/nn/utils/clip_grad.py; HF Trainer default max_grad_norm = 1.0,
  * TF/trainer.py): acc[0] += sum of squares of a bf16 range (skipped when *gate == 0; gate may be NULL), deterministic two-stage fold;

@@ -243,6 +243,14 @@ def main_smooth(out_dir=OUT):
     torch.set_num_threads(1)
     os.makedirs(out_dir, exist_ok=True)
     cfg, model = build(seed=SMOOTH_SEED)
+    with torch.no_grad():
+        # With N(0, 0.02) projections the ENCODER's attention logits have a standard deviation of 0.05: every softmax row is uniform to three
+        # digits and the q / k gradients of its last layer vanish to the size of bf16 rounding noise (|g| 4e-4 against 1e-2 elsewhere; the
+        # reference's own bf16 run is 18 % off on them, measured).  A golden for the BACKWARD needs attention that attends: the encoder's q and k
+        # projections are scaled by 4 (logit std ~ 0.8), everything else stays as initialised.
+        for n, p in model.named_parameters():
+            if "audio_tower" in n and (n.endswith("q_proj.weight") or n.endswith("k_proj.weight")):
+                p.mul_(4.0)
     round_bf16_(model)
     torch.save({k: v.to(torch.bfloat16) for k, v in model.state_dict().items()}, os.path.join(out_dir, "tiny64_smooth_state_bf16.pt"))
     model.train()  # dropout 0 everywhere: train() == eval() numerically; the backward is what is stored

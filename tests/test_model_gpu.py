@@ -225,8 +225,9 @@ def _distribution_assert(dist):
         if is_grad and min(f) > NOISE_DOMINATED:
             row["note"] = "noise-dominated at bf16 on this golden; pinned by cases D/E"
             continue
-        cap = GRAD_CAP if is_grad else float("inf")
-        if median(o) > min(cap, max(ab, FLOOR_FACTOR * median(f))) or max(o) > min(2 * cap, max(ab, FLOOR_FACTOR * max(f))):
+        row["ours_median_over_floor_median"] = median(o) / max(median(f), 1e-12)
+        cap = GRAD_CAP if is_grad else float("inf")   # caps the MEDIAN bar only: the worst batch of a heavy-tailed statistic is held to the reference's worst batch
+        if median(o) > min(cap, max(ab, FLOOR_FACTOR * median(f))) or max(o) > max(ab, FLOOR_FACTOR * max(f)):
             bad[name] = row
     assert not bad, bad
     assert all(o["argmax_mismatch_confident"] == 0 for o in dist["ours"]), [o["argmax_mismatch_confident"] for o in dist["ours"]]
