@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -190,17 +192,25 @@ class Arena:
     def _version_of(self, b: Block) -> int:
         return self.params._version * 1000003 + self.step_counter
 
-    def refresh_bucket_shadows(self, i: int):
-        for b in self.order:
-            if b.bucket == i and b.shadow_kind is not None and not (self.lazy_T_shadows and b.shadow_kind == "T"):
+    def refresh_bucket_shadows(self, i: int, skip=None):
+        """skip: blocks whose shadow the optimizer launch itself just wrote (FusedAdamW with FUSE_SHADOW)"""
+        for b in self._bucket_blocks[i]:
+            if b.shadow_kind is not None and not (self.lazy_T_shadows and b.shadow_kind == "T") and not (skip is not None and b.key in skip):
                 self._refresh_one(b)
 
-    def refresh_shadows(self, force: bool = True):
+    def refresh_shadows(self, force: bool = True, skip=None):
         for b in self.order:
-            if self.lazy_T_shadows and b.shadow_kind == "T":
+            if (self.lazy_T_shadows and b.shadow_kind == "T") or (skip is not None and b.key in skip):
                 continue
             if b.shadow_kind is not None and (force or b.shadow_version != self._version_of(b)):
                 self._refresh_one(b)
+
+    def ensure_T_shadow(self, b: Block) -> torch.Tensor:
+        """the [K, pad64(N)] buffer of a "T" block (allocated on first use; contents are whatever was last written)"""
+        if b.shadow is None:
+            n, k = b.shape[0], b.numel // b.shape[0]
+            b.shadow = torch.zeros((k, ops.pad64(n)), device=self.device, dtype=torch.bfloat16)
+        return b.shadow
 
     def shadow(self, key: str) -> torch.Tensor:
         b = self.blocks[key]
@@ -244,26 +254,66 @@ class FusedAdamW:
             self._sumsq = torch.zeros(len(arena.bucket_names), device=arena.device, dtype=torch.float32)  # one slot per gradient bucket
             self.grad_norm = torch.zeros(1, device=arena.device, dtype=torch.float32)  # norm of the last clipped step (device scalar)
             self._sumsq_ws = torch.empty(ops.sumsq_workspace_floats(), device=arena.device, dtype=torch.float32)
-        # contiguous segments sharing a decay setting
-        self.segments = []
-        for b in arena.order:
-            end = b.offset + (b.numel + ALIGN - 1) // ALIGN * ALIGN
-            wd = weight_decay if b.decay else 0.0
-            if self.segments and self.segments[-1][2] == wd and self.segments[-1][1] == b.offset:
-                self.segments[-1][1] = end
-            else:
-                self.segments.append([b.offset, end, wd])
+        # OPTIONAL, OFF by default: the W^T shadow of a 2-D GEMM weight (the dgrad operand) written by the optimizer launch itself
+        # (afk_adamw_step_t) instead of a transpose pass per weight - 15.4 GB fewer reads and ~245 fewer launches per AF3-7B step on paper.
+        # Built, bit-identical (tests/test_model_gpu.py::test_adamw_fused_transposed_shadow) and MEASURED SLOWER on the full step, same box:
+        # 440-442 vs 429-431 ms with thin launches of 256 blocks, 429 with 512, 434 vs 426 ms on the serial schedule - the 64 x 64-tiled
+        # launch (two barriers and an LDS transpose per tile, 128-byte bf16 row segments, <= 64 VGPRs so that it fits beside the GEMM waves)
+        # streams the 28 B/param of optimizer state slower than the flat kernel by more than the transposes cost.  AFK_ADAMW_FUSE_SHADOW=1 enables it.
+        self.fuse_shadow = os.environ.get("AFK_ADAMW_FUSE_SHADOW", "0") == "1" and arena.device.type == "cuda"
+        # launch plans: ("flat", start, end, wd) = contiguous run of blocks sharing a decay setting; ("T", block, wd) = one fused weight.
+        # Built on first use and rebuilt when the arena's shadow policy changes (bench.py sets lazy_T_shadows after constructing the optimizer)
+        self._plan_key = None
 
-        # per-bucket segments (for optimizer-in-backward overlap)
-        self.bucket_segments = [[] for _ in arena.bucket_names]
-        for blk in arena.order:
-            end = blk.offset + (blk.numel + ALIGN - 1) // ALIGN * ALIGN
-            wd = weight_decay if blk.decay else 0.0
-            segs = self.bucket_segments[blk.bucket]
-            if segs and segs[-1][2] == wd and segs[-1][1] == blk.offset:
-                segs[-1][1] = end
+    @property
+    def segments(self):
+        self._ensure_plans()
+        return self._segments
+
+    @property
+    def bucket_segments(self):
+        self._ensure_plans()
+        return self._bucket_segments
+
+    def _ensure_plans(self):
+        key = (self.fuse_shadow, self.arena.lazy_T_shadows, self.weight_decay)
+        if key != self._plan_key:
+            a = self.arena
+            self._segments = self._plan(a.order)
+            self._bucket_segments = [self._plan(a.bucket_blocks(i)) for i in range(len(a.bucket_names))]
+            self._plan_key = key
+
+    def _fusable(self, b) -> bool:
+        return (self.fuse_shadow and b.shadow_kind == "T" and not self.arena.lazy_T_shadows and len(b.shape) == 2 and b.shape[0] % 64 == 0
+                and b.shape[1] % 64 == 0 and b.offset % 8 == 0)
+
+    def _plan(self, blocks):
+        plan = []
+        for b in blocks:
+            end = b.offset + (b.numel + ALIGN - 1) // ALIGN * ALIGN
+            wd = self.weight_decay if b.decay else 0.0
+            if self._fusable(b):
+                plan.append(["T", b, wd])
+            elif plan and plan[-1][0] == "flat" and plan[-1][3] == wd and plan[-1][2] == b.offset:
+                plan[-1][2] = end
             else:
-                segs.append([blk.offset, end, wd])
+                plan.append(["flat", b.offset, end, wd])
+        return plan
+
+    def _fused_keys(self, plan):
+        return {op[1].key for op in plan if op[0] == "T"}
+
+    def _exec(self, plan, grad_scale, max_blocks=0, gate=None):
+        a = self.arena
+        for op in plan:
+            if op[0] == "flat":
+                self._launch(op[1], op[2], op[3], grad_scale, max_blocks, gate)
+            else:
+                b, wd = op[1], op[2]
+                s, e = b.offset, b.offset + b.numel
+                ops.adamw_step_t(self.master[s:e], self.m[s:e], self.v[s:e], a.grads[s:e], a.params[s:e], a.ensure_T_shadow(b), b.shape[0], b.shape[1],
+                                 lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t, grad_scale=grad_scale,
+                                 max_blocks=max_blocks, gate=gate, hyper=self.hyper)
 
     def _launch(self, s, e, wd, grad_scale, max_blocks=0, gate=None):
         a = self.arena
@@ -330,12 +380,9 @@ class FusedAdamW:
     def step_bucket(self, i: int, grad_scale: float = 1.0, max_blocks: int = 0, gate=None, written_only: bool = False):
         """AdamW on bucket i.  gate: device int32 - the launches do nothing when it reads 0 (data parallel: "did ANY rank touch this
         bucket", known only on the device).  written_only: cover just the blocks written since zero_grad() (torch skips ``grad is None``)."""
-        if written_only:
-            segs = self._runs([b for b in self.arena.bucket_blocks(i) if not b.fresh])
-        else:
-            segs = self.bucket_segments[i]
-        for s, e, wd in segs:
-            self._launch(s, e, wd, grad_scale, max_blocks, gate)
+        plan = self._plan([b for b in self.arena.bucket_blocks(i) if not b.fresh]) if written_only else self.bucket_segments[i]
+        self._exec(plan, grad_scale, max_blocks, gate)
+        return self._fused_keys(plan)
 
     def end_step(self):
         self.arena.step_counter += 1
@@ -357,18 +404,21 @@ class FusedAdamW:
             for i in range(len(a.bucket_names)):
                 self.add_sumsq(i, gate=gates[i:i + 1] if gates is not None else None, written_only=gates is None)
             self.set_clip_coef(grad_scale)
+        fused = set()
         if gates is not None:
             for i in range(len(a.bucket_names)):
-                for s, e, wd in self.bucket_segments[i]:
-                    self._launch(s, e, wd, grad_scale, gate=gates[i:i + 1])
+                self._exec(self.bucket_segments[i], grad_scale, gate=gates[i:i + 1])
+                fused |= self._fused_keys(self.bucket_segments[i])
         else:
-            segs = self.segments if all(not b.fresh for b in a.order) else self._runs([b for b in a.order if not b.fresh])
-            for s, e, wd in segs:
-                self._launch(s, e, wd, grad_scale)
+            plan = self.segments if all(not b.fresh for b in a.order) else self._plan([b for b in a.order if not b.fresh])
+            self._exec(plan, grad_scale)
+            fused = self._fused_keys(plan)
         a.step_counter += 1
         self._mark_synced()
         if refresh_shadows:
-            a.refresh_shadows(force=True)
+            a.refresh_shadows(force=True, skip=fused)
+            for k in fused:  # written by the optimizer launch itself
+                a.blocks[k].shadow_version = a._version_of(a.blocks[k])
 
     def zero_grad(self):
         self.arena.zero_grad()

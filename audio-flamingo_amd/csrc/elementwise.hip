@@ -489,6 +489,20 @@ __global__ __launch_bounds__(256) void embed_scatter_bwd_kernel(const int64_t* _
     }
 }
 
+// One AdamW element update, shared by adamw_kernel and adamw_t_kernel.  Floating-point contraction is switched OFF inside: left to the
+// optimiser, the two kernels fused different mul/add pairs into FMAs and their parameters differed in the last bit (measured) - the flat and
+// the transposed-shadow launch of the same step must be interchangeable bit for bit.
+__device__ __forceinline__ float adamw_elem(float& w, float& mm, float& vv, float gr, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                            float bc2_sqrt) {
+#pragma clang fp contract(off)
+    w = w * (1.f - lr * wd);
+    mm = b1 * mm + (1.f - b1) * gr;
+    vv = b2 * vv + ((1.f - b2) * gr) * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    w = w - (lr / bc1) * (mm / denom);
+    return w;
+}
+
 // ------------------------------------------------------------------ AdamW (bf16 param + fp32 master/m/v)
 // torch.optim.AdamW semantics: p *= 1-lr*wd; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).  grad_scale multiplies g (DP averaging / loss scaling).
@@ -510,13 +524,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float gr = (float)gg[e] * grad_scale;
-            w[e] *= 1.f - lr * wd;
-            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
-            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
-            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
-            w[e] -= (lr / bc1) * (mm[e] / denom);
-            o[e] = (bf16)w[e];
+            float we = w[e], me = mm[e], ve = vv[e];
+            o[e] = (bf16)adamw_elem(we, me, ve, (float)gg[e] * grad_scale, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+            w[e] = we, mm[e] = me, vv[e] = ve;
         }
         *(f32x4*)(master + 4 * i) = w;
         *(f32x4*)(m + 4 * i) = mm;
@@ -526,11 +536,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
     // tail (n % 4)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (nv << 2) + threadIdx.x;
-        const float gr = (float)g[i] * grad_scale;
-        float w = master[i] * (1.f - lr * wd);
-        const float mm = b1 * m[i] + (1.f - b1) * gr;
-        const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
-        w -= (lr / bc1) * (mm / (sqrtf(vv) / bc2_sqrt + eps));
+        float w = master[i], mm = m[i], vv = v[i];
+        adamw_elem(w, mm, vv, (float)g[i] * grad_scale, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
         master[i] = w;
         m[i] = mm;
         v[i] = vv;
@@ -546,6 +553,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
 // parameter; the transposed tile goes through LDS exactly as in transpose_kernel (2-byte column writes into a +2-padded tile, 16-byte row
 // reads) and leaves as 128-byte rows of the shadow.  Same arithmetic, element for element, as adamw_kernel: parameters are bit-identical to
 // the unfused step and shadow == transpose(param) (tests/test_ops_gpu.py::test_adamw_fused_transposed_shadow).  N % 64 == 0 and K % 64 == 0.
+// <= 64 VGPRs (8 waves/SIMD): a thin launch of this kernel must fit beside the two 224-VGPR waves a GEMM workgroup keeps on every SIMD (the first
+// build needed 72 and could not co-reside: +17 ms per step, measured)
 __global__ __launch_bounds__(256) void adamw_t_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                       const bf16* __restrict__ g, bf16* __restrict__ p, bf16* __restrict__ shadow, int N, int K,
                                                       int64_t ld_shadow, float lr, float b1, float b2, float eps, float wd, float bc1,
@@ -563,41 +572,26 @@ __global__ __launch_bounds__(256) void adamw_t_kernel(float* __restrict__ master
     const int64_t ntiles = (int64_t)tiles_x * (N >> 6);
     for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
         const int n0 = (int)(tix / tiles_x) * 64, k0 = (int)(tix % tiles_x) * 64;
+        // 16 lanes x 4 elements per row, 16 rows per pass, 4 passes: the same 4-element granularity (and register footprint) as adamw_kernel
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int r = (t >> 4) + 16 * j, c4 = (t & 15) * 4;
+            const int64_t off = (int64_t)(n0 + r) * K + k0 + c4;
+            f32x4 w = *(const f32x4*)(master + off), mm = *(const f32x4*)(m + off), vv = *(const f32x4*)(v + off);
+            const bf16x4 gg = *(const bf16x4*)(g + off);
+            bf16x4 o;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = t + 256 * j;
-            const int r = idx >> 3, ch = idx & 7;
-            const int64_t off = (int64_t)(n0 + r) * K + k0 + ch * 8;
-            f32x4 w[2], mm[2], vv[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                w[h] = *(const f32x4*)(master + off + 4 * h);
-                mm[h] = *(const f32x4*)(m + off + 4 * h);
-                vv[h] = *(const f32x4*)(v + off + 4 * h);
+            for (int e = 0; e < 4; ++e) {
+                float we = w[e], me = mm[e], ve = vv[e];
+                o[e] = (bf16)adamw_elem(we, me, ve, (float)gg[e] * grad_scale, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+                w[e] = we, mm[e] = me, vv[e] = ve;
             }
-            const bf16x8 gg = *(const bf16x8*)(g + off);
-            bf16x8 o;
+            *(f32x4*)(master + off) = w;
+            *(f32x4*)(m + off) = mm;
+            *(f32x4*)(v + off) = vv;
+            *(bf16x4*)(p + off) = o;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gr = (float)gg[4 * h + e] * grad_scale;
-                    w[h][e] *= 1.f - lr * wd;
-                    mm[h][e] = b1 * mm[h][e] + (1.f - b1) * gr;
-                    vv[h][e] = b2 * vv[h][e] + (1.f - b2) * gr * gr;
-                    const float denom = sqrtf(vv[h][e]) / bc2_sqrt + eps;
-                    w[h][e] -= (lr / bc1) * (mm[h][e] / denom);
-                    o[4 * h + e] = (bf16)w[h][e];
-                }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *(f32x4*)(master + off + 4 * h) = w[h];
-                *(f32x4*)(m + off + 4 * h) = mm[h];
-                *(f32x4*)(v + off + 4 * h) = vv[h];
-            }
-            *(bf16x8*)(p + off) = o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tile[ch * 8 + e][r] = o[e];
+            for (int e = 0; e < 4; ++e) tile[c4 + e][r] = o[e];
         }
         __syncthreads();
 #pragma unroll

@@ -333,8 +333,8 @@ class BackwardOverlap:
             self.opt.add_sumsq(i, gate=gate, written_only=written_only)
             self._clip_pending.append((i, gate, written_only))
             return
-        self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
-        self.arena.refresh_bucket_shadows(i)
+        fused = self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
+        self.arena.refresh_bucket_shadows(i, skip=fused)   # W^T shadows the optimizer launch wrote itself are skipped
 
     def _flush_clipped(self):
         if not self._clip_pending:
@@ -342,8 +342,8 @@ class BackwardOverlap:
         with torch.cuda.stream(self.side):
             self.opt.set_clip_coef(self.grad_scale)
             for i, gate, written_only in self._clip_pending:
-                self.opt.step_bucket(i, self.grad_scale, 0, gate=gate, written_only=written_only)  # backward is over: full-width launches
-                self.arena.refresh_bucket_shadows(i)
+                fused = self.opt.step_bucket(i, self.grad_scale, 0, gate=gate, written_only=written_only)  # backward is over: full-width launches
+                self.arena.refresh_bucket_shadows(i, skip=fused)
         self._clip_pending = []
 
     def finish(self):

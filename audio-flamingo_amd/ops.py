@@ -613,6 +613,13 @@ def adamw_step(master, m, v, grad, param, *, lr, beta1, beta2, eps, weight_decay
               int(max_blocks), _p(gate), _p(hyper), _stream())
 
 
+def adamw_step_t(master, m, v, grad, param, shadow, N, K, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_blocks=0, gate=None, hyper=None):
+    """afk_adamw_step on one 2-D weight [N, K] (flat views of the arena) that also writes shadow [K, ld] = the K-major copy of the updated weight"""
+    _lib.call("afk_adamw_step_t", master.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), param.data_ptr(), shadow.data_ptr(), int(N), int(K),
+              shadow.stride(0), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), int(max_blocks),
+              _p(gate), _p(hyper), _stream())
+
+
 def sumsq_workspace_floats() -> int:
     return int(_lib.load().afk_sumsq_workspace_floats())
 

@@ -916,3 +916,53 @@ def test_logits_are_returned_with_labels_and_trainer_evaluate_works(dev, tmp_pat
     res = AfkTrainer(model=m, args=args, eval_dataset=rows, compute_metrics=metrics).evaluate()
     assert seen["shape"] == (4, g["ids"].shape[1], 1024), seen
     assert abs(res["eval_loss"] - float(g["loss"])) <= 2e-2 and res["eval_acc"] >= 0.9, res   # the trained tiny model predicts its chain language
+
+
+def test_adamw_fused_transposed_shadow(dev):
+    """the optimizer launch of a 2-D GEMM weight writes its W^T shadow itself (afk_adamw_step_t): parameters, fp32 master and moments are
+    BIT-IDENTICAL to the unfused step (flat AdamW launch + one transpose pass per weight), every shadow equals the transpose of the updated
+    weight, in the plain step, in the overlapped per-bucket schedule (thin launches on the side stream) and under a closed DP gate"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import BackwardOverlap
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    models, opts = [], []
+    for fuse in (False, True, True):
+        m = _fresh_model(dev, seed=3)
+        o = FusedAdamW(m.arena, lr=2e-3, weight_decay=0.01)
+        o.fuse_shadow = fuse
+        models.append(m), opts.append(o)
+    assert any(op[0] == "T" for op in opts[1].segments) and not any(op[0] == "T" for op in opts[0].segments)
+    models[2].arena.enable_wgrad_stream(True)
+    ov = BackwardOverlap(models[2].arena, opts[2])
+    for step in range(2):
+        for i, (m, o) in enumerate(zip(models, opts)):
+            m.zero_grad()
+            if i == 2:
+                ov.begin_step()
+            m(**kw).loss.backward()
+            if i == 2:
+                ov.finish()
+            else:
+                o.step()
+        torch.cuda.synchronize()
+        for m, o in zip(models[1:], opts[1:]):
+            assert torch.equal(m.arena.params, models[0].arena.params), "fused AdamW changed the parameters"
+            assert torch.equal(o.master, opts[0].master) and torch.equal(o.m, opts[0].m) and torch.equal(o.v, opts[0].v)
+            n_t = 0
+            for b in m.arena.order:
+                if b.shadow_kind == "T":
+                    assert b.shadow_version == m.arena._version_of(b), b.key   # not re-transposed lazily later
+                    w2 = b.data.reshape(b.shape[0], -1)
+                    assert torch.equal(b.shadow[:, : w2.shape[0]], w2.t()), b.key
+                    n_t += 1
+            assert n_t >= 10
+    # closed gate: the launch leaves parameter, state and shadow alone
+    m, o = models[1], opts[1]
+    before, sh = m.arena.params.clone(), {b.key: b.shadow.clone() for b in m.arena.order if b.shadow_kind == "T"}
+    m.zero_grad()
+    m(**kw).loss.backward()
+    o.step(gates=torch.zeros(len(m.arena.bucket_names), device=dev, dtype=torch.int32))
+    torch.cuda.synchronize()
+    assert torch.equal(m.arena.params, before) and all(torch.equal(m.arena.blocks[k].shadow, v) for k, v in sh.items())
