@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
 // the epilogues of the AF3 training step get their own instantiation; anything else (SwiGLU backward, fp32 output, narrow stores) the generic one
 #define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_BIAS) X(AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_GELU) \
-    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(AFK_GEMM_SWIGLU_FWD) X(-1)
+    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(AFK_GEMM_SWIGLU_FWD) X(AFK_GEMM_SWIGLU_BWD) X(-1)
 
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;

@@ -737,6 +737,86 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
+        st["nxt"].copy_(self._select_token(self._decode_logits(st), st.get("sampling")))
+        st["cur"].add_(1)
+
+    @torch.no_grad()
+    def _beam_search(self, ids, last_hidden, cache, lo, nb, max_new, eos_token_id, pad_token_id, length_penalty, early_stopping):
+        """Beam search on the KV cache with GenerationMixin's scoring (transformers/generation/utils.py:3008-3400): every batch row keeps `nb`
+        running beams ranked by accumulated log-probability; at each step the best (n_eos + 1) * nb continuations over all beams are drawn, the
+        ones among the top nb that end (EOS, or the length limit) compete for the row's nb FINISHED slots with score = sum / generated_length ^
+        length_penalty, the best nb that do not end continue.  The loop stops when no running beam can still beat the worst finished one
+        (the reference's heuristic: best running sum / current generated length ^ length_penalty; early_stopping = True: as soon as every
+        finished slot is filled; "never": the optimistic bound at the maximum length when length_penalty > 0) or the length limit is reached.
+        The KV cache is reordered by beam parentage every step (index_select over its batch dimension).  Returns the best finished hypothesis
+        per row, padded with pad_token_id (eos if none)."""
+        dev = self.device_
+        B, S0 = ids.shape
+        Kc, Vt = cache
+        V = self.V
+        eos = [] if eos_token_id is None else ([int(e) for e in eos_token_id] if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
+        keep = (len(eos) + 1) * nb
+        rep = torch.arange(B, device=dev).repeat_interleave(nb)
+        Kc, Vt = Kc.index_select(1, rep).contiguous(), Vt.index_select(1, rep).contiguous()
+        st = {"cache": (Kc, Vt), "lo": lo.index_select(0, rep).contiguous(), "head": self.arena["lm_head.weight"].data,
+              "emb": self.arena[self._lm + "embed_tokens.weight"].data, "cur": torch.full((1,), S0, device=dev, dtype=torch.int32),
+              "nxt": torch.zeros(B * nb, device=dev, dtype=torch.int64)}
+        run_seq = torch.zeros((B, nb, max_new), device=dev, dtype=torch.int64)
+        run_score = torch.full((B, nb), -1.0e9, device=dev, dtype=torch.float32)
+        run_score[:, 0] = 0.0                                           # all beams of a row start identical: only the first one is live
+        fin_seq = torch.zeros((B, nb, max_new), device=dev, dtype=torch.int64)
+        fin_len = torch.zeros((B, nb), device=dev, dtype=torch.int64)
+        fin_score = torch.full((B, nb), -1.0e9, device=dev, dtype=torch.float32)
+        fin_done = torch.zeros((B, nb), device=dev, dtype=torch.bool)
+        logits = ops.gemm_nt(last_hidden, st["head"]).float().index_select(0, rep)      # next-token logits after the prompt, one copy per beam
+        top_mask = torch.arange(keep, device=dev) < nb
+        boff = (torch.arange(B, device=dev) * nb)[:, None]
+        can_improve = torch.ones((B, 1), device=dev, dtype=torch.bool)
+        for t in range(max_new):
+            logp = torch.log_softmax(logits, dim=-1).view(B, nb, V) + run_score[:, :, None]
+            cand_score, cand = logp.view(B, nb * V).topk(keep, dim=-1)
+            parent, tok = cand // V, cand % V
+            cand_seq = run_seq.gather(1, parent[:, :, None].expand(B, keep, max_new)).clone()
+            cand_seq[:, :, t] = tok
+            ends = torch.zeros_like(tok, dtype=torch.bool)
+            for e in eos:
+                ends |= tok == e
+            if t + 1 == max_new:
+                ends[:] = True                                            # the length limit finishes whatever is left
+            # finished slots: candidates among the top nb that end, scored sum / generated_length ^ length_penalty
+            fscore = cand_score / float((t + 1) ** length_penalty)
+            full = fin_done.all(-1, keepdim=True) & (early_stopping is True)
+            fscore = fscore + (full | ~can_improve | ~(ends & top_mask[None])).float() * -1.0e9
+            ms, mi = torch.cat([fin_score, fscore], 1).topk(nb, dim=-1)
+            fin_seq = torch.cat([fin_seq, cand_seq], 1).gather(1, mi[:, :, None].expand(B, nb, max_new))
+            fin_len = torch.cat([fin_len, torch.full_like(tok, t + 1)], 1).gather(1, mi)
+            fin_done = torch.cat([fin_done, ends & top_mask[None]], 1).gather(1, mi)
+            fin_score = ms
+            # running beams: the best nb candidates that do not end
+            rs, ri = (cand_score + ends.float() * -1.0e9).topk(nb, dim=-1)
+            run_seq, run_score = cand_seq.gather(1, ri[:, :, None].expand(B, nb, max_new)), rs
+            if t + 1 == max_new:
+                break
+            # can a running beam still beat the worst finished hypothesis?  (reference heuristic, utils.py:3008-3052)
+            hyp_len = (max_new if (early_stopping == "never" and length_penalty > 0.0) else (t + 1))
+            best_running = run_score[:, :1] / float(hyp_len ** length_penalty)
+            worst_fin = torch.where(fin_done, fin_score.min(-1, keepdim=True).values, torch.full_like(fin_score, -1.0e9))
+            can_improve = can_improve & (best_running > worst_fin).any(-1, keepdim=True)
+            if not bool(can_improve.any()) or (early_stopping is True and bool(fin_done.all())):
+                break
+            # advance the model: reorder the cache by parentage, feed the chosen tokens
+            src = (parent.gather(1, ri) + boff).reshape(-1)
+            Kc.copy_(Kc.index_select(1, src)), Vt.copy_(Vt.index_select(1, src))
+            st["nxt"].copy_(tok.gather(1, ri).reshape(-1))
+            logits = self._decode_logits(st)
+            st["cur"].add_(1)
+        best_seq, best_len = fin_seq[:, 0], fin_len[:, 0]
+        pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
+        best_seq = torch.where(torch.arange(max_new, device=dev)[None] < best_len[:, None], best_seq, torch.full_like(best_seq, pad))
+        return torch.cat([ids, best_seq[:, : int(best_len.max())]], dim=1)
+
+    def _decode_logits(self, st):
+        """logits [B, V] (fp32) of the position after st["nxt"]: one pass over the decoder weights, cache append at st["cur"] (not advanced here)"""
         B = st["nxt"].shape[0]
         x = st["emb"].index_select(0, st["nxt"])
         pos1 = (st["cur"] - st["lo"]).contiguous()
@@ -745,8 +825,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             y = self._decode_layers_fused(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"])
         else:
             y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])
-        st["nxt"].copy_(self._select_token(ops.gemm_nt(y, st["head"]).float(), st.get("sampling")))
-        st["cur"].add_(1)
+        return ops.gemm_nt(y, st["head"]).float()
 
     @staticmethod
     def _select_token(logits, sampling=None):
@@ -771,15 +850,27 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20,
                  do_sample=False, temperature=1.0, top_k=50, top_p=1.0, seed=None, eos_token_id=None, pad_token_id=None, use_cache=True,
-                 use_graph=None, **kwargs):
-        """Greedy decoding or sampling (GenerationMixin.generate, transformers/generation/utils.py; do_sample with temperature / top_k /
-        top_p as its logits warpers apply them; seed -> a device generator, so runs are reproducible).  Cache handling as
+                 use_graph=None, num_beams=1, length_penalty=1.0, early_stopping=False, generation_config=None, **kwargs):
+        """Greedy decoding, sampling or beam search (GenerationMixin.generate, transformers/generation/utils.py; do_sample with temperature /
+        top_k / top_p as its logits warpers apply them; seed -> a device generator, so runs are reproducible; num_beams > 1: beam search with the
+        reference's scoring - accumulated log-probabilities, finished hypotheses ranked by sum / length^length_penalty, its early-stop
+        heuristic).  generation_config (a transformers.GenerationConfig or anything with the same attributes) supplies defaults for the
+        arguments left at theirs, as GenerationMixin merges them.  Cache handling as
         Qwen2Attention.forward modeling_qwen2.py:213-214).  Prefill runs the prompt once and fills a per-layer KV cache; every new
         token then costs one pass over the weights and one Q=1 attention over the cache.  Batches may be LEFT padded
         (attention_mask, as the processor pads): positions count real tokens only and padded keys are never visible.
         The decode step is launch-bound in eager mode (~370 small launches per token), so it is captured once into a HIP graph and
         replayed (use_graph=None: whenever more than 3 tokens are requested)."""
         self._require_hip()
+        gc = generation_config if generation_config is not None else getattr(self, "generation_config", None)
+        if gc is not None:  # explicit arguments win; anything still at its default is taken from the generation config
+            pick = lambda cur, default, name: getattr(gc, name, None) if (cur == default and getattr(gc, name, None) is not None) else cur
+            max_new_tokens = pick(max_new_tokens, 20, "max_new_tokens")
+            do_sample, temperature, top_k, top_p = pick(do_sample, False, "do_sample"), pick(temperature, 1.0, "temperature"), pick(top_k, 50, "top_k"), pick(top_p, 1.0, "top_p")
+            num_beams, length_penalty, early_stopping = pick(num_beams, 1, "num_beams"), pick(length_penalty, 1.0, "length_penalty"), pick(early_stopping, False, "early_stopping")
+            eos_token_id, pad_token_id = pick(eos_token_id, None, "eos_token_id"), pick(pad_token_id, None, "pad_token_id")
+        if num_beams > 1 and (do_sample or not use_cache):
+            raise AfkError("generate(num_beams > 1): beam search is deterministic and runs on the KV cache (no do_sample, no use_cache=False)")
         sampling = None
         if do_sample:
             gen = torch.Generator(device=self.device_)
@@ -814,6 +905,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         fast = self.D in (64, 128) and ops.ATTN_IMPL == "lds" and (self.left_pad_on_lds_kernels or not padded)
         y = self._decode_layers(x, B, S0, 0, (Kc, Vt), pos_rows, krange, fast, kv_lo=lo if padded else None)
         last = y.reshape(B, S0, -1)[:, -1, :].contiguous()
+        if num_beams > 1:
+            return self._beam_search(ids, last, (Kc, Vt), lo, int(num_beams), int(max_new_tokens), eos_token_id, pad_token_id, float(length_penalty), early_stopping)
         st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
               "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling,
               "nxt": self._select_token(ops.gemm_nt(last, self.arena["lm_head.weight"].data).float(), sampling)}

@@ -966,3 +966,48 @@ def test_adamw_fused_transposed_shadow(dev):
     o.step(gates=torch.zeros(len(m.arena.bucket_names), device=dev, dtype=torch.int32))
     torch.cuda.synchronize()
     assert torch.equal(m.arena.params, before) and all(torch.equal(m.arena.blocks[k].shadow, v) for k, v in sh.items())
+
+
+@pytest.mark.parametrize("case,num_beams,with_eos", [("A", 3, False), ("A", 4, True), ("Apad", 2, False), ("Apad", 3, True)])
+def test_generate_beam_search_matches_reference(dev, case, num_beams, with_eos):
+    """generate(num_beams > 1) against the live reference's beam search (GenerationMixin._beam_search, fp32 on the host, same bf16-rounded
+    weights): the returned sequences must be IDENTICAL - without an EOS (every hypothesis runs to the length limit), with an EOS that the
+    greedy continuation hits after a few tokens (hypotheses finish early, length-normalised scores compete, rows end at different lengths and
+    are padded), for one row (case A prompt) and for a LEFT-padded two-row batch built from it (row 0 = the same prompt with its first five
+    tokens replaced by padding: positions, visible keys and cache reordering of a padded row).  Sharp rows only: where the trained model is
+    unsure (the short row of case C) fp32 and bf16 legitimately rank near-tied beams differently.  generation_config defaults honoured."""
+    from transformers import AudioFlamingo3ForConditionalGeneration, GenerationConfig
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    ref = AudioFlamingo3ForConditionalGeneration(_cfg())
+    ref.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    ref = ref.float().eval()
+    ids, att, nw = _gen_prompt(g), None, 1
+    feats_g, fmask_g = g["feats"][:1], g["fmask"][:1]
+    if case == "Apad":
+        padded = ids.clone()
+        padded[0, :5] = 1000
+        ids = torch.cat([padded, ids], 0)
+        att = torch.ones_like(ids)
+        att[0, :5] = 0
+        nw, feats_g, fmask_g = 2, feats_g.repeat(2, 1, 1), fmask_g.repeat(2, 1)
+    g = dict(g, feats=feats_g, fmask=fmask_g)
+    S0 = ids.shape[1]
+    eos = int(g["generate"][0, S0 + 6]) if with_eos else None     # the 7th greedy token of row 0: beams start finishing there
+    kw = dict(max_new_tokens=12, do_sample=False, num_beams=num_beams)
+    if with_eos:
+        kw.update(eos_token_id=eos, pad_token_id=0)
+    feats = g["feats"][:nw].to(torch.bfloat16).float()
+    with torch.no_grad():
+        want = ref.generate(input_ids=ids, input_features=feats, input_features_mask=g["fmask"][:nw], attention_mask=att, **kw)
+    m = _model(dev)
+    got = m.generate(ids.to(dev), input_features=g["feats"][:nw].to(dev), input_features_mask=g["fmask"][:nw].to(dev),
+                     attention_mask=None if att is None else att.to(dev), **kw)
+    assert got.cpu().tolist() == want.tolist(), (got.cpu().tolist(), want.tolist())
+    if with_eos:
+        assert (want[:, S0:] == eos).any(), "the EOS must actually be hit for this case to mean anything"
+    # the same through a GenerationConfig object (explicit arguments left at their defaults are taken from it)
+    gc = GenerationConfig(**kw)
+    got2 = m.generate(ids.to(dev), input_features=g["feats"][:nw].to(dev), input_features_mask=g["fmask"][:nw].to(dev),
+                      attention_mask=None if att is None else att.to(dev), generation_config=gc)
+    assert torch.equal(got2, got)
