@@ -15,7 +15,8 @@ Deviations from the oracle surface (documented, not silent):
   * ``forward(use_cache=True)`` / ``forward(past_key_values=cache)``: the reference's cache protocol for inference (prefill returns an
     ``AfkKVCache``, later calls append one or several tokens); same kernels and cache layout as ``generate``;
   * ``generate``: prefill fills a KV cache, each new token is one HIP-graph replay; greedy by default, ``do_sample=True`` with
-    ``temperature`` / ``top_k`` / ``top_p`` / ``seed`` (the reference's logits-warper order); no beam search;
+    ``temperature`` / ``top_k`` / ``top_p`` / ``seed`` (the reference's logits-warper order), or ``num_beams > 1`` (beam search with the
+    reference's scoring); ``generation_config`` supplies defaults; constrained / assisted decoding and custom logits processors are not built;
   * ``attention_mask`` rows must be one contiguous run of ones (left padding - the reference processor's default -, right padding, or
     both); masks with holes raise.  Hidden states of padded positions are zeros-attended garbage in both implementations and are
     never compared.
