@@ -42,6 +42,7 @@ class Block:
     shadow_kind: Optional[str] = None  # "T" (W^T), "conv" (tap-major + its transpose)
     shadow_aux: Optional[torch.Tensor] = None
     shadow_version: int = -1
+    shadow_lazy: bool = False  # the eager per-step refresh skips this block; arena.shadow() rebuilds it on demand (the training step never reads it)
 
 
 class Arena:
@@ -195,12 +196,12 @@ class Arena:
     def refresh_bucket_shadows(self, i: int, skip=None):
         """skip: blocks whose shadow the optimizer launch itself just wrote (FusedAdamW with FUSE_SHADOW)"""
         for b in self._bucket_blocks[i]:
-            if b.shadow_kind is not None and not (self.lazy_T_shadows and b.shadow_kind == "T") and not (skip is not None and b.key in skip):
+            if b.shadow_kind is not None and not b.shadow_lazy and not (self.lazy_T_shadows and b.shadow_kind == "T") and not (skip is not None and b.key in skip):
                 self._refresh_one(b)
 
     def refresh_shadows(self, force: bool = True, skip=None):
         for b in self.order:
-            if (self.lazy_T_shadows and b.shadow_kind == "T") or (skip is not None and b.key in skip):
+            if (self.lazy_T_shadows and b.shadow_kind == "T") or b.shadow_lazy or (skip is not None and b.key in skip):
                 continue
             if b.shadow_kind is not None and (force or b.shadow_version != self._version_of(b)):
                 self._refresh_one(b)
@@ -388,7 +389,7 @@ class FusedAdamW:
         self.arena.step_counter += 1
         self._mark_synced()
         for b in self.arena.order:  # shadows were refreshed bucket by bucket (lazy W^T shadows stay stale until used)
-            if b.shadow_kind is not None and not (self.arena.lazy_T_shadows and b.shadow_kind == "T"):
+            if b.shadow_kind is not None and not b.shadow_lazy and not (self.arena.lazy_T_shadows and b.shadow_kind == "T"):
                 b.shadow_version = self.arena._version_of(b)
 
     def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True, gates=None):

@@ -63,6 +63,7 @@ FUSE_SWIGLU_FWD = os.environ.get("AFK_FUSE_SWIGLU_FWD", "1") == "1"
 # separate gelu_fwd pass (round 2): 123 MB per encoder layer at B = 8 (3.9 GB for the tower, of 288 GB) buys back 34 launches and
 # 1.6 ms per step; bit-identical (the same kernel produced the same values either way).  AFK_SAVE_GELU=0 restores the recompute.
 SAVE_GELU = os.environ.get("AFK_SAVE_GELU", "1") == "1"
+LMHEAD_NN_DGRAD = os.environ.get("AFK_LMHEAD_NN_DGRAD", "1") == "1"   # see LMHeadLossFn.forward
 
 
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
@@ -454,7 +455,15 @@ class LMHeadLossFn(torch.autograd.Function):
         buf = torch.empty((chunk, V), device=dev, dtype=torch.bfloat16)
         direct = BWD_FORM == "direct"
         wdirect = direct or BWD_FORM == "wgrad_direct"
-        wt = arena.shadow(wkey) if need_grad and not direct else None
+        # dgrad dX[n, H] = dlogits[n, V] . W[V, H] reduces over the VOCABULARY (152 064) into a narrow output (n x 3584: 112 tiles of 256 x 256 for
+        # the 2 048 labelled rows of the benchmark batch): the NT form + W^T shadow ran it on the 128-tile kernel at 0.88 PF/s.  LMHEAD_NN_DGRAD
+        # runs it on the transposed-operand kernel straight from W with split-K over the vocabulary (one round of 224 workgroups, fp32 partials
+        # folded in fixed order): no W^T shadow of lm_head is read by the step any more, so its 1.09 GB refresh per step is skipped too
+        # (the block's shadow turns lazy; LMHeadFn's backward still rebuilds it on demand).
+        nn_dgrad = LMHEAD_NN_DGRAD and not direct and H % 8 == 0 and _tiles256(chunk, H) < DIRECT_MIN_TILES
+        if nn_dgrad and not blk.shadow_lazy:
+            blk.shadow_lazy = True
+        wt = arena.shadow(wkey) if need_grad and not direct and not nn_dgrad else None
         if need_grad:
             # unscaled lm_head gradient goes to a private buffer when it must be accumulated into existing grads
             gw_tmp = blk.grad if blk.fresh else torch.empty_like(blk.grad)
@@ -466,8 +475,8 @@ class LMHeadLossFn(torch.autograd.Function):
             ops.gemm_nt(x[s:e], blk.data, out=logits)
             ops.ce_fwd_bwd_(logits, shift_labels[s:e], row_loss[s:e], denom, upstream=1.0, write_grad=need_grad)
             if need_grad:
-                if direct:
-                    ops.gemm(logits, blk.data, out=dx[s:e], trans_b=True)                               # dX = dlogits . W
+                if direct or nn_dgrad:
+                    ops.gemm(logits, blk.data, out=dx[s:e], trans_b=True)                               # dX = dlogits . W  (split-K chosen by ops.splitk_plan_256)
                 else:
                     ops.gemm_nt(logits, wt, out=dx[s:e], K=V)
                 if wdirect:

@@ -63,7 +63,7 @@ class GraphedTrainStep:
         self.model.arena.step_counter += 1
         self.opt._mark_synced()
         for b in self.model.arena.order:
-            if b.shadow_kind is not None and not (self.model.arena.lazy_T_shadows and b.shadow_kind == "T"):
+            if b.shadow_kind is not None and not b.shadow_lazy and not (self.model.arena.lazy_T_shadows and b.shadow_kind == "T"):
                 b.shadow_version = self.model.arena._version_of(b)
         self.steps += 1
         return self.loss
