@@ -280,6 +280,25 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     def trainable_numel(self):
         return sum(b.numel for b in self.arena.order)
 
+    # ------------------------------------------------------------------ small PreTrainedModel conveniences scripts rely on
+    @property
+    def device(self):
+        return self.device_
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    def num_parameters(self, only_trainable: bool = False) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad or not only_trainable)
+
+    def get_input_embeddings(self):
+        """holder module whose `.weight` is the arena view of embed_tokens (the reference returns its nn.Embedding)"""
+        return self.model.language_model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
     # ------------------------------------------------------------------ checkpoints (PreTrainedModel.from_pretrained / save_pretrained surface)
     @classmethod
     def from_pretrained(cls, path, device="cuda", **kwargs):
@@ -543,11 +562,20 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         else:
             x = F_.EmbedScatterFn.apply(audio, self._anchor(lm + "embed_tokens.weight"), a, lm + "embed_tokens.weight", ids_flat, src)
         audio_hidden = audio
+        if kwargs.get("output_attentions"):
+            raise AfkError("output_attentions=True: the attention kernels never materialise the probabilities (the reference's default sdpa path returns none either)")
+        want_hidden = bool(kwargs.get("output_hidden_states", getattr(self.config, "output_hidden_states", False)))
+        hidden = [x.reshape(B, S, -1)] if want_hidden else None      # the reference's tuple: merged embeddings, every layer's output, ...
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
             x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
                             self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo)
+            if want_hidden and i + 1 < self.dec_layers:
+                hidden.append(x.reshape(B, S, -1))
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
+        if want_hidden:
+            hidden.append(x.reshape(B, S, -1))                            # ... with the LAST entry taken after the final norm (lm_head(hidden[-1]) == logits)
+            hidden = tuple(hidden)
         loss, logits = None, None
         if labels is not None:
             shift, rows = self._valid_rows(labels) if self.loss_on_valid_rows_only else (
@@ -564,9 +592,9 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             return F_.LMHeadFn.apply(xs, self._anchor("lm_head.weight"), a, "lm_head.weight").reshape(B, -1, self.V)
 
         if labels is None or return_logits:
-            return AF3Output(loss=loss, logits=_logits(), audio_hidden_states=audio_hidden)
+            return AF3Output(loss=loss, logits=_logits(), hidden_states=hidden, audio_hidden_states=audio_hidden)
         # labels given: the reference returns logits beside the loss (modeling_audioflamingo3.py:625-642); here they are built on first access
-        return AF3Output(loss=loss, logits_fn=_logits, audio_hidden_states=audio_hidden)
+        return AF3Output(loss=loss, logits_fn=_logits, hidden_states=hidden, audio_hidden_states=audio_hidden)
 
     # ------------------------------------------------------------------ generate (greedy; KV cache - SURVEY.md 8(f)-4)
     def _merged_embeddings(self, ids, input_features, input_features_mask):

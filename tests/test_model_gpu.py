@@ -1015,3 +1015,31 @@ def test_generate_beam_search_matches_reference(dev, case, num_beams, with_eos):
     got2 = m.generate(ids.to(dev), input_features=g["feats"][:nw].to(dev), input_features_mask=g["fmask"][:nw].to(dev),
                       attention_mask=None if att is None else att.to(dev), generation_config=gc)
     assert torch.equal(got2, got)
+
+
+def test_output_hidden_states_match_reference(dev):
+    """output_hidden_states=True: the reference's tuple (merged embeddings, every decoder layer's output, the LAST entry after the final
+    norm: lm_head(hidden[-1]) == logits) against the live reference's fp32 run; output_attentions is refused (the kernels never
+    materialise probabilities)"""
+    from transformers import AudioFlamingo3ForConditionalGeneration
+
+    from audio_flamingo_amd._lib import AfkError
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    ref = AudioFlamingo3ForConditionalGeneration(_cfg())
+    ref.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
+    ref = ref.float().eval()
+    with torch.no_grad():
+        want = ref(input_ids=g["ids"], input_features=g["feats"].float(), input_features_mask=g["fmask"], attention_mask=g["att"],
+                   output_hidden_states=True).hidden_states
+    m = _model(dev)
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), attention_mask=g["att"].to(dev))
+    out = m(**kw, output_hidden_states=True)
+    assert len(out.hidden_states) == len(want) == 3 and "hidden_states" in out.keys()
+    keep = g["att"].bool()
+    for i, (h, w) in enumerate(zip(out.hidden_states, want)):
+        assert h.shape == w.shape
+        assert _rel(h.float().cpu()[keep], w[keep]) <= 2e-2, (i, _rel(h.float().cpu()[keep], w[keep]))   # padded positions are never compared
+    assert m(**kw).hidden_states is None
+    with pytest.raises(AfkError, match="output_attentions"):
+        m(**kw, output_attentions=True)
