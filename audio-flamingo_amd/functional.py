@@ -83,8 +83,14 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
             arena.grad_written(blk)
             if bkey:
                 bb = arena[bkey]
-                for (s, e) in (bias_slices or [(0, N)]):
-                    ops.colsum(dy[:, s:e], bb.grad[s:e], accumulate=not bb.fresh)
+                if bias_slices is not None and len(bias_slices) == 2 and bias_slices[0][0] == 0 and bias_slices[1][1] == N:
+                    # two slices with a gap (the encoder's fused q|k|v bias: k_proj has no bias, :112): ONE column-sum launch over the full width,
+                    # then the gap is cleared - its gradient must read exactly zero so that the k-third of the fused bias never moves
+                    ops.colsum(dy, bb.grad, accumulate=not bb.fresh)
+                    bb.grad[bias_slices[0][1]: bias_slices[1][0]].zero_()
+                else:
+                    for (s, e) in (bias_slices or [(0, N)]):
+                        ops.colsum(dy[:, s:e], bb.grad[s:e], accumulate=not bb.fresh)
                 arena.grad_written(bb)
             return
         dyt = ops.transpose(dy)  # [N, Mp]

@@ -289,8 +289,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     def dtype(self):
         return torch.bfloat16
 
-    def num_parameters(self, only_trainable: bool = False) -> int:
-        return sum(p.numel() for p in self.parameters() if p.requires_grad or not only_trainable)
+    def num_parameters(self, only_trainable: bool = False, exclude_embeddings: bool = False) -> int:
+        """PreTrainedModel.num_parameters (the HF Trainer calls it with exclude_embeddings=True for its FLOPs estimate)"""
+        skip = {id(self._prm[self._lm + "embed_tokens.weight"]), id(self.embed_positions)} if exclude_embeddings else set()
+        return sum(p.numel() for p in self.parameters() if (p.requires_grad or not only_trainable) and id(p) not in skip)
 
     def get_input_embeddings(self):
         """holder module whose `.weight` is the arena view of embed_tokens (the reference returns its nn.Embedding)"""

@@ -454,6 +454,16 @@ def embed_scatter_bwd(ids, src, dout, d_embed, d_audio, perm=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
+def _row_stat_buffer(B, H, S, spad, device):
+    """fp32 [B, H, spad] per-query statistic (lse, delta) of the LDS-staged attention kernels.  The kernels write every query < S; only the
+    padding tail [S, spad) of a ragged last tile must read as zero - so nothing is filled when S is a multiple of 64 (the decoder's 1 024:
+    one fill launch per attention call saved), and only the tail otherwise."""
+    t = torch.empty((B, H, spad), device=device, dtype=torch.float32)
+    if spad > S:
+        t[:, :, S:].zero_()
+    return t
+
+
 ATTN_IMPL = "lds"  # "lds" = attention_lds.hip (head_dim 64/128), "direct" = attention.hip (also head_dim 32; A/B reference)
 
 
@@ -474,7 +484,7 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
     v = qkv[:, (Hq + Hkv) * D:]
     o = torch.empty((B * S, Hq * D), device=qkv.device, dtype=BF16)
     if _use_lds(D):
-        lse = torch.zeros((B, Hq, spad), device=qkv.device, dtype=torch.float32)
+        lse = _row_stat_buffer(B, Hq, S, spad, qkv.device)
         _lib.call("afk_attn2_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D, float(scale),
                   int(causal), _stream())
@@ -503,7 +513,7 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, k
     dk = dqkv[:, Hq * D:]
     dv = dqkv[:, (Hq + Hkv) * D:]
     if _use_lds(D) and lse.shape[-1] == spad:
-        delta = torch.zeros((B, Hq, spad), device=dev, dtype=torch.float32)
+        delta = _row_stat_buffer(B, Hq, S, spad, dev)
         _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S,
                   spad, D, _stream())
         scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
