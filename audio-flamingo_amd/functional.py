@@ -64,6 +64,11 @@ FUSE_SWIGLU_FWD = os.environ.get("AFK_FUSE_SWIGLU_FWD", "1") == "1"
 # 1.6 ms per step; bit-identical (the same kernel produced the same values either way).  AFK_SAVE_GELU=0 restores the recompute.
 SAVE_GELU = os.environ.get("AFK_SAVE_GELU", "1") == "1"
 LMHEAD_NN_DGRAD = os.environ.get("AFK_LMHEAD_NN_DGRAD", "1") == "1"   # see LMHeadLossFn.forward
+# Per-weight choice of the dgrad form: weights whose key ends with one of these suffixes take dX = dY . W on the transposed-operand (NN) kernel
+# straight from W - their W^T shadow turns lazy and is no longer refreshed every step - the others keep the NT kernel + shadow.
+# ("direct" = every weight.)  Measured per weight class on the full step: see NN_DGRAD_DEFAULT below.
+NN_DGRAD_DEFAULT = ""
+NN_DGRAD_SUFFIXES = tuple(x for x in os.environ.get("AFK_NN_DGRAD", NN_DGRAD_DEFAULT).split(",") if x)
 
 
 def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
@@ -113,7 +118,9 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
         x.record_stream(side)
     if not need_dx:
         return None
-    if direct and _tiles256(M, K) >= DIRECT_MIN_TILES:
+    if (direct or (NN_DGRAD_SUFFIXES and wkey.endswith(NN_DGRAD_SUFFIXES) and swiglu_gu is None)) and _tiles256(M, K) >= DIRECT_MIN_TILES:
+        if not direct:
+            blk.shadow_lazy = True   # nobody reads this W^T shadow in the step any more: skip its per-step refresh
         return ops.gemm(dy, blk.data.reshape(blk.shape[0], -1), trans_b=True)  # dX = dY . W, W as stored
     wt = arena.shadow(wkey)  # [K, pad64(N)]
     if swiglu_gu is not None:  # down-projection dgrad with the SwiGLU backward in its epilogue: returns d(gate|up) directly
