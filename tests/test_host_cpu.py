@@ -335,3 +335,55 @@ def test_bench_multi_rank_control_flow_gloo():
     d = json.loads(jl[0])
     assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 2 and d["replicas_identical_after_steps"] is True
     assert d["buckets"] == 8 and d["collectives_per_step"] == 9    # stem, enc0, enc1, enc_out, embed, dec0, dec1, head + the touched-flag MAX
+
+
+def test_af3_output_is_lazy_about_logits():
+    """forward(labels=...) hands back the reference's output surface with logits built on FIRST ACCESS: reading the loss (attribute, key or
+    index 0 - what Trainer.compute_loss does) must not build them; outputs[1:] (what Trainer.prediction_step reads) must"""
+    from audio_flamingo_amd.modeling import AF3Output
+
+    calls = []
+    out = AF3Output(loss=torch.tensor(1.5), logits_fn=lambda: (calls.append(1), torch.zeros(2, 3, 4))[1], audio_hidden_states=torch.ones(5))
+    assert out[0] is out.loss and out["loss"] is out.loss and out.keys() == ["loss", "logits", "audio_hidden_states"] and len(out) == 3
+    assert "logits" in out and "hidden_states" not in out and out.get("attentions", 7) == 7
+    assert not calls and not out.logits_materialized
+    rest = out[1:]
+    assert calls == [1] and rest[0].shape == (2, 3, 4) and rest[1] is out.audio_hidden_states
+    assert out.logits is rest[0] and out.to_tuple()[1] is rest[0] and calls == [1]        # built once
+    with pytest.raises(KeyError):
+        out["nope"]
+    eager = AF3Output(logits=torch.zeros(1))
+    assert eager.logits_materialized and eager.keys() == ["logits"] and eager[0] is eager.logits
+
+
+def test_dp_flags_and_adamw_launch_plans():
+    """host logic of round 3: (i) the per-bucket touched flags are written by fill launches (capturable into a HIP graph), one per run of
+    ones; (ii) FusedAdamW's launch plans - flat runs merged per decay class, one fused launch per 2-D GEMM weight when the transposed-shadow
+    kernel is enabled, none of those when the arena keeps lazy W^T shadows - and the per-block lazy shadow used by the lm_head"""
+    from audio_flamingo_amd.arena import FusedAdamW
+    from audio_flamingo_amd.dp import _flags_on_device
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    assert _flags_on_device([1, 1, 1], "cpu").tolist() == [1, 1, 1]
+    assert _flags_on_device([0, 1, 1, 0, 1, 0], "cpu").tolist() == [0, 1, 1, 0, 1, 0]
+    assert _flags_on_device([0, 0], "cpu").tolist() == [0, 0] and _flags_on_device([0, 0], "cpu").dtype == torch.int32
+    m = Mine(_cfg(), device="cpu")
+    opt = FusedAdamW(m.arena, lr=1e-3, weight_decay=0.01)
+    assert not opt.fuse_shadow and all(op[0] == "flat" for op in opt.segments)
+    covered = sum(op[2] - op[1] for op in opt.segments)
+    assert covered == m.arena.total                                   # the flat runs tile the whole arena
+    assert all(a[3] != b[3] for a, b in zip(opt.segments, opt.segments[1:]) if a[2] == b[1])   # adjacent runs differ in their decay class (else merged)
+    opt.fuse_shadow = True                                            # plans are rebuilt when the policy changes
+    kinds = [op[0] for op in opt.segments]
+    t_keys = {op[1].key for op in opt.segments if op[0] == "T"}
+    assert "T" in kinds and "flat" in kinds
+    assert all(m.arena[k].shadow_kind == "T" and m.arena[k].shape[0] % 64 == 0 and m.arena[k].shape[1] % 64 == 0 for k in t_keys)
+    assert "lm_head.weight" in t_keys and "model.language_model.embed_tokens.weight" not in t_keys      # embed_tokens has no dgrad shadow
+    flat_cov = sum(op[2] - op[1] for op in opt.segments if op[0] == "flat")
+    t_cov = sum((op[1].numel + 63) // 64 * 64 for op in opt.segments if op[0] == "T")
+    assert flat_cov + t_cov == m.arena.total
+    m.arena.lazy_T_shadows = True                                     # "direct" backward form: no eager shadows -> nothing to fuse
+    assert all(op[0] == "flat" for op in opt.segments)
+    m.arena.lazy_T_shadows = False
+    blk = m.arena["lm_head.weight"]
+    assert blk.shadow_lazy is False
