@@ -377,7 +377,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     }
     const float c2 = p.scale * LOG2E;
     const float nlse = p.LSE[((int64_t)b * p.Hq + h) * p.Spad + qc] * c2;  // stored negated, in score units (see the forward epilogue)
-    const float ndlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];      // stored negated (attn2_delta_kernel)
+    float ndlt;
+    if (p.O != nullptr) {
+        // afk_attn2_bwd_fused: delta = rowsum(dO o O) is computed HERE - this wave holds its queries' dO rows already - and published for the
+        // dK/dV sweep, which is launched behind this kernel: the separate pass over O and dO (attn2_delta_kernel) disappears.
+        // Lane (l31, hi) covers d = 16 ks + 8 hi + 0..7 of row q: the two lane halves together cover the whole row.
+        const bf16* Op = p.O + b * p.o_bs + h * p.o_hs + (int64_t)qc * p.o_rs + hi * 8;
+        float acc = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 o8 = *(const bf16x8*)(Op + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (float)o8[e] * (float)dof[ks][e];
+        }
+        acc += other_half(acc);
+        ndlt = -acc;   // stored negated: the backward kernels start the dP accumulators from it
+        if (hi == 0 && q < p.S) const_cast<float*>(p.delta)[((int64_t)b * p.Hq + h) * p.Spad + q] = ndlt;
+    } else {
+        ndlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];      // stored negated (attn2_delta_kernel)
+    }
     const bf16* Kbase = p.K + b * p.k_bs + hk * p.k_hs;
     const bf16* Vbase = p.V + b * p.v_bs + hk * p.v_hs;
 
@@ -929,13 +947,15 @@ extern "C" int afk_attn2_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_
     return AFK_OK;
 }
 
-extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
-                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
-                             int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
-                             int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
-                             int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
-                             int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
+static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                          int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* O, int64_t o_bs, int64_t o_hs,
+                          int64_t o_rs, const void* dO, int64_t do_bs,
+                          int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
+                          int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
+                          int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
+                          int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
     AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
+    AFK_REQUIRE(!O || (o_rs % 8 == 0 && o_hs % 8 == 0), "afk_attn2_bwd_fused: O strides must keep 16-byte alignment");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_bwd: bad shape");
     AFK_REQUIRE(D == 64 || D == 128, "afk_attn2_bwd: head_dim %d unsupported by the LDS kernels (64/128)", D);
     AFK_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && do_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 &&
@@ -946,6 +966,7 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
     p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
     p.dO = (const bf16*)dO; p.do_bs = do_bs; p.do_hs = do_hs; p.do_rs = do_rs;
+    p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;   // non-null: the dQ kernel computes delta itself and runs FIRST
     p.dQ = (bf16*)dQ; p.dq_bs = dq_bs; p.dq_hs = dq_hs; p.dq_rs = dq_rs;
     p.dK = (bf16*)dK; p.dk_bs = dk_bs; p.dk_hs = dk_hs; p.dk_rs = dk_rs;
     p.dV = (bf16*)dV; p.dv_bs = dv_bs; p.dv_hs = dv_hs; p.dv_rs = dv_rs;
@@ -980,14 +1001,16 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
         constexpr int L = 4 * Tile<128>::BYTES, LKV = L + 2048;  // dK/dV sweep: + one lse/delta strip per buffer
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
         (void)once;
+        if (O) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);   // publishes delta for the sweep behind it
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), LKV, st, pk);
-        if (!(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
+        if (!O && !(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
     } else {
         constexpr int L = 4 * Tile<64>::BYTES, LKV = L + 2048;
         static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
         (void)once;
+        if (O) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
-        if (!(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+        if (!O && !(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
     }
     if (split && !(AFK_DBG(p) & 4)) {
         AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
@@ -1000,4 +1023,27 @@ extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     }
     AFK_LAUNCH_CHECK("afk_attn2_bwd");
     return AFK_OK;
+}
+
+extern "C" int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* dO, int64_t do_bs,
+                             int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
+                             int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
+                             int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
+                             int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
+    return attn2_bwd_impl(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, nullptr, 0, 0, 0, dO, do_bs, do_hs, do_rs, LSE, delta, dQ, dq_bs,
+                          dq_hs, dq_rs, dK, dk_bs, dk_hs, dk_rs, dV, dv_bs, dv_hs, dv_rs, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, gqa_scratch, stream);
+}
+
+// the same with delta = rowsum(dO o O) computed inside the dQ kernel (no afk_attn2_delta call): delta_ws [B, Hq, Spad] fp32 is a WORKSPACE written
+// by this call (its padding tail [S, Spad) must read zero)
+extern "C" int afk_attn2_bwd_fused(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                                   int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* O, int64_t o_bs, int64_t o_hs,
+                                   int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs, int64_t do_rs, const float* LSE, float* delta_ws,
+                                   void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs,
+                                   void* dV, int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq,
+                                   int Hkv, int S, int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
+    AFK_REQUIRE(O != nullptr, "afk_attn2_bwd_fused: O is required (use afk_attn2_bwd with a precomputed delta otherwise)");
+    return attn2_bwd_impl(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, O, o_bs, o_hs, o_rs, dO, do_bs, do_hs, do_rs, LSE, delta_ws, dQ, dq_bs,
+                          dq_hs, dq_rs, dK, dk_bs, dk_hs, dk_rs, dV, dv_bs, dv_hs, dv_rs, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, gqa_scratch, stream);
 }

@@ -464,6 +464,7 @@ def _row_stat_buffer(B, H, S, spad, device):
     return t
 
 
+ATTN_FUSE_DELTA = os.environ.get("AFK_ATTN_FUSE_DELTA", "1") == "1"   # afk_attn2_bwd_fused (delta inside the dQ kernel) vs delta pass + afk_attn2_bwd
 ATTN_IMPL = "lds"  # "lds" = attention_lds.hip (head_dim 64/128), "direct" = attention.hip (also head_dim 32; A/B reference)
 
 
@@ -514,9 +515,15 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, k
     dv = dqkv[:, (Hq + Hkv) * D:]
     if _use_lds(D) and lse.shape[-1] == spad:
         delta = _row_stat_buffer(B, Hq, S, spad, dev)
+        scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
+        if ATTN_FUSE_DELTA:   # delta = rowsum(dO o O) inside the dQ kernel, which runs ahead of the dK/dV sweep: one pass over O and dO less
+            _lib.call("afk_attn2_bwd_fused", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+                      o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
+                      dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
+                      float(scale), int(causal), _p(scratch), _stream())
+            return dqkv
         _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S,
                   spad, D, _stream())
-        scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
                   dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,

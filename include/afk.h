@@ -221,6 +221,14 @@ int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
                   int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
                   int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream);
+/* afk_attn2_bwd with delta = rowsum(dO o O) computed inside the dQ kernel (which then runs ahead of the dK/dV sweep): no afk_attn2_delta call;
+ * delta_ws [B, Hq, Spad] fp32 is a workspace written by this call whose padding tail [S, Spad) must read zero. */
+int afk_attn2_bwd_fused(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                        int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* O, int64_t o_bs, int64_t o_hs,
+                        int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs, int64_t do_rs, const float* LSE, float* delta_ws,
+                        void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs,
+                        void* dV, int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq,
+                        int Hkv, int S, int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream);
 /* gqa_scratch: NULL, or 2*B*S*Hq*D bf16 - enables the one-block-per-query-head dK/dV sweep + group reduce (GQA) */
 
 /* Music Flamingo rotary time embedding on the encoder output (apply_rotary_time_emb, transformers/models/musicflamingo/
