@@ -65,9 +65,12 @@ FUSE_SWIGLU_FWD = os.environ.get("AFK_FUSE_SWIGLU_FWD", "1") == "1"
 SAVE_GELU = os.environ.get("AFK_SAVE_GELU", "1") == "1"
 LMHEAD_NN_DGRAD = os.environ.get("AFK_LMHEAD_NN_DGRAD", "1") == "1"   # see LMHeadLossFn.forward
 # Per-weight choice of the dgrad form: weights whose key ends with one of these suffixes take dX = dY . W on the transposed-operand (NN) kernel
-# straight from W - their W^T shadow turns lazy and is no longer refreshed every step - the others keep the NT kernel + shadow.
-# ("direct" = every weight.)  Measured per weight class on the full step: see NN_DGRAD_DEFAULT below.
-NN_DGRAD_DEFAULT = ""
+# straight from W - their W^T shadow turns lazy and is no longer refreshed every step - the others keep the NT kernel + shadow ("direct" = every
+# weight).  Measured on the full step, alternating runs in one gpurun call (profiles/r03_ab_experiments.md §4): gate|up alone 409.1 vs 414.6 ms
+# (three pairs: -5.0 / -4.6 / -6.9 ms; its shadow is the largest - 271 MB per layer, 3 ms of transposes per step - and its dgrad reduces over
+# K = 37 888, where the NN kernel is level with NT); adding down_proj (+0.4 / +4 ms), o_proj + qkv (+0.1) or the encoder weights (-0.7) on top of it
+# is neutral or worse.  Round 1-2 measured "direct" (all weights) slower and stopped there.
+NN_DGRAD_DEFAULT = "mlp.gate_up.weight"
 NN_DGRAD_SUFFIXES = tuple(x for x in os.environ.get("AFK_NN_DGRAD", NN_DGRAD_DEFAULT).split(",") if x)
 
 

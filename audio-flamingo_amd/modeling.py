@@ -200,6 +200,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         a.add(lm + "norm.weight", (H,), b, decay=False)
         a.add("lm_head.weight", (V, H), b, shadow="T")
         a.finalize()
+        # weights whose dgrad reads W itself (functional.NN_DGRAD_SUFFIXES: the NN kernel) never need an eager W^T shadow: not allocated, not refreshed
+        for blk in a.order:
+            if blk.shadow_kind == "T" and F_.NN_DGRAD_SUFFIXES and blk.key.endswith(F_.NN_DGRAD_SUFFIXES):
+                blk.shadow_lazy = True
 
         # ---------------- oracle-named parameters = views into the arena
         self._prm = {}
