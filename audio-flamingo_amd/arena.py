@@ -193,6 +193,10 @@ class Arena:
     def _version_of(self, b: Block) -> int:
         return self.params._version * 1000003 + self.step_counter
 
+    def version(self) -> int:
+        """changes whenever a parameter may have changed: in-place tensor writes (load_state_dict, torch ops) and our optimizer's raw-pointer steps"""
+        return self.params._version * 1000003 + self.step_counter
+
     def refresh_bucket_shadows(self, i: int, skip=None):
         """skip: blocks whose shadow the optimizer launch itself just wrote (FusedAdamW with FUSE_SHADOW)"""
         for b in self._bucket_blocks[i]:
@@ -277,7 +281,10 @@ class FusedAdamW:
         return self._bucket_segments
 
     def _ensure_plans(self):
-        key = (self.fuse_shadow, self.arena.lazy_T_shadows, self.weight_decay)
+        # the set of lazily-shadowed blocks is part of the key: linear_bwd / LMHeadLossFn flip Block.shadow_lazy at run time (a weight whose dgrad
+        # reads W itself needs no W^T shadow, and a fused launch would allocate and rewrite one for nothing)
+        lazy = tuple(b.key for b in self.arena.order if b.shadow_lazy) if self.fuse_shadow else ()
+        key = (self.fuse_shadow, self.arena.lazy_T_shadows, self.weight_decay, lazy)
         if key != self._plan_key:
             a = self.arena
             self._segments = self._plan(a.order)
@@ -285,7 +292,7 @@ class FusedAdamW:
             self._plan_key = key
 
     def _fusable(self, b) -> bool:
-        return (self.fuse_shadow and b.shadow_kind == "T" and not self.arena.lazy_T_shadows and len(b.shape) == 2 and b.shape[0] % 64 == 0
+        return (self.fuse_shadow and b.shadow_kind == "T" and not b.shadow_lazy and not self.arena.lazy_T_shadows and len(b.shape) == 2 and b.shape[0] % 64 == 0
                 and b.shape[1] % 64 == 0 and b.offset % 8 == 0)
 
     def _plan(self, blocks):

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k128(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) gemm_store_block32(p, m0 + wm * 64 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
+        for (int j = 0; j < 2; ++j) gemm_store_block32_body<-1>(p, m0 + wm * 64 + i * 32 + l31, n0 + wn * 64 + j * 32, hi, acc[i][j]);
 }
 
 // measured on the AF3-7B decode step (ms/token): M = 1 3.85 (MFMA split-K tiles: 6.5); M = 2 6.3, M = 4 6.4, M = 8 7.6 against 5.3-5.7 on

@@ -304,6 +304,7 @@ int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
         AFK_EPI_LIST(AFK_CASE)
 #undef AFK_CASE
         default:
+            afk_count(AFK_CNT_GEMM_GENERIC);
             hipLaunchKernelGGL(gemm_nt_bf16_k256<-1>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
     }
     return AFK_OK;

@@ -361,6 +361,7 @@ int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
         AFK_EPI_LIST(AFK_CASE)
 #undef AFK_CASE
         default:
+            afk_count(AFK_CNT_GEMM_GENERIC);
             if (trans_a) hipLaunchKernelGGL((gemm_xt_bf16_k256<true, -1>), grid, dim3(512), LDS_BYTES, st, p);
             else hipLaunchKernelGGL((gemm_xt_bf16_k256<false, -1>), grid, dim3(512), LDS_BYTES, st, p);
     }

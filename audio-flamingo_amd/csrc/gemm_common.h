@@ -140,8 +140,21 @@ __device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& p, int m, i
 // halves trade registers through v_permlane32_swap so that each lane owns 8 CONSECUTIVE columns (nb + 16t + 8hi + 0..7) - 16-byte stores
 // and 16-byte bias / residual loads, half as many memory instructions as the 8-byte form.  Split-K partials keep the 4-wide form.
 // F >= 0 (specialised instantiation): the launcher guarantees p.wide and p.splits <= 1.  F = -2: split-K partial sums only.
+template <int F>
+__device__ __forceinline__ void gemm_store_block32_body(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc);
+// The runtime-flag form (F = -1: narrow stores, fp32 output, epilogues outside the training step) as ONE out-of-line function per kernel
+// image: inlined at the 8 store sites of a 256x256 wave it made the generic instantiations of the 2-waves-per-SIMD kernels spill 730 VGPRs
+// to scratch; the accumulator block travels by value in 16 VGPRs.
+static __device__ __noinline__ void gemm_store_block32_generic(const GemmArgs& p, int m, int nb, int hi, f32x16 acc) {
+    gemm_store_block32_body<-1>(p, m, nb, hi, acc);
+}
 template <int F = -1>
 __device__ __forceinline__ void gemm_store_block32(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc) {
+    if constexpr (F == -1) gemm_store_block32_generic(p, m, nb, hi, acc);
+    else gemm_store_block32_body<F>(p, m, nb, hi, acc);
+}
+template <int F>
+__device__ __forceinline__ void gemm_store_block32_body(const GemmArgs& p, int m, int nb, int hi, const f32x16& acc) {
     if (m >= p.M) return;
     if (F == -2 || (F == -1 && p.splits > 1)) {  // F = -2: split-K launch, fp32 partial sums only
 #pragma unroll

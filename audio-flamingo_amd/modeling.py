@@ -477,6 +477,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     # (a static input buffer refilled in place every step: bench.py's rotating synthetic batches, a HIP-graph-replayed step).  The row
     # indices are then remembered per tensor object regardless of its version - no device scan, no host sync per step.
     label_rows_static = False
+    label_rows_check = True   # with label_rows_static: device-side check (no sync) that the labelled-row COUNT still matches; a mismatch turns the loss into NaN
+    _rows_poison = None
 
     def _valid_rows(self, labels):
         """-> (shift_labels [B*S] on the device, rows) with rows = int64 indices (device) of the positions whose SHIFTED label is not -100,
@@ -494,10 +496,15 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             return shift, rows
         c = self._rows_cache
         if c is not None and c[0]() is labels and (c[1] == labels._version or self.label_rows_static):
+            if self.label_rows_static and c[1] != labels._version and self.label_rows_check:
+                # the promise is checked without a host sync: the number of labelled positions is compared ON THE DEVICE with the remembered
+                # count and a mismatch poisons the loss (NaN), so a batch whose labelled positions moved cannot train on stale rows silently
+                n_now = (sh != -100).sum()
+                self._rows_poison = torch.where(n_now == c[3], 0.0, float("nan")).to(torch.float32)
             return sh.contiguous(), c[2]
         rows = (sh != -100).nonzero().reshape(-1)  # host sync: the count sizes the GEMMs
         rows = rows if 0 < rows.numel() < sh.numel() else None
-        self._rows_cache = (weakref.ref(labels), labels._version, rows)
+        self._rows_cache = (weakref.ref(labels), labels._version, rows, int(rows.numel()) if rows is not None else (int((sh != -100).sum()) if self.label_rows_static else -1))
         return sh.contiguous(), rows
 
     def forward(self, input_ids=None, input_features=None, input_features_mask=None, attention_mask=None, position_ids=None,
@@ -591,6 +598,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             else:
                 denom = ops.count_valid(shift)
             loss = F_.LMHeadLossFn.apply(x, self._anchor("lm_head.weight"), a, "lm_head.weight", shift, denom, rows)
+            if self._rows_poison is not None:   # label_rows_static promise broken -> NaN loss (see _valid_rows); 0.0 otherwise
+                loss, self._rows_poison = loss + self._rows_poison, None
         def _logits(xh=x):
             xs = xh
             if isinstance(logits_to_keep, int) and logits_to_keep > 0:
@@ -599,8 +608,20 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
         if labels is None or return_logits:
             return AF3Output(loss=loss, logits=_logits(), hidden_states=hidden, audio_hidden_states=audio_hidden)
-        # labels given: the reference returns logits beside the loss (modeling_audioflamingo3.py:625-642); here they are built on first access
-        return AF3Output(loss=loss, logits_fn=_logits, hidden_states=hidden, audio_hidden_states=audio_hidden)
+        # labels given: the reference returns logits beside the loss (modeling_audioflamingo3.py:625-642); here they are built on first access -
+        # from the DETACHED final hidden states (no second autograd branch, the step's graph is not kept alive by the output object) and only while
+        # the weights are still the ones the loss was computed with: after an optimizer step the lm_head has moved, the logits would no longer
+        # belong to `loss`, and the access raises instead (forward(return_logits=True) is the in-graph, forward-time path)
+        x_keep, weights_at = x.detach(), a.version()
+
+        def _lazy_logits():
+            if a.version() != weights_at:
+                raise AfkError("output.logits was first read after the parameters changed (optimizer step / load_state_dict): lazy logits would be "
+                               "computed with other weights than output.loss; read them before the step or call forward(return_logits=True)")
+            with torch.no_grad():
+                return _logits(x_keep)
+
+        return AF3Output(loss=loss, logits_fn=_lazy_logits, hidden_states=hidden, audio_hidden_states=audio_hidden)
 
     # ------------------------------------------------------------------ generate (greedy; KV cache - SURVEY.md 8(f)-4)
     def _merged_embeddings(self, ids, input_features, input_features_mask):

@@ -669,7 +669,7 @@ def gemm_set_variant(v: int):
 
 # ---------------------------------------------------------------------------------------------- profiling
 KERNEL_FAMILIES = ("gemm_nt128", "gemm_nt256", "gemm_nn256", "gemm_tn256", "gemm_splitk", "gemv", "attn2_fwd_d64", "attn2_fwd_d128",
-                   "attn2_bwd_d64", "attn2_bwd_d128", "gqa_reduce", "xattn_fwd", "xattn_bwd", "attn1_fwd", "attn1_bwd")
+                   "attn2_bwd_d64", "attn2_bwd_d128", "gqa_reduce", "xattn_fwd", "xattn_bwd", "attn1_fwd", "attn1_bwd", "gemm_generic_epilogue")
 
 
 def kernel_counts(reset: bool = False) -> dict:

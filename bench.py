@@ -480,7 +480,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
     ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) and the 10-minute leg of the default run")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the decode leg (KV-cache generate, B = 1 and 8) and the configs[3] ICL leg of the default run")
-    ap.add_argument("--batches", type=int, default=4, help="distinct synthetic batches resident in HBM, rotated one per step (1 = the same batch every step)")
+    ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches resident in HBM, one per step (0 = warm-up + steps + 8: no batch is ever "
+                    "trained on twice inside the run, so nothing is memorised in the timed region; 1 = the same batch every step)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend for N > 1 / --force-dp: nccl = RCCL (production); "
                     "gloo = host-staged exchange, for running the N > 1 control flow with several ranks on ONE GPU (tests/test_dp_gpu.py)")
     ap.add_argument("--no-overlap", action="store_true")
@@ -561,7 +562,7 @@ def main():
     # `--batches` distinct synthetic batches live in HBM; every step trains on the next one (copied into the static input tensors the step -
     # and its HIP graph - reads).  Training the SAME batch every step (round 2) drives the loss to ~0 within the timed region: saturated
     # softmax, vanishing gradients - and on a power-limited chip operand statistics move the clock.
-    nb = max(1, args.batches)
+    nb = args.batches if args.batches > 0 else min(args.warmup + args.steps + 8, 96)
     pool = [synthetic_batch(args.batch, (rank + k * world) * args.batch, dev, windows) for k in range(nb)]
     waves, ids, labels = (t.clone() for t in pool[0])
     model.label_rows_static = True   # the labelled POSITIONS are the same in every synthetic batch; only the token values change
@@ -788,7 +789,7 @@ def main():
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
-            "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb,
+            "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb, "label_rows_static": bool(model.label_rows_static),
             "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind, "form": engine.form if engine.native is not None else "allreduce",
                                                "collectives_forced_at_world_1": bool(engine.force_collectives and world == 1),
                                                "buckets": len(model.arena.bucket_names), "bucket_bytes_max": 2 * max(e - s_ for s_, e in model.arena._bucket_ranges),

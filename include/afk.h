@@ -45,6 +45,7 @@ int afk_has_probes(void);
 #define AFK_CNT_XATTN_BWD 12
 #define AFK_CNT_ATTN1_FWD 13
 #define AFK_CNT_ATTN1_BWD 14
+#define AFK_CNT_GEMM_GENERIC 15 /* 256x256 launches served by a runtime-flag (generic-epilogue) instantiation: 0 on the AF3 training step */
 #define AFK_CNT_MAX 16
 int afk_kernel_counts(int64_t* host_out, int n);
 int afk_kernel_counts_reset(void);

@@ -17,7 +17,9 @@ Two kinds of goldens (round 3):
   "ours <= 2 x the reference's own bf16 deviation": FLOOR_FACTOR = 2 (round 2 used 4 on ONE noisy sample).  The floor is now a DISTRIBUTION:
   the reference's bf16 run on this device against its fp32 run, over N_FLOOR_SEEDS fresh seeded batches of the same kind plus the stored
   golden batch (tests/test_model_gpu.py::_floor_distribution).  Every statistic s of ours must satisfy
-        s(ours, golden batch)        <= max(absolute bar, FLOOR_FACTOR * max over batches of s(reference bf16))
+        s(ours, golden batch)        <= max(absolute bar, min(FLOOR_FACTOR * max over batches of s(reference bf16),
+                                                                  ABS_RELAX * absolute bar        [logits, loss]
+                                                                  FLOOR_FACTOR * median over batches [gradients]))      (round 4: see floor_bar)
         median over batches s(ours)  <= max(absolute bar, FLOOR_FACTOR * median over batches of s(reference bf16))
   Gradient bars are capped at GRAD_CAP; a tensor whose floor exceeds NOISE_DOMINATED on EVERY batch (the encoder's cancellation-dominated
   q_proj.bias: 5-8x its fp32 norm in the reference's own bf16 run) carries no information at bf16 on these goldens - it is reported, not
@@ -37,9 +39,19 @@ def logit_tol(ref_absmax: float) -> float:
     return LOGIT_RTOL * max(1.0, float(ref_absmax))
 
 
-def floor_bar(abs_bar: float, floor_values, cap=None) -> float:
-    """bar of a statistic given the reference-bf16 values of the same statistic over the floor batches"""
-    b = max(float(abs_bar), FLOOR_FACTOR * max(float(v) for v in floor_values))
+ABS_RELAX = 3.0        # round 4: a non-gradient statistic on the stored golden may exceed its absolute bar by at most this factor,
+                       # however large the reference's own worst bf16 batch was (a bar of 2 x floor_max was up to 25 x what it measured)
+
+
+def floor_bar(abs_bar: float, floor_values, cap=None, is_grad=False) -> float:
+    """bar of a statistic OF THE STORED GOLDEN BATCH given the reference-bf16 values of the same statistic over the floor batches.
+    The floor is heavy-tailed (reference logit-max 0.23 ... 8.4 across batches), so its MAXIMUM is no bar for one batch of ours:
+      logits / loss:  max(abs, min(FLOOR_FACTOR x floor_max, ABS_RELAX x abs))
+      gradients:      max(abs, min(FLOOR_FACTOR x floor_max, FLOOR_FACTOR x floor_median, cap))   (the typical reference batch, not its worst)"""
+    fl = [float(v) for v in floor_values]
+    relaxed = FLOOR_FACTOR * max(fl)
+    relaxed = min(relaxed, FLOOR_FACTOR * median(fl)) if is_grad else min(relaxed, ABS_RELAX * float(abs_bar))
+    b = max(float(abs_bar), relaxed)
     return b if cap is None else min(float(cap), b)
 
 

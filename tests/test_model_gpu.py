@@ -187,8 +187,9 @@ def _abs_bar(name, rep):
 
 
 def _golden_assert(rep, floor, dist):
-    """tests/_tol.py: every statistic of ours on the stored golden <= max(absolute bar, 2 x the LARGEST reference-bf16 value of that statistic
-    over the floor batches + the golden batch itself); gradient bars capped at GRAD_CAP; tensors the reference's bf16 never resolves
+    """tests/_tol.py floor_bar: every statistic of ours on the stored golden <= max(absolute bar, min(2 x the LARGEST reference-bf16 value of that
+    statistic over the floor batches + the golden batch itself, 3 x the absolute bar [logits, loss] / 2 x the floor MEDIAN [gradients]));
+    gradient bars capped at GRAD_CAP; tensors the reference's bf16 never resolves
     (floor > NOISE_DOMINATED on every batch) are reported, not asserted.  -> the table of (ours, bar, floor max) per statistic"""
     table, bad = {}, {}
     mine = _stat_table(rep, floor)
@@ -199,8 +200,9 @@ def _golden_assert(rep, floor, dist):
         if is_grad and min(fl) > NOISE_DOMINATED:
             table[name] = {"ours": v, "floor_min": min(fl), "floor_max": max(fl), "bar": None, "note": "noise-dominated at bf16 on this golden; pinned by cases D/E"}
             continue
-        bar = floor_bar(_abs_bar(name, rep), fl, cap=GRAD_CAP if is_grad else None)
-        table[name] = {"ours": v, "bar": bar, "floor_max": max(fl), "floor_median": median(fl), "ratio_to_floor_max": v / max(max(fl), 1e-12)}
+        bar = floor_bar(_abs_bar(name, rep), fl, cap=GRAD_CAP if is_grad else None, is_grad=is_grad)
+        table[name] = {"ours": v, "bar": bar, "bar_over_ours": bar / max(v, 1e-12), "floor_max": max(fl), "floor_median": median(fl),
+                       "ratio_to_floor_median": v / max(median(fl), 1e-12)}
         if v > bar:
             bad[name] = table[name]
     assert not bad, (bad, rep)

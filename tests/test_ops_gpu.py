@@ -47,13 +47,6 @@ def test_gemm_plain(dev, M, N, K):
     _cmp(f"gemm {M}x{N}x{K}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
 
 
-def _need_probes(variant):
-    """variants 3..13 are the rejected 256x256 schedules: they exist only in a `make PROBES=1` build of libafk.so"""
-    from audio_flamingo_amd import _lib
-    if variant > 2 and not _lib.has_probes():
-        pytest.skip("rejected GEMM schedule: needs a -DAFK_PROBES build (make -C audio-flamingo_amd/csrc PROBES=1)")
-
-
 def test_default_build_has_no_probe_paths(dev):
     """the shipped libafk.so refuses every probe selector of afk_gemm_set_variant (wrong-result timing probes, rejected schedules) and
     ignores AFK_ATTN_DBG: a stray value cannot corrupt results"""
@@ -68,13 +61,12 @@ def test_default_build_has_no_probe_paths(dev):
     ops.gemm_set_variant(0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 6, 10, 13])
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (300, 260, 320), (1000, 1280, 1280), (8, 512, 4096),
                                    (777, 1028, 64), (2048, 256, 2048)])
 def test_gemm_variants(dev, variant, M, N, K):
-    """all NT kernels (1: 128x128; 2: 256x256 8-wave ping-pong; probe builds only - 3: 256x256 4-wave x 128x128; 6 / 10: 256x256 8-wave free-running;
-    13: persistent tile loop) on every edge shape: K-tiles 1/2/3/many (prologue + tail waits), M/N tails, tiny M"""
-    _need_probes(variant)
+    """both NT kernels (1: 128x128; 2: 256x256 8-wave ping-pong) on every edge shape: K-tiles 1/2/3/many (prologue + tail waits), M/N tails,
+    tiny M.  (The rejected 256x256 schedules and their tests live in tools/probes/ and need a `make PROBES=1` build.)"""
     ops = _ops()
     ops.gemm_set_variant(variant)
     try:
@@ -91,33 +83,6 @@ def test_gemm_variants(dev, variant, M, N, K):
         ops.gemm_set_variant(0)
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 8192, 512), (5120, 7680, 64), (5000, 7700, 192), (8192, 9472, 1280)])
-def test_gemm_persistent_tile_loop_matches_one_tile_per_workgroup(dev, M, N, K):
-    """variant 13 (gemm256p.hip: one workgroup per CU walks 2-5 tiles, next prologue issued behind the previous tile's stores) must give
-    the ping-pong kernel's result bit for bit - same per-tile arithmetic - with every epilogue the step uses, and stay so when repeated"""
-    _need_probes(13)
-    ops = _ops()
-    a = _rand((M, K), dev, seed=31).to(BF)
-    b = _rand((N, K), dev, seed=32).to(BF)
-    bias = _rand((N,), dev, seed=33).to(BF)
-    res = _rand((M, N), dev, seed=34).to(BF)
-    outs = {}
-    for variant in (2, 13):
-        ops.gemm_set_variant(variant)
-        try:
-            pre = torch.empty((M, N), device=dev, dtype=BF)
-            outs[variant] = (ops.gemm_nt(a, b), ops.gemm_nt(a, b, bias=bias, gelu=True, preact_out=pre), pre,
-                             ops.gemm_nt(a, b, residual=res), ops.gemm_nt(a, b, out=res.clone(), accumulate=True))
-            if variant == 13:
-                for _ in range(3):
-                    assert torch.equal(ops.gemm_nt(a, b), outs[13][0]), "persistent GEMM not deterministic (LDS hand-over between tiles?)"
-        finally:
-            ops.gemm_set_variant(0)
-    for x, y in zip(outs[2], outs[13]):
-        assert torch.equal(x, y)
-    _cmp("persistent vs fp32", outs[13][0], a.float() @ b.float().t(), atol=0.02 * math.sqrt(K), rtol=1e-2)
-
-
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (304, 264, 320), (1000, 1280, 1280), (8, 512, 4096), (2048, 256, 2048)])
 def test_gemm_nn_dgrad_form(dev, M, N, K):
     """C = A[M,K] . Bt[K,N]  (B stored reduction-major, as dX = dY . W needs it)"""
@@ -128,6 +93,57 @@ def test_gemm_nn_dgrad_form(dev, M, N, K):
     _cmp(f"gemm NN {M}x{N}x{K}", c, a.float() @ bt.float(), atol=0.02 * math.sqrt(K), rtol=1e-2)
     for _ in range(3):
         assert torch.equal(ops.gemm(a, bt, trans_b=True), c), "non-deterministic NN GEMM (LDS race?)"
+
+
+@pytest.mark.parametrize("form", ["NT", "NN", "TN"])
+def test_gemm_generic_epilogue_instantiations(dev, form):
+    """the runtime-flag instantiations (<.., -1>: narrow 8-byte stores because N % 8 != 0, bias + residual + accumulate epilogues on the
+    transposed-operand kernels) - one out-of-line epilogue function per kernel since round 4 (they spilled 730 VGPRs inlined) - are counted
+    (`gemm_generic_epilogue`) and give the same values as fp32"""
+    ops = _ops()
+    M, N, K = 520, 260, 320      # N % 8 = 4: no 16-byte epilogue -> generic instantiation on every form
+    a = _rand((K, M) if form == "TN" else (M, K), dev, seed=51).to(BF)
+    b = _rand((N, K) if form == "NT" else (K, N), dev, seed=52).to(BF)
+    bias = _rand((N,), dev, seed=53).to(BF)
+    res = _rand((M, N), dev, seed=54).to(BF)
+    af = a.float().t() if form == "TN" else a.float()
+    bf = b.float().t() if form == "NT" else b.float()
+    ops.gemm_set_variant(2)      # the 256x256 kernels also for this small NT shape
+    try:
+        ops.kernel_counts(reset=True)
+        if form == "NT":
+            c = ops.gemm_nt(a, b, bias=bias, residual=res)
+        else:
+            c = ops.gemm(a, b, trans_a=form == "TN", trans_b=True, bias=bias, residual=res, _splits=1)
+        assert ops.kernel_counts()["gemm_generic_epilogue"] == 1
+        ref = (af @ bf + bias.float()).to(BF).float() + res.float()
+        _cmp(f"generic epilogue {form}", c, ref, atol=0.02 * math.sqrt(K), rtol=1e-2)
+        if form != "NT":
+            acc = ops.gemm(a, b, out=res.clone(), trans_a=form == "TN", trans_b=True, accumulate=True, _splits=1)
+            _cmp(f"generic accumulate {form}", acc, af @ bf + res.float(), atol=0.02 * math.sqrt(K), rtol=1e-2)
+        # a wide shape with the step's flags must NOT land there
+        ops.kernel_counts(reset=True)
+        a2 = _rand((K, 512) if form == "TN" else (512, K), dev, seed=55).to(BF)
+        b2 = _rand((256, K) if form == "NT" else (K, 256), dev, seed=56).to(BF)
+        ops.gemm_nt(a2, b2) if form == "NT" else ops.gemm(a2, b2, trans_a=form == "TN", trans_b=True, _splits=1)
+        assert ops.kernel_counts()["gemm_generic_epilogue"] == 0
+    finally:
+        ops.gemm_set_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(512, 768, 4096, 4), (304, 264, 8192, 16), (1000, 1280, 4096 + 192, 3), (2048, 256, 2048, 2)])
+def test_gemm_nn_splitk(dev, M, N, K, splits):
+    """the NN form with an explicit split-K plan (the lm_head dgrad's path): fp32 partials folded in fixed order, ragged last split, bias epilogue"""
+    ops = _ops()
+    a = _rand((M, K), dev, seed=41).to(BF)
+    bt = _rand((K, N), dev, seed=42).to(BF)
+    bias = _rand((N,), dev, seed=43).to(BF)
+    c = ops.gemm(a, bt, trans_b=True, bias=bias, _splits=splits)
+    _cmp(f"gemm NN split-K {M}x{N}x{K}/{splits}", c, a.float() @ bt.float() + bias.float(), atol=0.02 * math.sqrt(K), rtol=1e-2)
+    one = ops.gemm(a, bt, trans_b=True, bias=bias, _splits=1)
+    _cmp("split-K vs one pass", c, one.float(), atol=0.02 * math.sqrt(K) / 8, rtol=2e-2)
+    for _ in range(3):
+        assert torch.equal(ops.gemm(a, bt, trans_b=True, bias=bias, _splits=splits), c), "non-deterministic NN split-K GEMM"
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (512, 768, 192), (304, 264, 320), (1280, 1280, 12000), (3840, 1280, 6000), (8, 512, 100),
