@@ -24,6 +24,7 @@ Deviations from the oracle surface (documented, not silent):
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -391,16 +392,73 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             self._rope_cache[S] = (emb.cos().to(torch.bfloat16).contiguous(), emb.sin().to(torch.bfloat16).contiguous())
         return self._rope_cache[S]
 
-    # per-layer activation checkpointing (oracle: GradientCheckpointingLayer.__call__, transformers/modeling_layers.py:79-114,
-    # switched on by gradient_checkpointing_enable, modeling_utils.py:3187): each transformer layer re-runs its forward in backward
+    # Activation checkpointing (oracle: GradientCheckpointingLayer.__call__, transformers/modeling_layers.py:79-114, switched on by
+    # gradient_checkpointing_enable, modeling_utils.py:3187: EVERY transformer layer re-runs its forward in backward - the answer for 80 GB
+    # parts).  Here the switch keeps its meaning ("trade recompute for memory") but recomputes only what a memory budget requires: 288 GB of
+    # HBM3E hold the activations of a 5-minute clip outright (185 GiB), and a recomputed layer costs a third of its forward+backward time
+    # again.  Policy (gradient_checkpointing_kwargs / attributes):
+    #     memory_budget_gib = None   -> CKPT_BUDGET_FRACTION of the device's memory (0.85 x 268 GiB = 228 GiB on MI355X); env AFK_CKPT_BUDGET_GIB
+    #     policy = "budget" (default) | "full" (the reference's every-layer recompute; env AFK_CKPT_POLICY)
+    # The plan - how many of the FIRST layers of each tower are recomputed (their recompute runs last in backward, when the later layers'
+    # activations are already gone) - is made per forward from the batch geometry and what is allocated at that moment; gradients are
+    # bit-identical whatever the plan (tests/test_model_gpu.py::test_gradient_checkpointing_matches).
+    CKPT_BUDGET_FRACTION = 0.85
+
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        kw = dict(gradient_checkpointing_kwargs or {})
         self.gradient_checkpointing = True
+        self.ckpt_policy = kw.get("policy", os.environ.get("AFK_CKPT_POLICY", "budget"))
+        b = kw.get("memory_budget_gib", os.environ.get("AFK_CKPT_BUDGET_GIB"))
+        self.ckpt_budget_bytes = None if b is None else int(float(b) * 2 ** 30)
+        if self.ckpt_policy not in ("budget", "full"):
+            raise ValueError(f"gradient_checkpointing policy {self.ckpt_policy!r}: 'budget' or 'full'")
 
     def gradient_checkpointing_disable(self):
         self.gradient_checkpointing = False
 
-    def _layer(self, fn, *args):
-        if self.gradient_checkpointing and torch.is_grad_enabled():
+    ckpt_policy, ckpt_budget_bytes, ckpt_plan = "budget", None, None
+
+    def activation_bytes_per_layer(self, windows: int, dec_rows: int):
+        """bytes one encoder layer / one decoder layer keeps for backward (functional.EncoderLayerFn / DecoderLayerFn.save_for_backward):
+        encoder, per row of W x 1500: x, h, o, x2, h2 (E each), qkv (3E), fc1 pre-activation and GELU output (F each) + fp32 statistics;
+        decoder, per token: x, h, o, x2, h2 (H), qkv ((Hq + 2 Hkv) D), gate|up (2 I), SwiGLU output (I) + fp32 lse per head and statistics"""
+        ac, tc = self.config.audio_config, self.config.text_config
+        E, Fi = ac.hidden_size, ac.intermediate_size
+        enc = windows * self.max_pos * (2 * (8 * E + 2 * Fi) + 4 * (4 + self.enc_heads))
+        H, I = tc.hidden_size, tc.intermediate_size
+        dec = dec_rows * (2 * (5 * H + (self.Hq + 2 * self.Hkv) * self.D + 3 * I) + 4 * (2 + self.Hq))
+        return enc, dec
+
+    def plan_checkpointing(self, windows: int, dec_rows: int, allocated_bytes: int, total_bytes: int):
+        """-> {"enc": n, "dec": n, ...}: how many of the first layers of each tower are recomputed.  Pure host arithmetic (tested on the CPU)."""
+        enc_b, dec_b = self.activation_bytes_per_layer(windows, dec_rows)
+        if self.ckpt_policy == "full":
+            return {"enc": self.enc_layers if windows else 0, "dec": self.dec_layers, "policy": "full"}
+        budget = self.ckpt_budget_bytes if self.ckpt_budget_bytes is not None else int(self.CKPT_BUDGET_FRACTION * total_bytes)
+        # what backward needs on top of the kept activations: one layer being recomputed + one layer's worth of gradient temporaries in each tower
+        # in flight (three streams), the lm_head logits chunk and its fp32 split-K partials, allocator slack
+        V = self.config.text_config.vocab_size
+        headroom = 2 * dec_b + 2 * enc_b + 3 * F_.LMHeadLossFn.CHUNK * V * 2 + (6 << 30)
+        avail = budget - allocated_bytes - headroom
+        need = self.enc_layers * enc_b + self.dec_layers * dec_b
+        n_dec = n_enc = 0
+        if need > avail:
+            n_dec = min(self.dec_layers, -(-(need - avail) // max(dec_b, 1))) if dec_b else 0
+            need -= n_dec * dec_b
+            if need > avail and enc_b:
+                n_enc = min(self.enc_layers, -(-(need - avail) // enc_b))
+        return {"enc": int(n_enc), "dec": int(n_dec), "policy": "budget", "budget_gib": round(budget / 2 ** 30, 1),
+                "allocated_gib": round(allocated_bytes / 2 ** 30, 1), "enc_layer_gib": round(enc_b / 2 ** 30, 3), "dec_layer_gib": round(dec_b / 2 ** 30, 3)}
+
+    def _make_ckpt_plan(self, windows, dec_rows):
+        if not (self.gradient_checkpointing and torch.is_grad_enabled()):
+            self.ckpt_plan = None
+            return
+        total = torch.cuda.get_device_properties(self.device_).total_memory
+        self.ckpt_plan = self.plan_checkpointing(windows, dec_rows, torch.cuda.memory_allocated(self.device_), total)
+
+    def _layer(self, fn, *args, ckpt=True):
+        if ckpt and self.gradient_checkpointing and torch.is_grad_enabled():
             from torch.utils.checkpoint import checkpoint
 
             return checkpoint(fn, *args, use_reentrant=False)
@@ -445,9 +503,12 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         x = F_.ConvStemFn.apply(feats, self._anchor(at + "conv1.weight"), a,
                                 (at + "conv1.weight", at + "conv1.bias", at + "conv2.weight", at + "conv2.bias"),
                                 self.embed_positions.data, W, T, C)
+        if self.ckpt_plan is None or self.ckpt_plan.get("_windows") != W:   # stand-alone call (forward() plans both towers before it gets here)
+            self._make_ckpt_plan(W, 0)
+        n_ck = self.enc_layers if self.ckpt_plan is None else self.ckpt_plan["enc"]
         for i in range(self.enc_layers):
             p = f"{at}layers.{i}."
-            x = self._layer(F_.EncoderLayerFn.apply, x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len)
+            x = self._layer(F_.EncoderLayerFn.apply, x, self._anchor(p + "fc1.weight"), a, p, W, T2, self.enc_heads, kv_len, ckpt=i < n_ck)
         T3 = T2 // 2
         x = F_.PoolNormFn.apply(x, self._anchor(at + "layer_norm.weight"), a, at + "layer_norm.weight", at + "layer_norm.bias", W * T3)
         x = self._post_encoder(x, W, T3, n_tok, input_ids)
@@ -531,6 +592,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             B, S = ids.shape
             ids_flat = ids.reshape(-1).contiguous()
         audio, src = None, None
+        # checkpoint plan of BOTH towers from the batch geometry, before the first layer allocates anything (memory-budgeted recompute)
+        self._make_ckpt_plan(0 if input_features is None else int(input_features.shape[0]), B * S)
+        if self.ckpt_plan is not None:
+            self.ckpt_plan["_windows"] = 0 if input_features is None else int(input_features.shape[0])
         if input_features is not None:
             audio, n_tok = self.get_audio_features(input_features.to(self.device_), input_features_mask, input_ids=ids)
             src, cnt = ops.placeholder_scan(ids_flat, self.audio_token_id)
@@ -582,7 +647,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
             x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
-                            self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo)
+                            self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo, ckpt=self.ckpt_plan is None or i < self.ckpt_plan["dec"])
             if want_hidden and i + 1 < self.dec_layers:
                 hidden.append(x.reshape(B, S, -1))
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)

@@ -76,15 +76,16 @@ def synthetic_batch(batch, first_idx, device, windows=1):
 
 
 def train_flops_per_sample(S=S_TOK, windows=1, recompute=False):
-    """algorithmic FLOPs (2*MACs, causal attention at 1/2), forward x 3; recompute=True adds the checkpointed layers' second
-    forward (x 4 on the layer stacks) - reported separately as hardware FLOPs, never as model FLOPs"""
-    enc_l = 32 * (2 * 1500 * (4 * 1280 ** 2 + 2 * 1280 * 5120) + 4 * 1500 ** 2 * 1280)
+    """algorithmic FLOPs (2*MACs, causal attention at 1/2), forward x 3; recompute adds the checkpointed layers' second
+    forward (x 4 on those layers) - reported separately as hardware FLOPs, never as model FLOPs.  recompute: False | True (every layer) |
+    (n_enc, n_dec) = how many layers of each tower the memory-budgeted plan recomputes"""
+    enc_1 = 2 * 1500 * (4 * 1280 ** 2 + 2 * 1280 * 5120) + 4 * 1500 ** 2 * 1280
     enc = windows * (2 * 3000 * 128 * 3 * 1280 + 2 * 1500 * 1280 * 3 * 1280)
     proj = windows * 2 * 750 * (1280 * 3584 + 3584 * 3584)
-    dec = 28 * (2 * S * (2 * 3584 ** 2 + 2 * 3584 * 512 + 3 * 3584 * 18944) + 2 * S ** 2 * 3584)
+    dec_1 = 2 * S * (2 * 3584 ** 2 + 2 * 3584 * 512 + 3 * 3584 * 18944) + 2 * S ** 2 * 3584
     lm = 2 * S * 3584 * 152064
-    layers = windows * enc_l + dec
-    return 3.0 * (enc + proj + lm) + (4.0 if recompute else 3.0) * layers
+    n_enc, n_dec = (32, 28) if recompute is True else (0, 0) if not recompute else recompute
+    return 3.0 * (enc + proj + lm) + windows * enc_1 * (3.0 * 32 + n_enc) + dec_1 * (3.0 * 28 + n_dec)
 
 
 def _layer_flops():
@@ -719,14 +720,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ldt = float(t.item())
         model.gradient_checkpointing_disable()
+        plan = {k: v for k, v in (model.ckpt_plan or {}).items() if not k.startswith("_")}
         ls = 9 + N_AUDIO_TOK * lw["windows"] + 9 + N_ANSWER
         sps = world * lw["batch"] * 3 / ldt
-        res_ = {"workload": f"AF3-7B bf16 train step, {label} = {lw['windows']} windows/sample, S={ls}, micro-batch {lw['batch']}/GPU, per-layer "
-                            "activation checkpointing ON", "ms_per_step": 1000.0 * ldt / 3, "steps": 3, "warmup": 2,
+        res_ = {"workload": f"AF3-7B bf16 train step, {label} = {lw['windows']} windows/sample, S={ls}, micro-batch {lw['batch']}/GPU, "
+                            f"activation checkpointing ON (memory-budgeted: {plan.get('enc')}/32 encoder + {plan.get('dec')}/28 decoder layers recomputed "
+                            f"under a {plan.get('budget_gib')} GiB budget; policy 'full' = the reference's every-layer recompute)",
+                "ms_per_step": 1000.0 * ldt / 3, "steps": 3, "warmup": 2,
                 "value": sps * CLIP_SECONDS * lw["windows"], "unit": "audio-s/s", "decoder_tokens_per_s": sps * ls,
                 "model_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"]) * sps / world / 1e12,
-                "hardware_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"], True) * sps / world / 1e12,
-                "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
+                "hardware_tflops_per_gpu": train_flops_per_sample(ls, lw["windows"], (plan.get("enc", 32), plan.get("dec", 28))) * sps / world / 1e12,
+                "checkpoint_plan": plan, "peak_mem_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1)}
         data["waves"], data["ids"], data["labels"] = waves, ids, labels
         return res_
 
@@ -769,11 +773,13 @@ def main():
             traffic_detail.setdefault("stale", []).append({"file": os.path.relpath(tpath, ROOT), "measured_on_build": tj.get("afk_build_id", "unstamped (round 2)"),
                                                             "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")})
         model_tf = train_flops_per_sample(s_tok, windows) * samples_per_s / world / 1e12 if full_model else None
-        hw_tf = train_flops_per_sample(s_tok, windows, ckpt) * samples_per_s / world / 1e12 if full_model else None
+        plan = {k: v for k, v in (model.ckpt_plan or {}).items() if not k.startswith("_")} if ckpt else None
+        rc = (plan.get("enc", 32), plan.get("dec", 28)) if plan else bool(ckpt)     # layers the memory-budgeted plan really recomputed
+        hw_tf = train_flops_per_sample(s_tok, windows, rc) * samples_per_s / world / 1e12 if full_model else None
         # lm_head + loss (forward, dgrad, wgrad) run only on the rows that carry a label: identical loss and gradients, fewer executed FLOPs.
         # model_tflops stays ALGORITHMIC (the reference's 3 x forward over every row); executed = what the kernels really did.
         skipped = 3.0 * 2 * (s_tok - N_ANSWER) * 3584 * 152064 if model.loss_on_valid_rows_only else 0.0
-        exec_tf = (train_flops_per_sample(s_tok, windows, ckpt) - skipped) * samples_per_s / world / 1e12 if full_model else None
+        exec_tf = (train_flops_per_sample(s_tok, windows, rc) - skipped) * samples_per_s / world / 1e12 if full_model else None
         res = {
             "metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train",
             "value": samples_per_s * CLIP_SECONDS * windows, "unit": "audio-s/s",
@@ -782,10 +788,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ((("AF3 (AF-Whisper 32L + Qwen2.5-7B 28L, MLP projector) bf16 train step fwd+bwd+AdamW, 30 s clips, S=1024" if windows == 1 else
                                       f"AF3-7B bf16 train step fwd+bwd+AdamW, LONG AUDIO: 5-min clips = {windows} windows/sample, S={s_tok}, "
-                                      f"per-layer activation checkpointing {'ON' if ckpt else 'OFF'} (BASELINE configs[4])")) if full_model
+                                      f"activation checkpointing {'ON (memory-budgeted plan: ' + str(plan) + ')' if ckpt else 'OFF'} (BASELINE configs[4])")) if full_model
                                     else f"DEPTH-REDUCED AF3 ({args.enc_layers} enc + {args.dec_layers} dec layers) - not the BASELINE config"),
                        "micro_batch_per_gpu": args.batch, "global_batch": args.batch * world, "seq_len": s_tok, "audio_tokens": n_audio_tok,
-                       "windows_per_sample": windows, "activation_checkpointing": ckpt, "max_grad_norm": args.clip if args.clip > 0 else None,
+                       "windows_per_sample": windows, "activation_checkpointing": ckpt, "checkpoint_plan": plan, "max_grad_norm": args.clip if args.clip > 0 else None,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,

@@ -387,3 +387,32 @@ def test_dp_flags_and_adamw_launch_plans():
     m.arena.lazy_T_shadows = False
     blk = m.arena["lm_head.weight"]
     assert blk.shadow_lazy is False
+
+
+def test_checkpoint_planner_recomputes_only_what_the_budget_requires():
+    """memory-budgeted recompute (oracle switch: GradientCheckpointingLayer, modeling_layers.py:79-114): host arithmetic
+    of the plan on the AF3-7B geometry - a 5-minute clip fits 228 GiB outright, a 10-minute clip recomputes part of the decoder, a small
+    budget falls back to the reference's every-layer recompute"""
+    import bench
+
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    m = Mine.__new__(Mine)   # geometry only: no arena, no device
+    cfg = bench.af3_7b_config()
+    ac, tc = cfg.audio_config, cfg.text_config
+    m.config, m.enc_layers, m.dec_layers, m.max_pos, m.enc_heads = cfg, ac.num_hidden_layers, tc.num_hidden_layers, ac.max_source_positions, ac.num_attention_heads
+    m.Hq, m.Hkv, m.D = tc.num_attention_heads, tc.num_key_value_heads, tc.hidden_size // tc.num_attention_heads
+    m.ckpt_policy, m.ckpt_budget_bytes = "budget", None
+    total = 288 * 10 ** 9
+    resident = int(139.5 * 2 ** 30)          # parameters + gradients + AdamW state + W^T shadows of the 7B model (DESIGN.md section 2)
+    enc5, dec5 = m.activation_bytes_per_layer(10, 7774)
+    assert 0.055e9 * 10 < enc5 < 0.07e9 * 10 and 1.2e9 < dec5 < 1.3e9, (enc5, dec5)      # 61 MB per window-layer, 1.23 GB per decoder layer
+    p5 = m.plan_checkpointing(10, 7774, resident, total)
+    assert (p5["enc"], p5["dec"]) == (0, 0), p5
+    p10 = m.plan_checkpointing(20, 15274, resident, total)
+    assert p10["enc"] == 0 and 0 < p10["dec"] < 28, p10
+    m.ckpt_budget_bytes = 150 * 2 ** 30
+    tight = m.plan_checkpointing(20, 15274, resident, total)
+    assert tight["dec"] == 28 and tight["enc"] == 32, tight
+    m.ckpt_policy = "full"
+    assert m.plan_checkpointing(10, 7774, resident, total)["dec"] == 28

@@ -707,17 +707,41 @@ def test_generate_left_padded_batch_matches_single(dev):
 
 
 def test_gradient_checkpointing_matches(dev):
-    """per-layer recompute (oracle row a19) must not change loss or gradients"""
+    """recompute (oracle row a19) must not change loss or gradients, whatever the plan: the reference's every-layer recompute ("full"), the
+    memory-budgeted default (which recomputes nothing when the batch fits the budget) and a budget so tight that only part of each tower is
+    recomputed - all bit-identical to the step that keeps every activation"""
     g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
     kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
-    ma, mb = _model(dev), _model(dev)
-    mb.gradient_checkpointing_enable()
-    ma.zero_grad(), mb.zero_grad()
-    la, lb = ma(**kw).loss, mb(**kw).loss
-    la.backward(), lb.backward()
+    ma = _model(dev)
+    ma.zero_grad()
+    la = ma(**kw).loss
+    la.backward()
     torch.cuda.synchronize()
-    assert float(la) == float(lb)
-    assert torch.equal(ma.arena.grads, mb.arena.grads)
+    plans = {}
+    for name, ck in (("full", dict(policy="full")), ("budget", None), ("partial", "partial")):
+        mb = _model(dev)
+        if ck == "partial":
+            # a budget that leaves room for about half of the activations: headroom + allocated + 1.5 encoder layers + 1 decoder layer
+            mb.gradient_checkpointing_enable()
+            W, rows = int(kw["input_features"].shape[0]), int(kw["input_ids"].numel())
+            enc_b, dec_b = mb.activation_bytes_per_layer(W, rows)
+            full_need = mb.enc_layers * enc_b + mb.dec_layers * dec_b
+            V = mb.config.text_config.vocab_size
+            headroom = 2 * dec_b + 2 * enc_b + 3 * 4096 * V * 2 + (6 << 30)
+            mb.ckpt_budget_bytes = int(torch.cuda.memory_allocated(dev) + headroom + full_need // 2 + (8 << 20))
+        else:
+            mb.gradient_checkpointing_enable(ck)
+        mb.zero_grad()
+        lb = mb(**kw).loss
+        lb.backward()
+        torch.cuda.synchronize()
+        plans[name] = {k: v for k, v in mb.ckpt_plan.items() if not k.startswith("_")}
+        assert float(la) == float(lb), name
+        assert torch.equal(ma.arena.grads, mb.arena.grads), name
+    assert plans["full"]["enc"] == 2 and plans["full"]["dec"] == 2, plans
+    assert plans["budget"]["enc"] == 0 and plans["budget"]["dec"] == 0, plans        # the tiny batch fits: nothing is recomputed
+    assert 0 < plans["partial"]["enc"] + plans["partial"]["dec"] < 4, plans             # part of the layers only
+    REPORT["gradient_checkpointing_plans"] = plans
 
 
 def test_long_audio_shape_config5_like(dev):
