@@ -47,6 +47,7 @@ struct AttnArgs2 {
     int causal;
     int dbg;          // AFK_ATTN_DBG experiments: read only in -DAFK_PROBES builds (AFK_DBG below), ignored otherwise
     int split_heads;  // dK/dV sweep: one block per QUERY head, partial dK/dV per query head (GQA), reduced afterwards
+    int wide;         // 16-byte epilogue stores are legal (every output pointer / stride keeps 16-byte alignment)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -71,6 +72,36 @@ __device__ __forceinline__ float other_half(float x) {
     return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
 }
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// Epilogue store of one 32 (rows) x 32 (columns) MFMA result block, row-per-lane: lane (l31, hi) holds its row's columns 8q + 4hi + {0..3} in
+// accumulator registers 4q..4q+3, i.e. four 8-byte pieces 16 bytes apart.  WIDE: the two lane halves (same row) trade registers through
+// v_permlane32_swap so that each lane owns 8 CONSECUTIVE columns (16t + 8hi + 0..7): two 16-byte stores instead of four 8-byte ones.  The
+// store tail of these short blocks is issue-bound (MI355X_MICROARCH: row-per-lane stores at a row stride; halving the instruction count at
+// equal bytes halves it), and at S = 1024 a block lives for only 2-16 key tiles.  rowp = &out[row][32-column block].
+template <bool WIDE>
+__device__ __forceinline__ void store_block32(bf16* rowp, const f32x16& acc, float mul, int hi) {
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[8 * t + e]), __float_as_uint(acc[8 * t + 4 + e]), false, false);
+                o[e] = (bf16)(__uint_as_float(r[0]) * mul);       // lo lanes: own q = 2t;       hi lanes: partner's q = 2t + 1
+                o[4 + e] = (bf16)(__uint_as_float(r[1]) * mul);   // lo lanes: partner's q = 2t; hi lanes: own q = 2t + 1
+            }
+            *(bf16x8*)(rowp + 16 * t + 8 * hi) = o;
+        }
+    } else {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[4 * qd + e] * mul);
+            *(bf16x4*)(rowp + 8 * qd + 4 * hi) = o;
+        }
+    }
+}
 
 template <int D>
 __device__ __forceinline__ int swz(int r) {
@@ -332,17 +363,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         l += other_half(l);
         const float inv = (l > 0.f) ? 1.f / l : 0.f;
         bf16* Op = p.O + b * p.o_bs + h * p.o_hs + (int64_t)q * p.o_rs;
+        if (p.wide) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt) store_block32<true>(Op + dt * 32, oacc[dt], inv, hi);
+        } else {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(oacc[dt][4 * qd + e] * inv);
-                *(bf16x4*)(Op + dt * 32 + 8 * qd + 4 * hi) = o;
-            }
+            for (int dt = 0; dt < DT; ++dt) store_block32<false>(Op + dt * 32, oacc[dt], inv, hi);
+        }
         // internal to the v2 kernels: MINUS the log-sum-exp in SCORE units, P = 2^(c2 (S + LSE)); +inf for a row that saw no key
         if (hi == 0 && p.LSE) p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = (l > 0.f) ? -(m + __log2f(l)) / c2 : INFINITY;
+    } else if (hi == 0 && p.LSE && q < p.Spad) {
+        p.LSE[((int64_t)b * p.Hq + h) * p.Spad + q] = 0.f;   // padding tail [S, Spad) of a ragged last tile: the dK/dV sweep reads whole 64-query strips (no host-side fill)
     }
 }
 
@@ -392,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         }
         acc += other_half(acc);
         ndlt = -acc;   // stored negated: the backward kernels start the dP accumulators from it
-        if (hi == 0 && q < p.S) const_cast<float*>(p.delta)[((int64_t)b * p.Hq + h) * p.Spad + q] = ndlt;
+        if (hi == 0 && q < p.Spad) const_cast<float*>(p.delta)[((int64_t)b * p.Hq + h) * p.Spad + q] = (q < p.S) ? ndlt : 0.f;   // the tail [S, Spad) must read zero
     } else {
         ndlt = p.delta[((int64_t)b * p.Hq + h) * p.Spad + qc];      // stored negated (attn2_delta_kernel)
     }
@@ -512,15 +543,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     }
     if (q < p.S) {
         bf16* dQp = p.dQ + b * p.dq_bs + h * p.dq_hs + (int64_t)q * p.dq_rs;
+        if (p.wide) {   // (softmax scale folded out of dS)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt) store_block32<true>(dQp + dt * 32, dqacc[dt], p.scale, hi);
+        } else {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(dqacc[dt][4 * qd + e] * p.scale);  // softmax scale folded out of dS
-                *(bf16x4*)(dQp + dt * 32 + 8 * qd + 4 * hi) = o;
-            }
+            for (int dt = 0; dt < DT; ++dt) store_block32<false>(dQp + dt * 32, dqacc[dt], p.scale, hi);
+        }
     }
 }
 
@@ -807,19 +836,19 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     if (key < p.S) {
         bf16* dKp = p.dK + b * p.dk_bs + hy * p.dk_hs + (int64_t)key * p.dk_rs;
         bf16* dVp = p.dV + b * p.dv_bs + hy * p.dv_hs + (int64_t)key * p.dv_rs;
+        if (p.wide) {   // (softmax scale folded out of dS)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                bf16x4 ok, ov;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ok[e] = (bf16)(dkacc[dt][4 * qd + e] * p.scale);  // softmax scale folded out of dS
-                    ov[e] = (bf16)dvacc[dt][4 * qd + e];
-                }
-                *(bf16x4*)(dKp + dt * 32 + 8 * qd + 4 * hi) = ok;
-                *(bf16x4*)(dVp + dt * 32 + 8 * qd + 4 * hi) = ov;
+            for (int dt = 0; dt < DT; ++dt) {
+                store_block32<true>(dKp + dt * 32, dkacc[dt], p.scale, hi);
+                store_block32<true>(dVp + dt * 32, dvacc[dt], 1.f, hi);
             }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                store_block32<false>(dKp + dt * 32, dkacc[dt], p.scale, hi);
+                store_block32<false>(dVp + dt * 32, dvacc[dt], 1.f, hi);
+            }
+        }
     }
     if (probe) {
         // block timeline on the 100 MHz clock: entry -> loop start -> loop end -> stores retired, + the CU the block ran on
@@ -889,6 +918,12 @@ __global__ __launch_bounds__(256) void gqa_reduce_kernel(const bf16* __restrict_
     }
 }
 
+// AFK_ATTN_WIDE=0: the 8-byte epilogue stores of rounds 1-3 (A/B)
+bool attn_wide_stores() {
+    static const bool on = [] { const char* e = getenv("AFK_ATTN_WIDE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <typename K>
 int set_lds(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 1;
@@ -896,7 +931,8 @@ int set_lds(K kern, int bytes) {
 
 }  // namespace
 
-// LSE / delta rows are Spad long (multiple of 64, zero-initialised by the host) so that the kernels can use aligned float4 reads.
+// LSE / delta rows are Spad long (multiple of 64) so that the kernels can use aligned float4 reads; the tail [S, Spad) reads zero: afk_attn2_fwd
+// and afk_attn2_bwd_fused write it themselves (round 4), afk_attn2_delta does not - its caller clears the delta tail.
 extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
                              int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
                              int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
@@ -914,6 +950,7 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     AFK_REQUIRE(!kv_lo || causal, "afk_attn2_fwd: kv_lo (left padding) is defined for causal attention only");
     p.LSE = LSE; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    p.wide = attn_wide_stores() && (uintptr_t)O % 16 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 && o_rs % 8 == 0;
     dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
     afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
@@ -984,6 +1021,9 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
         if (dbg) p.dbg = atoi(dbg);
     }
 #endif
+    auto al16 = [](const void* ptr, int64_t bs, int64_t hs, int64_t rs) { return (uintptr_t)ptr % 16 == 0 && bs % 8 == 0 && hs % 8 == 0 && rs % 8 == 0; };
+    p.wide = attn_wide_stores() && al16(dQ, dq_bs, dq_hs, dq_rs) && al16(dK, dk_bs, dk_hs, dk_rs) && al16(dV, dv_bs, dv_hs, dv_rs) &&
+             (!split || ((uintptr_t)gqa_scratch % 16 == 0 && D % 8 == 0));
     AttnArgs2 pk = p;
     if (split) {
         pk.split_heads = 1;

@@ -11,13 +11,22 @@
 //   RMSNorm    (Qwen2RMSNorm.forward, modeling_qwen2.py:247-252; eps 1e-6): x32 = float(x);
 //              xh = bf16(x32 * rsqrt(mean(x32^2)+eps));  y = bf16(w * xh)   (cast BEFORE the weight multiply).
 // Weight/bias gradients are reduced in two stages: each block keeps fp32 partial column sums for the rows it
-// visited and writes one partial row to a workspace [nblocks, 2, D]; afk_colsum_partials folds them.
+// visited and writes one partial row to a workspace [nblocks, 2, D]; fold_partials_kernel folds them.
+//
+// Backward, round 4 (norm_bwd_cols_kernel, D % 8 == 0): the row-per-wave form above needs the whole row AND fp32 dw/db partials of the
+// whole row in every lane's registers (246 VGPRs at D = 3584: two waves per SIMD, one row at a time, two dependent HBM round trips per
+// row - 3.2 TB/s).  The column-owned form turns the block by 90 degrees: thread t owns the 8 columns 8t..8t+7 of EVERY row the block
+// visits (one 16-byte vector per tensor and row), so the dw/db partials are 8 + 8 registers, a group of R = 4 rows is 12 independent
+// 16-byte loads per thread issued back to back (x, dy, dx_add), and the per-row statistics (sum of g, sum of g*xh over D) go through one
+// wave reduction + one LDS exchange + ONE barrier per group (double-buffered strip).  No cross-wave fold of the partials at the end: a
+// column lives in exactly one thread.
 #include "common.h"
 #include "../../include/afk.h"
 
 namespace {
 
 constexpr int ROWS_PER_BLOCK = 4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // VW = elements per lane-vector: 8 (16-byte accesses, 1 KiB per wave-instruction) whenever D % 8 == 0, else 4
 template <int VPL, bool RMS, int VW>
@@ -255,6 +264,135 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
     }
 }
 
+// Column-owned backward (see the header).  blockDim.x = D / 8 rounded up to whole waves; R rows per group.
+template <bool RMS, bool ADD, int R>
+__global__ __launch_bounds__(512, 3) void norm_bwd_cols_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const bf16* __restrict__ dy,
+                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                             bf16* __restrict__ dx, const bf16* __restrict__ dx_add, float* __restrict__ partials,
+                                                             int64_t rows, int D) {
+    constexpr int NS = RMS ? R : 2 * R;                      // statistics per group: sum(g * xh) [, sum(g)] per row
+    __shared__ float red[2][16][NS];                         // [parity][wave][stat]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = threadIdx.x * 8;
+    const bool live = col < D;
+    const int colc = live ? col : D - 8;
+    const float invD = 1.f / (float)D;
+    float wf[8], pw[8], pb[8];
+    {
+        const bf16x8 wt = *(const bf16x8*)(w + colc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wf[e] = (float)wt[e];
+            pw[e] = pb[e] = 0.f;
+        }
+    }
+    const int64_t ngroups = (rows + R - 1) / R;
+    int par = 0;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
+        const int64_t r0 = g * R;
+        bf16x8 xv[R], dv[R], av[R];
+        float mean[R], rstd[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = min(r0 + r, rows - 1);       // block-uniform clamp: a ragged last group re-reads the last row, its results are dropped
+            // branch-free: lanes beyond D (the last wave of a block, D / 8 not a multiple of 64) read the row's last vector and drop it
+            xv[r] = *(const bf16x8*)(x + row * D + colc);
+            dv[r] = *(const bf16x8*)(dy + row * D + colc);
+            if (ADD) av[r] = *(const bf16x8*)(dx_add + row * D + colc);
+            if (!live) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dv[r][e] = (bf16)0.f;   // g = 0: contributes nothing to the row statistics
+            }
+            mean[r] = RMS ? 0.f : mean_in[row];
+            rstd[r] = rstd_in[row];
+        }
+        float st[NS];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool valid = r0 + r < rows;                // block-uniform
+            float sgx = 0.f, sg = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)dv[r][e];
+                const float xh = ((float)xv[r][e] - mean[r]) * rstd[r];
+                const float gg = d * wf[e];
+                sgx += gg * xh;
+                sg += gg;
+                if (valid) {
+                    pw[e] += d * (RMS ? rbf(xh) : xh);
+                    if (!RMS) pb[e] += d;
+                }
+            }
+            st[r] = sgx;
+            if (!RMS) st[R + r] = sg;
+            __builtin_amdgcn_sched_barrier(0);   // one row's fp32 expansion at a time: interleaving the four rows costs 60 more VGPRs (a wave per SIMD)
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) st[i] = wave_sum(st[i]);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) red[par][wv][i] = st[i];
+        }
+        // opaque to the optimiser: the second pass re-derives xh / g from the PACKED rows instead of keeping 64 fp32 values of the first pass
+        // alive across the barrier (184-228 VGPRs -> two waves per SIMD; the point of this kernel is many loads in flight)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            asm volatile("" : "+v"(*(u32x4*)&xv[r]));
+            asm volatile("" : "+v"(*(u32x4*)&dv[r]));
+        }
+        __syncthreads();   // one barrier per group: the strip of the NEXT group is the other parity, and a wave can only get two groups ahead by passing the next barrier
+        float tot[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) tot[i] = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < nw; ++k) {                        // fixed order: bit-reproducible
+#pragma unroll
+            for (int i = 0; i < NS; ++i) tot[i] += red[par][k][i];
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (r0 + r >= rows) break;
+                const float sgx = tot[r] * invD, sg = RMS ? 0.f : tot[R + r] * invD;
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)xv[r][e] - mean[r]) * rstd[r];
+                    const float gg = (float)dv[r][e] * wf[e];
+                    float v = rstd[r] * (gg - sg - xh * sgx);
+                    if (ADD) v = rbf(v) + (float)av[r][e];   // fused residual-gradient merge: dx = bf16(norm-branch) + skip-branch
+                    o[e] = (bf16)v;
+                }
+                *(bf16x8*)(dx + (r0 + r) * D + col) = o;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // this block's partial row: partials[block][0][D] = dw, [1][D] = db - each column written by its one owner
+    if (live) {
+        float* outp = partials + (int64_t)blockIdx.x * 2 * D + col;
+        *(f32x4*)(outp) = f32x4{pw[0], pw[1], pw[2], pw[3]};
+        *(f32x4*)(outp + 4) = f32x4{pw[4], pw[5], pw[6], pw[7]};
+        if (!RMS) {
+            *(f32x4*)(outp + D) = f32x4{pb[0], pb[1], pb[2], pb[3]};
+            *(f32x4*)(outp + D + 4) = f32x4{pb[4], pb[5], pb[6], pb[7]};
+        }
+    }
+}
+
+// rows per group of the column-owned backward: 2 by default (99-109 VGPRs: four waves per SIMD = two 7-wave blocks per CU at D = 3584);
+// AFK_NORM_BWD_R=4 selects the 4-row groups of the RMSNorm instantiation (139-157 VGPRs, one 7-wave block per CU) for A/B runs
+int norm_bwd_rows_per_group(bool rms) {
+    static const int r = [] { const char* e = getenv("AFK_NORM_BWD_R"); return (e && e[0] == '4') ? 4 : 2; }();
+    return rms ? r : 2;
+}
+int norm_bwd_cols_blocks(int64_t rows, int D, bool rms) {
+    // wide rows (448 threads = 7 waves at D = 3584): two blocks per CU; narrow rows (3 waves at D = 1280): four
+    const int64_t cap = (D / 8 > 256) ? 512 : 1024;
+    const int64_t g = afk_cdiv(rows, norm_bwd_rows_per_group(rms));
+    return (int)(g < cap ? g : cap);
+}
+
 int norm_grid(int64_t rows) {
     int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
     if (g > 2048) g = 2048;
@@ -284,6 +422,22 @@ int launch_fwd(const void* x, const void* w, const void* b, void* y, float* mean
 }
 
 template <bool RMS>
+int launch_bwd_cols(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
+                    const void* dx_add, float* partials, int nblocks, int64_t rows, int D, hipStream_t st) {
+    const int nt = (int)afk_cdiv(D / 8, 64) * 64;
+#define AFK_NBC(ADD, R)                                                                                                                            \
+    hipLaunchKernelGGL((norm_bwd_cols_kernel<RMS, ADD, R>), dim3(nblocks), dim3(nt), 0, st, (const bf16*)x, (const bf16*)w, (const bf16*)dy, mean, \
+                       rstd, (bf16*)dx, (const bf16*)dx_add, partials, rows, D)
+    if (RMS && norm_bwd_rows_per_group(true) == 4) {
+        if (dx_add) AFK_NBC(true, (RMS ? 4 : 2)); else AFK_NBC(false, (RMS ? 4 : 2));
+    } else {
+        if (dx_add) AFK_NBC(true, 2); else AFK_NBC(false, 2);
+    }
+#undef AFK_NBC
+    return AFK_OK;
+}
+
+template <bool RMS>
 int launch_bwd(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx,
                const void* dx_add, float* partials, int nblocks, int64_t rows, int D, hipStream_t st) {
 #define AFK_NB(V, W)                                                                                                 \
@@ -304,11 +458,26 @@ int launch_bwd(const void* x, const void* w, const void* dy, const float* mean, 
 
 }  // namespace
 
+// upper bound of the partial rows either backward form writes (the workspace is sized with it)
 extern "C" int afk_norm_bwd_blocks(int64_t rows) {
+    int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
+    if (g > 1024) g = 1024;
+    return (int)g;
+}
+static int norm_bwd_rowwave_blocks(int64_t rows) {
     int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
     if (g > 512) g = 512;
     return (int)g;
 }
+// AFK_NORM_BWD=rows restores the row-per-wave form (A/B)
+static bool norm_bwd_use_cols(int D) {
+    static const bool rows_form = [] { const char* e = getenv("AFK_NORM_BWD"); return e && e[0] == 'r'; }();
+    return !rows_form && D % 8 == 0 && D / 8 <= 512;
+}
+#define AFK_NORM_BWD_ALIGN(name)                                                                                                               \
+    AFK_REQUIRE((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dx_add % 16 == 0 && (uintptr_t)w % 16 == 0 && \
+                    (uintptr_t)dw % 8 == 0 && (uintptr_t)workspace % 16 == 0,                                                               \
+                name ": x / dy / dx / dx_add / w / workspace must be 16-byte aligned, dw / db 8-byte aligned (vector accesses)")
 
 extern "C" int afk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                                  int64_t rows, int D, float eps, void* stream) {
@@ -332,10 +501,14 @@ extern "C" int afk_layernorm_bwd(const void* x, const void* w, const void* dy, c
                                  void* dx, const void* dx_add, void* dw, void* db, int accumulate, float* workspace,
                                  int64_t rows, int D, void* stream) {
     AFK_REQUIRE(x && w && dy && mean && rstd && dx && dw && db && workspace, "afk_layernorm_bwd: null pointer");
-    AFK_REQUIRE(D % 4 == 0 && D <= 3584 && rows > 0, "afk_layernorm_bwd: unsupported D=%d", D);
-    const int nb = afk_norm_bwd_blocks(rows);
+    AFK_REQUIRE(D % 4 == 0 && D <= 4096 && (D <= 3584 || D % 8 == 0) && rows > 0, "afk_layernorm_bwd: unsupported D=%d", D);
+    AFK_NORM_BWD_ALIGN("afk_layernorm_bwd");
+    AFK_REQUIRE((uintptr_t)db % 8 == 0, "afk_layernorm_bwd: db must be 8-byte aligned");
+    const bool cols = norm_bwd_use_cols(D);
+    const int nb = cols ? norm_bwd_cols_blocks(rows, D, false) : norm_bwd_rowwave_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
-    launch_bwd<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    if (cols) launch_bwd_cols<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    else launch_bwd<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 64), 2), dim3(256), 0, st, workspace, nb, D, 2 * D, (bf16*)dw, (bf16*)db,
                        accumulate);
     AFK_LAUNCH_CHECK("afk_layernorm_bwd");
@@ -346,10 +519,13 @@ extern "C" int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
                                const void* dx_add, void* dw, int accumulate, float* workspace, int64_t rows, int D,
                                void* stream) {
     AFK_REQUIRE(x && w && dy && rstd && dx && dw && workspace, "afk_rmsnorm_bwd: null pointer");
-    AFK_REQUIRE(D % 4 == 0 && D <= 3584 && rows > 0, "afk_rmsnorm_bwd: unsupported D=%d", D);
-    const int nb = afk_norm_bwd_blocks(rows);
+    AFK_REQUIRE(D % 4 == 0 && D <= 4096 && (D <= 3584 || D % 8 == 0) && rows > 0, "afk_rmsnorm_bwd: unsupported D=%d", D);
+    AFK_NORM_BWD_ALIGN("afk_rmsnorm_bwd");
+    const bool cols = norm_bwd_use_cols(D);
+    const int nb = cols ? norm_bwd_cols_blocks(rows, D, true) : norm_bwd_rowwave_blocks(rows);
     hipStream_t st = (hipStream_t)stream;
-    launch_bwd<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    if (cols) launch_bwd_cols<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
+    else launch_bwd<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 64), 1), dim3(256), 0, st, workspace, nb, D, 2 * D, (bf16*)dw, (bf16*)nullptr,
                        accumulate);
     AFK_LAUNCH_CHECK("afk_rmsnorm_bwd");

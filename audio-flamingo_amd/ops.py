@@ -454,12 +454,13 @@ def embed_scatter_bwd(ids, src, dout, d_embed, d_audio, perm=None):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def _row_stat_buffer(B, H, S, spad, device):
-    """fp32 [B, H, spad] per-query statistic (lse, delta) of the LDS-staged attention kernels.  The kernels write every query < S; only the
-    padding tail [S, spad) of a ragged last tile must read as zero - so nothing is filled when S is a multiple of 64 (the decoder's 1 024:
-    one fill launch per attention call saved), and only the tail otherwise."""
+def _row_stat_buffer(B, H, S, spad, device, kernel_writes_tail=True):
+    """fp32 [B, H, spad] per-query statistic (lse, delta) of the LDS-staged attention kernels.  The kernels write every query < S, and the
+    padding tail [S, spad) of a ragged last tile must read as zero: afk_attn2_fwd (lse) and afk_attn2_bwd_fused (delta) write that tail
+    themselves since round 4 - no fill launch at all (the encoder's S = 1500 paid two ATen fills per attention call: 64 of the ~96 per step);
+    only the separate delta pass (afk_attn2_delta) leaves it to the host."""
     t = torch.empty((B, H, spad), device=device, dtype=torch.float32)
-    if spad > S:
+    if spad > S and not kernel_writes_tail:
         t[:, :, S:].zero_()
     return t
 
@@ -514,7 +515,7 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, k
     dk = dqkv[:, Hq * D:]
     dv = dqkv[:, (Hq + Hkv) * D:]
     if _use_lds(D) and lse.shape[-1] == spad:
-        delta = _row_stat_buffer(B, Hq, S, spad, dev)
+        delta = _row_stat_buffer(B, Hq, S, spad, dev, kernel_writes_tail=ATTN_FUSE_DELTA)
         scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
         if ATTN_FUSE_DELTA:   # delta = rowsum(dO o O) inside the dQ kernel, which runs ahead of the dK/dV sweep: one pass over O and dO less
             _lib.call("afk_attn2_bwd_fused", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,

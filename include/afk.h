@@ -106,7 +106,8 @@ int afk_gemm_bf16_splitk(int trans_a, int trans_b, const void* A, int64_t lda, c
  * LayerNorm: nn.LayerNorm(eps=1e-5) at modeling_audioflamingo3.py:207,212 (per layer) and :335,403 (final).
  * RMSNorm:   Qwen2RMSNorm.forward, modeling_qwen2.py:247-252 (eps 1e-6, cast to bf16 BEFORE the weight multiply).
  * bwd: dx = norm-branch grad (+ dx_add if non-null: fused residual-gradient merge); dw/db (bf16) are
- * overwritten or accumulated; workspace = afk_norm_bwd_blocks(rows) * 2 * D floats. */
+ * overwritten or accumulated; workspace = afk_norm_bwd_blocks(rows) * 2 * D floats.  Alignment (vector accesses): x, dy, dx, dx_add, w and
+ * the workspace 16 bytes, dw / db 8 bytes; D % 8 == 0 takes the column-owned kernel (D <= 4096), D % 4 == 0 the row-per-wave form (D <= 3584). */
 int afk_norm_bwd_blocks(int64_t rows);
 int afk_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd,
                       int64_t rows, int D, float eps, void* stream);

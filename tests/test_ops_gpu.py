@@ -285,6 +285,47 @@ def test_rmsnorm(dev, rows, D):
     _cmp("rms dw", dw, wr.grad, atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
 
 
+@pytest.mark.parametrize("kind,rows,D", [("rms", 8192, 3584), ("ln", 12000, 1280), ("rms", 4099, 3584), ("ln", 3001, 1280), ("rms", 70, 100), ("ln", 70, 100)])
+def test_norm_bwd_training_shapes(dev, kind, rows, D):
+    """the backward kernels at the shapes the training step launches them with (decoder RMSNorm 8192 x 3584, encoder LayerNorm 12000 x 1280:
+    several row groups per block, ragged last group), with the fused residual-gradient merge and gradient accumulation, against fp32 torch;
+    D = 100 (D % 8 != 0) takes the row-per-wave form.  Repeated launches are bit-identical (fixed-order reductions)."""
+    ops = _ops()
+    x = _rand((rows, D), dev, 2.0, 1).to(BF)
+    w = (1 + 0.1 * _rand((D,), dev, seed=2)).to(BF)
+    b = (0.1 * _rand((D,), dev, seed=3)).to(BF)
+    dy = _rand((rows, D), dev, 1.0, 4).to(BF)
+    skip = _rand((rows, D), dev, 1.0, 5).to(BF)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    if kind == "ln":
+        y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-5)
+        torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5).backward(dy.float())
+    else:
+        y, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+        (wr * (xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6))).backward(dy.float())
+    base = (0.5 * _rand((D,), dev, seed=6)).to(BF)
+
+    def run():
+        dw, db = base.clone(), base.clone()
+        if kind == "ln":
+            dx = ops.layernorm_bwd(x, w, dy, mean, rstd, dw, db, dx_add=skip, accumulate=True)
+        else:
+            dx = ops.rmsnorm_bwd(x, w, dy, rstd, dw, dx_add=skip, accumulate=True)
+        return dx, dw, db
+
+    dx, dw, db = run()
+    _cmp(f"{kind} dx+skip", dx, xr.grad + skip.float(), atol=4e-2, rtol=2e-2)
+    _cmp(f"{kind} dw acc", dw, wr.grad + base.float(), atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
+    if kind == "ln":
+        _cmp("ln db acc", db, br.grad + base.float(), atol=0.02 * math.sqrt(rows) + 0.05, rtol=2e-2)
+    # the column sums are sharp too: relative L2 error of the whole dw vector well under a percent
+    rel = float((dw.float() - (wr.grad + base.float())).norm() / (wr.grad + base.float()).norm())
+    assert rel < 5e-3, rel
+    for _ in range(2):
+        dx2, dw2, db2 = run()
+        assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2), "norm backward not bit-deterministic"
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def test_gelu_silu_rope_misc(dev):
     ops = _ops()
