@@ -103,6 +103,24 @@ __device__ __forceinline__ void store_block32(bf16* rowp, const f32x16& acc, flo
     }
 }
 
+// Buffer parity of a tile: DynPar = run-time (boundary tiles, the odd tile in front of the unrolled interior loop), StaticPar<P> = compile time
+// - the interior loops are unrolled by two so that EVERY LDS address of a tile is "lane-constant register + immediate" (the buffer offset folded
+// into the 16-bit ds offset field): the run-time form paid 16 v_add_u32 per 64-key tile for it (round 4, ISA count).
+struct DynPar { int par; };
+template <int P> struct StaticPar { static constexpr int par = P; };
+template <typename T> struct is_static_par : std::false_type {};
+template <int P> struct is_static_par<StaticPar<P>> : std::true_type {};
+template <typename P>
+__host__ __device__ constexpr int par_static_off(int bytes) {   // compile-time part of the buffer offset (0 for DynPar)
+    if constexpr (is_static_par<P>::value) return P::par * bytes;
+    else return 0;
+}
+template <typename P>
+__device__ __forceinline__ uint32_t par_dyn_off(const P& p, int bytes) {   // run-time part (0 for StaticPar)
+    if constexpr (is_static_par<P>::value) return 0u;
+    else return (uint32_t)(p.par * bytes);
+}
+
 template <int D>
 __device__ __forceinline__ int swz(int r) {
     if (D == 128) return ((r & 3) << 2) | ((r >> 2) & 3);
@@ -189,7 +207,11 @@ struct Tile {
     } while (0)
 constexpr float RESCALE_THR = 8.f;  // log2 domain
 
-template <int D>
+// LM (round 4): the row sum l comes out of the matrix pipe - one more accumulator block fed with an all-ones A fragment against the SAME
+// probability fragments (l = P^T . 1: every row of the block equals the per-query sum over the tile's keys, it accumulates over tiles and takes
+// the lazy rescale like O).  4 MFMAs per tile replace 29 VALU adds (the kernels are VALU-co-limited: at head_dim 64 the softmax arithmetic
+// per score is the same as at 128 with half the MFMA work), and the normaliser is the sum of the bf16-ROUNDED probabilities that P.V uses.
+template <int D, bool LM>
 __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
     constexpr int KS = T::KS, DT = T::DT;
@@ -222,7 +244,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
-    float m = NEG_INF, l = 0.f;  // running (possibly stale) max in the log2 domain; row sum of THIS lane half
+    float m = NEG_INF, l = 0.f;  // running (possibly stale) max in the log2 domain; row sum of THIS lane half (LM: lacc instead)
+    f32x16 lacc = zero16();
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.f;
     const float c2 = p.scale * LOG2E;
 
     const int kv_end_blk = p.causal ? min(kv_len, min(qb0 + 128, p.S)) : kv_len;  // keys any row of the block can see
@@ -244,31 +270,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     };
     // interior form: lane-constant source pointers of tile 0, advanced by whole tiles (no per-tile address arithmetic beyond one
     // 64-bit add per piece); only legal while all 64 rows of the staged tile exist
+    // per-lane part of every source address = a tile-independent 32-bit byte offset (row r of the tile, swizzled chunk); the tile part is wave-uniform:
+    // scalar base + VGPR offset addressing, no per-tile address VALU (the 64-bit per-lane pointers of rounds 1-3 cost 16 v_lshl_add_u64 per tile)
     constexpr int NP = T::UNITS / 4;
-    const bf16* ksrc[NP];
-    const bf16* vsrc[NP];
+    uint32_t koff[NP], voff[NP];
 #pragma unroll
     for (int u0 = 0; u0 < NP; ++u0) {
         const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
-        ksrc[u0] = Kbase + (int64_t)r * p.k_rs + chunk * 8;
-        vsrc[u0] = Vbase + (int64_t)r * p.v_rs + chunk * 8;
+        koff[u0] = (uint32_t)(r * (int)p.k_rs + chunk * 8) * 2u;
+        voff[u0] = (uint32_t)(r * (int)p.v_rs + chunk * 8) * 2u;
     }
-    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
     auto stage_fast = [&](int j) {
-        char* buf = smem + (j & 1) * 2 * T::BYTES;
+        const uint32_t buf = lds0 + (j & 1) * 2 * T::BYTES + wave * 1024;
+        const bf16* k0 = Kbase + (int64_t)j * 64 * p.k_rs;
+        const bf16* v0 = Vbase + (int64_t)j * 64 * p.v_rs;
 #pragma unroll
         for (int u0 = 0; u0 < NP; ++u0) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(ksrc[u0] + j * kstep), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc[u0] + j * vstep), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
         }
     };
     const int n_full = p.S >> 6;  // tiles whose 64 rows all exist
 
-    // one 64-key tile.  MASKED: per-element visibility (key < kv_len, causal key <= q) is applied to the scores.
-    auto tile = [&](int j, auto masked_) {
+    // one 64-key tile.  MASKED: per-element visibility (key < kv_len, causal key <= q) is applied to the scores.  par_: DynPar / StaticPar<P>.
+    auto tile = [&](int j, auto masked_, auto par_) {
         constexpr bool MASKED = decltype(masked_)::value;
-        const char* kimg = smem + (j & 1) * 2 * T::BYTES;
-        const uint32_t boff = (j & 1) * 2 * T::BYTES;
+        constexpr int POFF = par_static_off<decltype(par_)>(2 * T::BYTES);           // compile-time buffer offset (folded into the ds offset fields)
+        const uint32_t boff = par_dyn_off(par_, 2 * T::BYTES);                        // run-time buffer offset
+        const char* kimg = smem + POFF + boff;
         f32x16 st[2] = {zero16(), zero16()};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         auto issue = [&](auto g_, bf16x8(&dst)[4]) {
             constexpr int dt = decltype(g_)::value;
             const uint32_t a0 = vtr[dt][0] + boff, a1 = vtr[dt][1] + boff;
-            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<s4 * 16 * T::RS>(a0, a1); });
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<POFF + s4 * 16 * T::RS>(a0, a1); });
         };
         issue(std::integral_constant<int, 0>{}, fa);
         if (MASKED) {
@@ -303,7 +332,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
             asm volatile("" ::);  // keeps this a real (almost never taken) branch: the compiler would otherwise speculate the O rescale
             const float m_new = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f(m - ((m_new == NEG_INF) ? 0.f : m_new));  // m = -inf -> 0
-            l *= alpha;
+            if (LM) lacc[0] *= alpha;   // only register 0 of the all-equal-rows block is ever read
+            else l *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -321,11 +351,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
                 const f32x2 s2 = {st[kt2][r], st[kt2][r + 1]};
                 const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, nmv);
                 const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-                rs2 += p2;
+                if (!LM) rs2 += p2;
                 pb[2 * kt2 + (r >> 3)][r & 7] = (bf16)p2[0];
                 pb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
             }
-        l += rs2[0] + rs2[1];
+        if (!LM) l += rs2[0] + rs2[1];
+        if (LM) {   // l += sum over the tile's 64 keys of the (bf16) probabilities: rows of the ones fragment x P - ahead of the V^T ring, no LDS operand
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) lacc = MFMA(ones, pb[s4], lacc);
+        }
         afk_frag_ring<DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
             constexpr int dt = decltype(g_)::value;
 #pragma unroll
@@ -340,27 +374,42 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     int j = j0;
     for (; j < min(j_int0, ntiles); ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     const int n_fast = min(n_int, n_full - 1);  // tile j+1 must be a full tile for the pointer form of the prefetch
+    if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
+        stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{1});
+        AFK_ATTN_BARRIER();
+        ++j;
+    }
+    for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
+        stage_fast(j + 1);
+        tile(j, std::false_type{}, StaticPar<0>{});
+        AFK_ATTN_BARRIER();
+        stage_fast(j + 2);
+        tile(j + 1, std::false_type{}, StaticPar<1>{});
+        AFK_ATTN_BARRIER();
+    }
     for (; j < n_fast; ++j) {
         stage_fast(j + 1);
-        tile(j, std::false_type{});
+        tile(j, std::false_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));  // a redundant re-stage of the last tile lands in the other buffer and is never read
-        tile(j, std::false_type{});
+        tile(j, std::false_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     for (; j < ntiles; ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});  // wave-uniform
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});  // wave-uniform
         AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
-        l += other_half(l);
+        if (LM) l = lacc[0];              // the full-row sum already (the MFMA reduced over all 64 keys of a tile): no lane-half fold
+        else l += other_half(l);
         const float inv = (l > 0.f) ? 1.f / l : 0.f;
         bf16* Op = p.O + b * p.o_bs + h * p.o_hs + (int64_t)q * p.o_rs;
         if (p.wide) {
@@ -451,30 +500,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         T::stage(buf, Kbase, p.k_rs, j * 64, p.S - 1, wave, lane);
         T::stage(buf + T::BYTES, Vbase, p.v_rs, j * 64, p.S - 1, wave, lane);
     };
-    constexpr int NP = T::UNITS / 4;
-    const bf16* ksrc[NP];
-    const bf16* vsrc[NP];
+    constexpr int NP = T::UNITS / 4;   // scalar base + per-lane 32-bit offset (see the forward kernel)
+    uint32_t koff[NP], voff[NP];
 #pragma unroll
     for (int u0 = 0; u0 < NP; ++u0) {
         const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
-        ksrc[u0] = Kbase + (int64_t)r * p.k_rs + chunk * 8;
-        vsrc[u0] = Vbase + (int64_t)r * p.v_rs + chunk * 8;
+        koff[u0] = (uint32_t)(r * (int)p.k_rs + chunk * 8) * 2u;
+        voff[u0] = (uint32_t)(r * (int)p.v_rs + chunk * 8) * 2u;
     }
-    const int64_t kstep = 64 * p.k_rs, vstep = 64 * p.v_rs;
     auto stage_fast = [&](int j) {
-        char* buf = smem + (j & 1) * 2 * T::BYTES;
+        const uint32_t buf = lds0 + (j & 1) * 2 * T::BYTES + wave * 1024;
+        const bf16* k0 = Kbase + (int64_t)j * 64 * p.k_rs;
+        const bf16* v0 = Vbase + (int64_t)j * 64 * p.v_rs;
 #pragma unroll
         for (int u0 = 0; u0 < NP; ++u0) {
-            __builtin_amdgcn_global_load_lds((gbl_void*)(ksrc[u0] + j * kstep), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc[u0] + j * vstep), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
         }
     };
 
-    auto tile = [&](int j, auto masked_) {
+    auto tile = [&](int j, auto masked_, auto par_) {
         constexpr bool MASKED = decltype(masked_)::value;
-        const char* kimg = smem + (j & 1) * 2 * T::BYTES;
+        constexpr int POFF = par_static_off<decltype(par_)>(2 * T::BYTES);
+        const uint32_t boff = par_dyn_off(par_, 2 * T::BYTES);
+        const char* kimg = smem + POFF + boff;
         const char* vimg = kimg + T::BYTES;
-        const uint32_t boff = (j & 1) * 2 * T::BYTES;
         f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -487,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         auto issue = [&](auto g_, bf16x8(&dst)[4]) {
             constexpr int dt = decltype(g_)::value;
             const uint32_t a0 = ktr[dt][0] + boff, a1 = ktr[dt][1] + boff;
-            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<s4 * 16 * T::RS>(a0, a1); });
+            afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<POFF + s4 * 16 * T::RS>(a0, a1); });
         };
         issue(std::integral_constant<int, 0>{}, fa);
         const f32x2 c2v = {c2, c2}, nl = {nlse, nlse}, nd = {ndlt, ndlt};
@@ -522,23 +572,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     int j = j0;
     for (; j < min(j_int0, ntiles); ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     const int n_fast = min(n_int, n_full - 1);
+    if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
+        stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{1});
+        AFK_ATTN_BARRIER();
+        ++j;
+    }
+    for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
+        stage_fast(j + 1);
+        tile(j, std::false_type{}, StaticPar<0>{});
+        AFK_ATTN_BARRIER();
+        stage_fast(j + 2);
+        tile(j + 1, std::false_type{}, StaticPar<1>{});
+        AFK_ATTN_BARRIER();
+    }
     for (; j < n_fast; ++j) {
         stage_fast(j + 1);
-        tile(j, std::false_type{});
+        tile(j, std::false_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));
-        tile(j, std::false_type{});
+        tile(j, std::false_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     for (; j < ntiles; ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
         AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
@@ -636,12 +700,13 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
         const bf16* qb = p.Q + b * p.q_bs + h * p.q_hs;
         const bf16* dob = p.dO + b * p.do_bs + h * p.do_hs;
         if (qt < n_full) {
-            const char* q0 = (const char*)(qb + (int64_t)qt * 64 * p.q_rs);
-            const char* d0 = (const char*)(dob + (int64_t)qt * 64 * p.do_rs);
+            const bf16* q0 = qb + (int64_t)qt * 64 * p.q_rs;
+            const bf16* d0 = dob + (int64_t)qt * 64 * p.do_rs;
+            const uint32_t dst = lds0 + slot * BUF + wave * 1024;
 #pragma unroll
-            for (int u0 = 0; u0 < NP; ++u0) {
-                __builtin_amdgcn_global_load_lds((gbl_void*)(q0 + qoff[u0]), (lds_void*)(buf + (wave + 4 * u0) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((gbl_void*)(d0 + dooff[u0]), (lds_void*)(buf + T::BYTES + (wave + 4 * u0) * 1024), 16, 0, 0);
+            for (int u0 = 0; u0 < NP; ++u0) {   // scalar base + per-lane 32-bit offset, issued as asm: no address VALU (common.h afk_dma16_saddr)
+                afk_dma16_saddr(q0, qoff[u0], dst + 4 * u0 * 1024);
+                afk_dma16_saddr(d0, dooff[u0], dst + T::BYTES + 4 * u0 * 1024);
             }
         } else {
             T::stage(buf, qb, p.q_rs, qt * 64, p.S - 1, wave, lane);
@@ -954,17 +1019,23 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
     afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
+    // row sum on the matrix pipe (kernel template LM): default at head_dim 64, where the kernel is VALU-bound with the matrix pipe a third busy;
+    // AFK_ATTN_LSUM=0 / 1 forces it off / on for both head sizes (A/B)
+    static const int lsum_env = [] { const char* e = getenv("AFK_ATTN_LSUM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool lm = lsum_env < 0 ? D == 64 : lsum_env == 1;
+#define AFK_FWD(DD, LM_)                                                                      \
+    do {                                                                                      \
+        constexpr int L = 4 * Tile<DD>::BYTES;                                                \
+        static int once = set_lds(attn_fwd_lds_kernel<DD, LM_>, L);                           \
+        (void)once;                                                                           \
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<DD, LM_>), grid, dim3(256), L, st, p);        \
+    } while (0)
     if (D == 128) {
-        constexpr int L = 4 * Tile<128>::BYTES;
-        static int once = set_lds(attn_fwd_lds_kernel<128>, L);
-        (void)once;
-        hipLaunchKernelGGL(attn_fwd_lds_kernel<128>, grid, dim3(256), L, st, p);
+        if (lm) AFK_FWD(128, true); else AFK_FWD(128, false);
     } else {
-        constexpr int L = 4 * Tile<64>::BYTES;
-        static int once = set_lds(attn_fwd_lds_kernel<64>, L);
-        (void)once;
-        hipLaunchKernelGGL(attn_fwd_lds_kernel<64>, grid, dim3(256), L, st, p);
+        if (lm) AFK_FWD(64, true); else AFK_FWD(64, false);
     }
+#undef AFK_FWD
     AFK_LAUNCH_CHECK("afk_attn2_fwd");
     return AFK_OK;
 }

@@ -170,3 +170,35 @@ extern "C" int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, i
     AFK_NCCL(Broadcast(buf, buf, (size_t)n, t, root, c->comm, (hipStream_t)stream), "ncclBroadcast");
     return AFK_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------- CU-contention probe (pre-flight of the 8-GPU run)
+// RCCL's collective kernels are persistent workgroups, one per channel, that hold their CU for the whole collective.  A 256x256 GEMM workgroup
+// needs an ENTIRE CU (128 KiB of LDS, 8 waves x 256 registers), so every CU a channel sits on is a CU the GEMM rounds lose: 4 736 tiles run 18.5
+// rounds on 256 CUs and 19.7 on 240.  Without a second GPU the exchange cannot be run, but its footprint can: afk_cu_hog parks `nblocks`
+// workgroups (64 threads + `lds_bytes` of LDS each: above 32 KiB no GEMM workgroup fits beside one) on the stream until *stop_flag becomes non-zero
+// (or max_ticks of the 100 MHz clock pass).  bench.py --hog-cus N times the training step beside it; tools/cu_contention.py sweeps N.
+namespace {
+__global__ __launch_bounds__(64) void cu_hog_kernel(const int* stop_flag, long long max_ticks) {
+    extern __shared__ char hog_lds[];
+    if (threadIdx.x == 0) hog_lds[0] = 0;   // the allocation is what matters
+    unsigned long long start;
+    asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(start)::"memory");
+    while (true) {
+        if (__hip_atomic_load(stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // system scope: the writer ran on another XCD (L2s are not coherent with each other)
+        unsigned long long now;
+        asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+        if ((long long)(now - start) > max_ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+}  // namespace
+
+extern "C" int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, void* stream) {
+    AFK_REQUIRE(nblocks > 0 && nblocks <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && stop_flag && max_ticks > 0, "afk_cu_hog: bad arguments");
+    static int once = hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : 1;
+    (void)once;
+    hipLaunchKernelGGL(cu_hog_kernel, dim3((unsigned)nblocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, stop_flag, (long long)max_ticks);
+    AFK_LAUNCH_CHECK("afk_cu_hog");
+    return AFK_OK;
+}

@@ -83,6 +83,16 @@ __device__ __forceinline__ bf16x8 afk_lds_b128(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
+// LDS-DMA of 16 bytes per lane in the SCALAR-BASE form: source = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset (VGPR),
+// destination = wave-uniform LDS byte address + 16 x lane (M0).  The builtin (__builtin_amdgcn_global_load_lds) always takes a 64-bit per-lane
+// pointer: hipcc zero-extends the offset into a VGPR PAIR and adds the base with one v_lshl_add_u64 per piece - 16 VALU instructions and 16 extra
+// VGPRs per 64-key attention tile for addresses whose per-lane part never changes.  Issued as asm the piece costs no VALU at all.  The caller owns
+// the wait (counted s_waitcnt vmcnt + barrier before the image is read), exactly as with the builtin in these kernels; compiler-inserted vmcnt waits
+// for its own loads can only over-wait because of the extra (unknown to it) operations in the in-order queue.
+__device__ __forceinline__ void afk_dma16_saddr(const void* wave_uniform_base, uint32_t lane_byte_offset, uint32_t lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_dst) : "memory", "m0");
+}
+
 template <int N>
 __device__ __forceinline__ void afk_lgkmcnt() {
     static_assert(N >= 0 && N <= 15, "lgkmcnt is a 4-bit counter");

@@ -245,7 +245,7 @@ extern "C" int afk_gemm_set_variant(int v) {
     // -DAFK_PROBES builds only (gm bit 6: no epilogue = WRONG results, bit 7: raw dispatch order; base 3..13: gemm256w4 / f8 / p.hip).
     const int gm = (v >> 8) & 255, base = v & 15;
 #ifdef AFK_PROBES
-    AFK_REQUIRE(base >= 0 && base <= 13, "afk_gemm_set_variant: 13 = 256x256 ping-pong as a persistent tile loop, 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
+    AFK_REQUIRE(base >= 0 && base <= 14, "afk_gemm_set_variant: 14 = persistent tile loop with the next tile's prologue issued ahead of the epilogue stores (round-4 probe), 13 = 256x256 ping-pong as a persistent tile loop, 0 auto, 1 = 128x128, 2 = 256x256 8-wave ping-pong, 3 = 256x256 4-wave (4, 5: its timing probes), 6 = 256x256 8-wave free-running BK=64 (7, 8, 9: probes), 10 = 8-wave free-running BK=32 ring-10 (11: probe)");
 #else
     AFK_REQUIRE(base >= 0 && base <= 2, "afk_gemm_set_variant: variant %d is a probe / rejected schedule; this libafk.so was built without -DAFK_PROBES (make PROBES=1)", base);
     AFK_REQUIRE((gm & 0xc0) == 0, "afk_gemm_set_variant: gm bits 6 / 7 are timing probes (wrong results); this libafk.so was built without -DAFK_PROBES");
@@ -352,6 +352,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     const bool w4 = use256 && !trans_b && impl256 >= 3 && impl256 <= 9;
     const bool f8 = use256 && !trans_b && impl256 >= 10 && impl256 <= 12;
     const bool persist = use256 && !trans_b && impl256 == 13;
+    const bool persist_q = use256 && !trans_b && impl256 == 14;
 #endif
     // SWIGLU_FWD is implemented by gemm_nt_bf16_k256<AFK_GEMM_SWIGLU_FWD> alone, which needs the 16-byte epilogue form: refuse instead of
     // falling through to an instantiation that would leave preact_out unwritten
@@ -401,7 +402,7 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
         }
     } else if (use256) {
 #ifdef AFK_PROBES
-        if (int e = persist ? afk_launch_gemm256p(p, st) : f8 ? afk_launch_gemm256f8(p, impl256 - 10, st) : w4 ? afk_launch_gemm256w4(p, impl256 - 3, st) : afk_launch_gemm256(p, st)) return e;
+        if (int e = persist_q ? afk_launch_gemm256q(p, st) : persist ? afk_launch_gemm256p(p, st) : f8 ? afk_launch_gemm256f8(p, impl256 - 10, st) : w4 ? afk_launch_gemm256w4(p, impl256 - 3, st) : afk_launch_gemm256(p, st)) return e;
 #else
         if (int e = afk_launch_gemm256(p, st)) return e;
 #endif

@@ -193,7 +193,8 @@ __device__ __forceinline__ void gemm_store_block32_body(const GemmArgs& p, int m
 
 // 256x256 ping-pong kernel (gemm256.hip)
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st);
-int afk_launch_gemm256p(const GemmArgs& p, hipStream_t st);  // persistent tile loop (gemm256p.hip)
+int afk_launch_gemm256p(const GemmArgs& p, hipStream_t st);  // persistent tile loop (tools/probes/gemm256p.hip)
+int afk_launch_gemm256q(const GemmArgs& p, hipStream_t st);  // persistent tile loop, next tile's prologue ahead of the epilogue stores (tools/probes/gemm256q.hip)
 // 256x256, K-step 32, eight free-running waves, ten-slot LDS ring (gemm256f8.hip); mode 1 = no-DMA timing probe
 int afk_launch_gemm256f8(const GemmArgs& p, int mode, hipStream_t st);
 // 256x256 four-wave kernel, 128x128 per wave, accumulators in AGPRs (gemm256w4.hip)

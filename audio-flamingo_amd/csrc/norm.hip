@@ -20,6 +20,7 @@
 // 16-byte loads per thread issued back to back (x, dy, dx_add), and the per-row statistics (sum of g, sum of g*xh over D) go through one
 // wave reduction + one LDS exchange + ONE barrier per group (double-buffered strip).  No cross-wave fold of the partials at the end: a
 // column lives in exactly one thread.
+#include <algorithm>
 #include "common.h"
 #include "../../include/afk.h"
 
@@ -460,7 +461,7 @@ int launch_bwd(const void* x, const void* w, const void* dy, const float* mean, 
 
 // upper bound of the partial rows either backward form writes (the workspace is sized with it)
 extern "C" int afk_norm_bwd_blocks(int64_t rows) {
-    int64_t g = afk_cdiv(rows, ROWS_PER_BLOCK);
+    int64_t g = afk_cdiv(rows, 2);   // the column-owned form runs one block per 2-row group (cap 512 / 1024), the row-per-wave form one per 4 rows (cap 512)
     if (g > 1024) g = 1024;
     return (int)g;
 }
@@ -505,7 +506,7 @@ extern "C" int afk_layernorm_bwd(const void* x, const void* w, const void* dy, c
     AFK_NORM_BWD_ALIGN("afk_layernorm_bwd");
     AFK_REQUIRE((uintptr_t)db % 8 == 0, "afk_layernorm_bwd: db must be 8-byte aligned");
     const bool cols = norm_bwd_use_cols(D);
-    const int nb = cols ? norm_bwd_cols_blocks(rows, D, false) : norm_bwd_rowwave_blocks(rows);
+    const int nb = std::min(cols ? norm_bwd_cols_blocks(rows, D, false) : norm_bwd_rowwave_blocks(rows), afk_norm_bwd_blocks(rows));
     hipStream_t st = (hipStream_t)stream;
     if (cols) launch_bwd_cols<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
     else launch_bwd<false>(x, w, dy, mean, rstd, dx, dx_add, workspace, nb, rows, D, st);
@@ -522,7 +523,7 @@ extern "C" int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, con
     AFK_REQUIRE(D % 4 == 0 && D <= 4096 && (D <= 3584 || D % 8 == 0) && rows > 0, "afk_rmsnorm_bwd: unsupported D=%d", D);
     AFK_NORM_BWD_ALIGN("afk_rmsnorm_bwd");
     const bool cols = norm_bwd_use_cols(D);
-    const int nb = cols ? norm_bwd_cols_blocks(rows, D, true) : norm_bwd_rowwave_blocks(rows);
+    const int nb = std::min(cols ? norm_bwd_cols_blocks(rows, D, true) : norm_bwd_rowwave_blocks(rows), afk_norm_bwd_blocks(rows));
     hipStream_t st = (hipStream_t)stream;
     if (cols) launch_bwd_cols<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);
     else launch_bwd<true>(x, w, dy, nullptr, rstd, dx, dx_add, workspace, nb, rows, D, st);

@@ -490,6 +490,9 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient branch on the compute stream")
     ap.add_argument("--force-dp", action="store_true", help="run the data-parallel engine even with one rank AND issue its collectives (identity at world 1): the whole RCCL path on a 1-GPU box")
     ap.add_argument("--dp-graph", action="store_true", help="data parallel: capture the step - RCCL collectives included - into the HIP graph (default for N > 1: eager enqueue)")
+    ap.add_argument("--cu-contention", default="", help="pre-flight of the multi-GPU run (VERDICT r03 item 5a): comma-separated CU counts, e.g. 0,8,16,32,64 - "
+                    "for each, park that many persistent workgroups on a side stream (afk_cu_hog: what RCCL's channel kernels do to the GEMM rounds) and time "
+                    "5 steps beside them; reported as cu_contention {n: ms_per_step}")
     ap.add_argument("--no-settle", action="store_true", help="do not wait for the driver to release a previous process's VRAM (tests)")
     ap.add_argument("--dry-run-cpu", action="store_true", help="CONTROL-FLOW TEST ONLY (tests/test_host_cpu.py): no GPU, no kernels - the N > 1 sequence of this script "
                     "(process group, parameter broadcast, per-bucket exchange in backward order, replica checksum, one JSON line on rank 0) with a stub in place of the step")
@@ -734,6 +737,34 @@ def main():
         data["waves"], data["ids"], data["labels"] = waves, ids, labels
         return res_
 
+    # CU-contention sweep (before the legs below change the model's mode): the graphed / overlapped step beside n parked workgroups
+    cu_contention = None
+    if args.cu_contention and not use_dp:
+        from audio_flamingo_amd import _lib
+        cu_contention = {}
+        hog_stream = torch.cuda.Stream(device=dev)
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        for n_hog in [int(x) for x in args.cu_contention.split(",") if x.strip() != ""]:
+            flag.zero_()
+            fence()
+            if n_hog > 0:   # 64 KiB of LDS per parked workgroup: a 128 KiB GEMM workgroup cannot share its CU; at most 30 s (100 MHz ticks)
+                _lib.call("afk_cu_hog", n_hog, 64 * 1024, flag.data_ptr(), 3_000_000_000, hog_stream.cuda_stream)
+            load_next()
+            run()                      # one step for the parked workgroups to settle on their CUs
+            torch.cuda.current_stream().synchronize()
+            t_h = time.perf_counter()
+            for _ in range(5):
+                load_next()
+                run()
+            torch.cuda.current_stream().synchronize()
+            if overlap is not None:
+                model.arena.join_streams()
+                torch.cuda.current_stream().synchronize()
+            cu_contention[str(n_hog)] = round(1000.0 * (time.perf_counter() - t_h) / 5, 2)
+            flag.fill_(1)              # from the MAIN stream (a fill on the hog stream would queue behind the parked kernel)
+            fence()
+        print(f"[bench] cu_contention (ms/step beside n parked CUs): {cu_contention}", file=sys.stderr, flush=True)
+
     long_audio = long_10min = None
     if args.workload == "clip30" and full_model and not args.no_long_audio:
         long_audio = long_leg("long5min", "5-min clips (BASELINE configs[4])")
@@ -801,7 +832,7 @@ def main():
                                                "buckets": len(model.arena.bucket_names), "bucket_bytes_max": 2 * max(e - s_ for s_, e in model.arena._bucket_ranges),
                                                "bucket_bytes_total": 2 * model.arena.total, "overlapped_with_backward": overlap is not None or engine.overlap,
                                                "collectives_per_step": len(model.arena.bucket_names) + 1},
-            "long_audio_configs4": long_audio, "long_audio_10min": long_10min, "decode": decode,
+            "long_audio_configs4": long_audio, "long_audio_10min": long_10min, "decode": decode, "cu_contention_ms_per_step": cu_contention,
             "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
             "host_enqueue_ms_idle_gpu": round(1000.0 * host_enqueue_idle, 1),
             "waited_for_free_hbm_s": waited,

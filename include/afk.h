@@ -322,6 +322,10 @@ int afk_comm_destroy(void* comm);
 int afk_allreduce_bucket(void* comm, void* buf, int64_t n, int dtype, int op_max, void* stream);
 int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream);
 int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, void* stream);
+/* CU-contention probe (pre-flight of the multi-GPU run; models the CUs RCCL's persistent channel kernels take from the GEMM rounds - reference
+ * behaviour being prepared for: TORCH/nn/parallel/distributed.py:1012,1442): parks `nblocks` workgroups of 64 threads + lds_bytes of LDS on `stream`
+ * until *stop_flag (device memory) becomes non-zero or max_ticks of the 100 MHz clock have passed. */
+int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, void* stream);
 
 #ifdef __cplusplus
 }
