@@ -179,26 +179,33 @@ extern "C" int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, i
 // workgroups (64 threads + `lds_bytes` of LDS each: above 32 KiB no GEMM workgroup fits beside one) on the stream until *stop_flag becomes non-zero
 // (or max_ticks of the 100 MHz clock pass).  bench.py --hog-cus N times the training step beside it; tools/cu_contention.py sweeps N.
 namespace {
-__global__ __launch_bounds__(64) void cu_hog_kernel(const int* stop_flag, long long max_ticks) {
+__global__ __launch_bounds__(64) void cu_hog_kernel(const int* stop_flag, long long max_ticks, long long* report) {
     extern __shared__ char hog_lds[];
     if (threadIdx.x == 0) hog_lds[0] = 0;   // the allocation is what matters
-    unsigned long long start;
+    unsigned long long start, now;
     asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(start)::"memory");
+    now = start;
     while (true) {
         if (__hip_atomic_load(stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // system scope: the writer ran on another XCD (L2s are not coherent with each other)
-        unsigned long long now;
         asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
         if ((long long)(now - start) > max_ticks) break;
         __builtin_amdgcn_s_sleep(64);
     }
+    if (report && threadIdx.x == 0) {   // [block][3]: start tick, ticks alive (100 MHz), XCC id << 16 | HW_ID (CU / SE bits)
+        const unsigned hwid = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
+        report[3 * blockIdx.x + 0] = (long long)start;
+        report[3 * blockIdx.x + 1] = (long long)(now - start);
+        report[3 * blockIdx.x + 2] = ((long long)xcc << 32) | hwid;
+    }
 }
 }  // namespace
 
-extern "C" int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, void* stream) {
+extern "C" int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, int64_t* report, void* stream) {
     AFK_REQUIRE(nblocks > 0 && nblocks <= 256 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && stop_flag && max_ticks > 0, "afk_cu_hog: bad arguments");
     static int once = hipFuncSetAttribute((const void*)cu_hog_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : 1;
     (void)once;
-    hipLaunchKernelGGL(cu_hog_kernel, dim3((unsigned)nblocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, stop_flag, (long long)max_ticks);
+    hipLaunchKernelGGL(cu_hog_kernel, dim3((unsigned)nblocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, stop_flag, (long long)max_ticks, (long long*)report);
     AFK_LAUNCH_CHECK("afk_cu_hog");
     return AFK_OK;
 }

@@ -132,7 +132,7 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
 
 
 # ---------------------------------------------------------------------------------------------- conv stem (a2)
-class ConvStemFn(torch.autograd.Function):
+class ConvStemFn:
     """gelu(conv1) -> gelu(conv2, stride 2) -> permute -> + embed_positions   (modeling_audioflamingo3.py:380-385)"""
 
     @staticmethod
@@ -193,7 +193,7 @@ class ConvStemFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- encoder layer (a5, a6)
-class EncoderLayerFn(torch.autograd.Function):
+class EncoderLayerFn:
     """pre-LN attention block + pre-LN GELU MLP   (AudioFlamingo3EncoderLayer.forward, :211-245)"""
 
     @staticmethod
@@ -247,7 +247,7 @@ class EncoderLayerFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- avg-pool + LN (a7)
-class PoolNormFn(torch.autograd.Function):
+class PoolNormFn:
     """AvgPool1d(2,2) over time then LayerNorm (:401-403)"""
 
     @staticmethod
@@ -269,22 +269,22 @@ class PoolNormFn(torch.autograd.Function):
         return ops.avgpool2_bwd(dp, out_rows, E), None, None, None, None, None
 
 
-class RotaryTimeFn(torch.autograd.Function):
+class RotaryTimeFn:
     """Music Flamingo: rotary time embedding on the encoder output rows (apply_rotary_time_emb, modeling_musicflamingo.py:187-204)"""
 
     @staticmethod
-    def forward(ctx, x, cos, sin):
+    def forward(ctx, x, cos, sin, arena):
         ctx.save_for_backward(cos, sin)
         return ops.rotary_time(x, cos, sin)
 
     @staticmethod
     def backward(ctx, dy):
         cos, sin = ctx.saved_tensors
-        return ops.rotary_time(dy.contiguous(), cos, sin, backward=True), None, None
+        return ops.rotary_time(dy.contiguous(), cos, sin, backward=True), None, None, None
 
 
 # ---------------------------------------------------------------------------------------------- projector (a8)
-class ProjectorFn(torch.autograd.Function):
+class ProjectorFn:
     """Linear -> GELU -> Linear (AudioFlamingo3MultiModalProjector.forward, :435-439)"""
 
     @staticmethod
@@ -311,7 +311,7 @@ class ProjectorFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- embedding scatter (a10)
-class EmbedScatterFn(torch.autograd.Function):
+class EmbedScatterFn:
     """embed_tokens(input_ids) with <sound> rows overwritten by audio rows in row-major order (:532-545)"""
 
     @staticmethod
@@ -338,7 +338,7 @@ class EmbedScatterFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- decoder layer (a13-a16)
-class DecoderLayerFn(torch.autograd.Function):
+class DecoderLayerFn:
     """RMSNorm -> GQA causal attention (RoPE) -> +res ; RMSNorm -> SwiGLU -> +res  (Qwen2DecoderLayer.forward, :269-298)"""
 
     @staticmethod
@@ -402,7 +402,7 @@ class DecoderLayerFn(torch.autograd.Function):
         return (dx,) + (None,) * 15
 
 
-class RMSNormFn(torch.autograd.Function):
+class RMSNormFn:
     """final Qwen2RMSNorm (modeling_qwen2.py:398)"""
 
     @staticmethod
@@ -423,7 +423,7 @@ class RMSNormFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------- lm_head (+ fused loss) (a17, a18)
-class LMHeadFn(torch.autograd.Function):
+class LMHeadFn:
     """logits = hidden @ lm_head.weight^T   (materialised; used for generate() and parity checks)"""
 
     @staticmethod
@@ -440,7 +440,7 @@ class LMHeadFn(torch.autograd.Function):
         return linear_bwd(arena, dy.contiguous(), x, wkey), None, None, None
 
 
-class LMHeadLossFn(torch.autograd.Function):
+class LMHeadLossFn:
     """lm_head + shifted cross-entropy without materialising [B*S, V] (lm_head :625-627 + ForCausalLMLoss, loss_utils.py:51-72).
 
     Row chunks: logits chunk (bf16, as the oracle's lm_head output) -> afk_ce_fwd_bwd turns it into dlogits in place
@@ -506,14 +506,16 @@ class LMHeadLossFn(torch.autograd.Function):
         loss = torch.empty((), device=dev, dtype=torch.float32)
         ops.loss_reduce(row_loss, denom, loss)
         if need_grad:
-            ctx.save_for_backward(dx, gw_tmp, rows)
-            ctx.meta = (arena, wkey, gw_tmp is blk.grad, M_all)
+            # the unscaled weight gradient sits in the gradient arena itself when the block was fresh (saved as None: a stage keeps no arena view)
+            ctx.save_for_backward(dx, None if gw_tmp is blk.grad else gw_tmp, rows)
+        ctx.meta = (arena, wkey, M_all)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dx, gw_tmp, rows = ctx.saved_tensors
-        arena, wkey, inplace, M_all = ctx.meta
+        arena, wkey, M_all = ctx.meta
+        inplace = gw_tmp is None
         blk = arena[wkey]
         g32 = g.reshape(1).float()
         ops.scale_add_(dx, dx, g32, accumulate=False)
@@ -525,3 +527,20 @@ class LMHeadLossFn(torch.autograd.Function):
             ops.scale_add_(gw_tmp, blk.grad, g32, accumulate=True)
         arena.grad_written(blk)
         return dx, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------- the stages as registered operators
+# <Stage>Fn.apply(...) - what modeling.py calls - dispatches torch.ops.afk.<stage> (stage_ops.py): schema, fake implementation, backward operator
+# with the gradient arena declared as mutated, autograd registration.  Slot kinds per forward argument: T tensor, T? optional tensor, A arena, S static.
+from .stage_ops import register_stage  # noqa: E402
+
+ConvStemFn.apply = staticmethod(register_stage("conv_stem", ConvStemFn, ("T", "T", "A", "S", "T", "S", "S", "S")))
+EncoderLayerFn.apply = staticmethod(register_stage("encoder_layer", EncoderLayerFn, ("T", "T", "A", "S", "S", "S", "S", "T?")))
+PoolNormFn.apply = staticmethod(register_stage("pool_norm", PoolNormFn, ("T", "T", "A", "S", "S", "S")))
+RotaryTimeFn.apply = staticmethod(register_stage("rotary_time_stage", RotaryTimeFn, ("T", "T", "T", "A")))
+ProjectorFn.apply = staticmethod(register_stage("projector", ProjectorFn, ("T", "T", "A", "S")))
+EmbedScatterFn.apply = staticmethod(register_stage("embed_scatter", EmbedScatterFn, ("T?", "T", "A", "S", "T", "T?")))
+DecoderLayerFn.apply = staticmethod(register_stage("decoder_layer", DecoderLayerFn, ("T", "T", "A", "S", "S", "S", "S", "S", "S", "S", "T", "T", "T?", "T?", "T?", "T?")))
+RMSNormFn.apply = staticmethod(register_stage("final_rms_norm", RMSNormFn, ("T", "T", "A", "S", "S")))
+LMHeadFn.apply = staticmethod(register_stage("lm_head", LMHeadFn, ("T", "T", "A", "S")))
+LMHeadLossFn.apply = staticmethod(register_stage("lm_head_loss", LMHeadLossFn, ("T", "T", "A", "S", "T", "T", "T?")))

@@ -74,4 +74,4 @@ class MusicFlamingoForConditionalGeneration(AudioFlamingo3ForConditionalGenerati
         ts = self._audio_timestamps(input_ids.to(self.device_), post, T3)
         cos, sin = self._tables(ts, T3)
         R = cos.shape[-1]
-        return F_.RotaryTimeFn.apply(x, cos.reshape(W * T3, R), sin.reshape(W * T3, R))
+        return F_.RotaryTimeFn.apply(x, cos.reshape(W * T3, R), sin.reshape(W * T3, R), self.arena)

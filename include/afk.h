@@ -324,8 +324,9 @@ int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dt
 int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, void* stream);
 /* CU-contention probe (pre-flight of the multi-GPU run; models the CUs RCCL's persistent channel kernels take from the GEMM rounds - reference
  * behaviour being prepared for: TORCH/nn/parallel/distributed.py:1012,1442): parks `nblocks` workgroups of 64 threads + lds_bytes of LDS on `stream`
- * until *stop_flag (device memory) becomes non-zero or max_ticks of the 100 MHz clock have passed. */
-int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, void* stream);
+ * until *stop_flag (device memory) becomes non-zero or max_ticks of the 100 MHz clock have passed.  report (nullable, device, int64 [nblocks][3]):
+ * start tick, ticks alive, XCC id << 32 | HW_ID of every parked workgroup - proof that they sat where the GEMM workgroups wanted to be. */
+int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, int64_t* report, void* stream);
 
 #ifdef __cplusplus
 }

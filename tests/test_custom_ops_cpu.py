@@ -53,3 +53,97 @@ def test_shape_functions_and_single_graph_trace():
     afk = [t for t in targets if t.startswith("afk.")]
     assert afk == ["afk.rms_norm_fwd.default", "afk.linear.default", "afk.rope.default", "afk.attention_fwd.default", "afk.linear.default",
                    "afk.rms_norm_fwd.default", "afk.linear.default", "afk.silu_mul.default", "afk.linear.default"], afk
+
+
+def test_stage_operator_plumbing_with_a_toy_stage():
+    """stage_ops.register_stage (the dispatcher plumbing every stage of the training step runs on since round 4) on a toy stage whose body is
+    plain torch: forward / backward operators with schema, the gradient arena written in place by the BACKWARD operator (declared mutated),
+    optional inputs, an input and a None among the tensors kept for backward, activation checkpointing, no-grad calls, and
+    torch.compile(fullgraph=True) through the registered operators."""
+    import torch
+    from torch.utils.checkpoint import checkpoint
+
+    from audio_flamingo_amd import stage_ops
+
+    class Arena:   # what a stage sees of the arena: flat parameter / gradient buffers + named views
+        def __init__(self):
+            self.params = torch.arange(1, 7, dtype=torch.float32).reshape(-1) / 10
+            self.grads = torch.zeros(6)
+            self.w = self.params[:6].view(2, 3)
+            self.gw = self.grads[:6].view(2, 3)
+
+    class ToyFn:
+        @staticmethod
+        def forward(ctx, x, anchor, arena, scale, bias):
+            h = x @ arena.w.t()                      # [n, 2]
+            y = torch.tanh(h) * scale
+            if bias is not None:
+                y = y + bias
+            ctx.save_for_backward(x, h, None, bias)  # an input, an activation, a None, an optional input
+            ctx.meta = (arena, scale)
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, h, nothing, bias = ctx.saved_tensors
+            arena, scale = ctx.meta
+            assert nothing is None
+            dh = dy * scale * (1 - torch.tanh(h) ** 2)
+            arena.gw += dh.t() @ x                   # weight gradient straight into the gradient arena
+            return dh @ arena.w, None, None, None, (dy.sum(0) if bias is not None else None)
+
+    name = "toy_stage_for_the_cpu_test"
+    if name not in stage_ops.registered_stages():
+        ToyFn.apply = staticmethod(stage_ops.register_stage(name, ToyFn, ("T", "T", "A", "S", "T?")))
+    else:
+        ToyFn.apply = staticmethod(stage_ops._STAGES[name].apply)
+    assert "Tensor(a!) grads" in str(getattr(torch.ops.afk, name + "_bwd").default._schema)
+    assert "!" not in str(getattr(torch.ops.afk, name).default._schema)
+
+    def reference(x, w, bias, scale):
+        y = torch.tanh(x @ w.t()) * scale
+        return y + bias if bias is not None else y
+
+    for use_bias in (True, False):
+        a = Arena()
+        anchor = torch.nn.Parameter(torch.zeros(1))
+        x = torch.randn(5, 3, requires_grad=True)
+        b = torch.randn(2, requires_grad=True) if use_bias else None
+        y = ToyFn.apply(x, anchor, a, 2.0, b)
+        y.square().sum().backward()
+        w = a.w.clone().requires_grad_(True)
+        xr = x.detach().clone().requires_grad_(True)
+        br = b.detach().clone().requires_grad_(True) if use_bias else None
+        reference(xr, w, br, 2.0).square().sum().backward()
+        assert torch.allclose(x.grad, xr.grad, atol=1e-6) and torch.allclose(a.gw, w.grad, atol=1e-6)
+        assert anchor.grad is None
+        if use_bias:
+            assert torch.allclose(b.grad, br.grad, atol=1e-6)
+        # checkpointed: same gradients (the backward operator runs once, on the recomputed activations)
+        a2 = Arena()
+        x2 = x.detach().clone().requires_grad_(True)
+        y2 = checkpoint(ToyFn.apply, x2, anchor, a2, 2.0, b, use_reentrant=False)
+        y2.square().sum().backward()
+        assert torch.allclose(x2.grad, xr.grad, atol=1e-6) and torch.allclose(a2.gw, w.grad, atol=1e-6)
+        # no-grad call: forward only, nothing recorded
+        with torch.no_grad():
+            assert torch.equal(ToyFn.apply(x, anchor, a, 2.0, b), y.detach())
+
+    # the whole toy step under torch.compile(fullgraph=True): the operators are opaque graph nodes, no graph break
+    a3 = Arena()
+    anchor = torch.nn.Parameter(torch.zeros(1))
+    x3 = torch.randn(5, 3, requires_grad=True)
+    b3 = torch.randn(2, requires_grad=True)
+
+    def step(x, b):
+        return ToyFn.apply(ToyFn.apply(x, anchor, a3, 2.0, b)[:, :2] @ torch.ones(2, 3), anchor, a3, 2.0, b).square().sum()
+
+    eager = step(x3, b3)
+    eager.backward()           # also records the stage geometry the fake implementations answer from
+    g_eager, gw_eager = x3.grad.clone(), a3.gw.clone()
+    x3.grad = None
+    a3.grads.zero_()
+    compiled = torch.compile(step, fullgraph=True, backend="aot_eager")
+    out = compiled(x3, b3)
+    out.backward()
+    assert torch.allclose(out, eager) and torch.allclose(x3.grad, g_eager, atol=1e-6) and torch.allclose(a3.gw, gw_eager, atol=1e-6)

@@ -93,3 +93,94 @@ def test_decoder_layer_from_registered_ops_matches_the_training_stage(dev, compi
     for n, p in zip(names, prm):
         r = rel(p.grad, a[pfx + n].grad)
         assert r <= 2e-2, (n, r)
+
+
+def test_training_step_runs_on_registered_stage_operators_and_traces_under_torch_compile(dev):
+    """the product path IS the registered-operator path.  (1) One training step of the tiny AF3 model dispatches every stage
+    through torch.ops.afk.* (dispatch counts per stage; the backward operators declare the gradient arena as mutated).  (2) The stage chain of that
+    step - conv stem, encoder layers, pool + LayerNorm, projector, embedding scatter, decoder layers, final RMSNorm, lm_head + loss - traces into
+    ONE graph under torch.compile(fullgraph=True) (aot_eager: the ctypes calls into libafk.so stay opaque operator nodes) and reproduces the eager
+    loss and every gradient bit for bit."""
+    import os
+
+    from audio_flamingo_amd import functional as F_
+    from audio_flamingo_amd import ops, stage_ops
+    from tests.test_model_gpu import G, _model
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    m.check_placeholders = False
+    m.loss_on_valid_rows_only = False      # the chain below feeds lm_head + loss every row, as the reference does: same arithmetic in both runs
+    ids, feats, labels = g["ids"].to(dev), g["feats"].to(dev), g["labels"].to(dev)
+
+    # ---- (1) the model's own forward / backward: count dispatches per registered stage
+    counts = {}
+    orig = {}
+    for name, st in stage_ops._STAGES.items():
+        orig[name] = (st.op, st.op_bwd)
+
+        def wrap(op, nm):
+            def call(*a):
+                counts[nm] = counts.get(nm, 0) + 1
+                return op(*a)
+            return call
+        st.op, st.op_bwd = wrap(st.op, name), wrap(st.op_bwd, name + "_bwd")
+    try:
+        m.zero_grad()
+        out = m(input_ids=ids, input_features=feats, labels=labels)
+        out.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        for name, st in stage_ops._STAGES.items():
+            st.op, st.op_bwd = orig[name]
+    L_enc, L_dec = m.enc_layers, m.dec_layers
+    want = {"conv_stem": 1, "encoder_layer": L_enc, "pool_norm": 1, "projector": 1, "embed_scatter": 1, "decoder_layer": L_dec, "final_rms_norm": 1, "lm_head_loss": 1}
+    for k, v in want.items():
+        assert counts.get(k) == v and counts.get(k + "_bwd") == v, (k, counts)
+    for name in want:
+        assert "Tensor(a!) grads" in str(getattr(torch.ops.afk, name + "_bwd").default._schema)
+    eager_loss, eager_grads = float(out.loss), m.arena.grads.clone()
+
+    # ---- (2) the same stage chain as one traced graph
+    a, at, lm, pj = m.arena, m._at, m._lm, m._pj
+    W, C, T = feats.shape
+    T2 = (T - 1) // 2 + 1
+    T3 = T2 // 2
+    B, S = ids.shape
+    ids_flat = ids.reshape(-1).contiguous()
+    src, _ = ops.placeholder_scan(ids_flat, m.audio_token_id)
+    cos, sin = m._rope_tables(S)
+    shift = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:].reshape(-1).contiguous()
+    denom = ops.count_valid(shift)
+    anchors = {k: m._anchor(k) for k in [at + "conv1.weight", at + "layer_norm.weight", pj + "linear_1.weight", lm + "embed_tokens.weight", lm + "norm.weight", "lm_head.weight"]
+               + [f"{at}layers.{i}.fc1.weight" for i in range(L_enc)] + [f"{lm}layers.{i}.mlp.down_proj.weight" for i in range(L_dec)]}
+    pos_table = m.embed_positions.data
+
+    def chain(feats_, ids_flat_, src_, shift_, denom_):
+        x = F_.ConvStemFn.apply(feats_, anchors[at + "conv1.weight"], a, (at + "conv1.weight", at + "conv1.bias", at + "conv2.weight", at + "conv2.bias"), pos_table, W, T, C)
+        for i in range(L_enc):
+            p = f"{at}layers.{i}."
+            x = F_.EncoderLayerFn.apply(x, anchors[p + "fc1.weight"], a, p, W, T2, m.enc_heads, None)
+        x = F_.PoolNormFn.apply(x, anchors[at + "layer_norm.weight"], a, at + "layer_norm.weight", at + "layer_norm.bias", W * T3)
+        x = F_.ProjectorFn.apply(x, anchors[pj + "linear_1.weight"], a, pj)
+        x = F_.EmbedScatterFn.apply(x, anchors[lm + "embed_tokens.weight"], a, lm + "embed_tokens.weight", ids_flat_, src_)
+        for i in range(L_dec):
+            p = f"{lm}layers.{i}."
+            x = F_.DecoderLayerFn.apply(x, anchors[p + "mlp.down_proj.weight"], a, p, B, S, m.Hq, m.Hkv, m.D, m.rms_eps, cos, sin, None, None, None, None)
+        x = F_.RMSNormFn.apply(x, anchors[lm + "norm.weight"], a, lm + "norm.weight", m.rms_eps)
+        return F_.LMHeadLossFn.apply(x, anchors["lm_head.weight"], a, "lm_head.weight", shift_, denom_, None)
+
+    m.zero_grad()
+    l0 = chain(feats, ids_flat, src, shift, denom)     # eager pass of the chain: also records the stage geometries the fake implementations answer from
+    l0.backward()
+    torch.cuda.synchronize()
+    assert abs(float(l0) - eager_loss) < 1e-6
+    assert torch.equal(m.arena.grads, eager_grads)
+    m.zero_grad()
+    compiled = torch.compile(chain, fullgraph=True, backend="aot_eager")
+    l1 = compiled(feats, ids_flat, src, shift, denom)
+    l1.backward()
+    m.arena.join_streams()
+    torch.cuda.synchronize()
+    assert float(l1) == float(l0)
+    assert torch.equal(m.arena.grads, eager_grads), "traced step: gradients differ from the eager step"
