@@ -108,7 +108,10 @@ class _Stage:
         static = tuple(args[i] for i in self.s_idx)
         shapes = tuple(None if t is None else (tuple(t.shape), str(t.dtype)) for t in tens)
         uid = _uid(arena)
-        key = f"{self.name}|{uid}|{static!r}|{shapes!r}"
+        # does this call record a backward?  (the operator's implementation runs below the autograd key with grad mode off and cannot see it;
+        # lm_head + loss produces its gradients during the forward sweep only when somebody will ask for them)
+        need = int(torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tens))
+        key = f"{self.name}|{uid}|{static!r}|{shapes!r}|g{need}"
         if key not in _STATIC:
             _STATIC[key] = (uid, static)
         return self.op(*tens, arena.params, arena.grads, key)[0]
@@ -128,7 +131,7 @@ class _Stage:
         arena, static = _arena_of(key)
         ctx = _Ctx()
         full = self._full_args(tens, arena, static)
-        ctx.needs_input_grad = tuple(bool(torch.is_grad_enabled() and isinstance(x, Tensor) and x.requires_grad) for x in full)
+        ctx.needs_input_grad = (key.endswith("|g1"),) * len(full)
         out = self.fn.forward(ctx, *full)
         g_store, p_store = grads.untyped_storage().data_ptr(), params.untyped_storage().data_ptr()
         outs, src = [out], []

@@ -223,12 +223,12 @@ def test_gemm_tn_wgrad_headline_shapes_sampled_rows(dev, M, N, K):
     assert torch.equal(ops.gemm(at, bt, trans_a=True, trans_b=True), c), "non-deterministic TN GEMM result"
 
 
-@pytest.mark.parametrize("M,N,K,splits", [(8192, 3584, 37888, 1), (2048, 3584, 152064, None), (8192, 3584, 152064, None)])
+@pytest.mark.parametrize("M,N,K,splits", [(8192, 3584, 37888, 1), (2048, 3584, 152064, None), (8192, 3584, 152064, 1)])
 def test_gemm_nn_dgrad_headline_shapes_sampled_rows(dev, M, N, K, splits):
     """dX[M,N] = dY[M,K] . W[K,N] straight from W (the kernels that became the hot path in round 3 had no value test at
     their hot shapes): the gate|up dgrad (reduction over 37 888, one launch per decoder layer) and the lm_head dgrad over the 152 064-wide
     vocabulary with split-K (2 048 labelled rows of the benchmark batch: 112 tiles -> fp32 partials folded in fixed order; 8 192 rows = the
-    all-rows form), on `gemm_xt_bf16_k256<false, .>` - against fp32 on 64 sampled rows, bit-deterministic when repeated"""
+    all-rows form: 448 tiles, one pass), on `gemm_xt_bf16_k256<false, .>` - against fp32 on 64 sampled rows, bit-deterministic when repeated"""
     from audio_flamingo_amd import ops
 
     a = (_rand((M, K), dev, 1.0, seed=7) * (K ** -0.25)).to(BF)     # operand scales keep |dX| = O(1) over the long reductions
