@@ -186,7 +186,9 @@ __global__ __launch_bounds__(64) void cu_hog_kernel(const int* stop_flag, long l
     asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(start)::"memory");
     now = start;
     while (true) {
-        if (__hip_atomic_load(stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;   // system scope: the writer ran on another XCD (L2s are not coherent with each other)
+        // system-scope ACQUIRE: the flag is written by the host (pinned memory) or by a kernel on another XCD - L2s are not coherent with each other,
+        // a relaxed load kept hitting this XCD's stale line and the parked workgroups only left at max_ticks
+        if (__hip_atomic_load(stop_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
         asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
         if ((long long)(now - start) > max_ticks) break;
         __builtin_amdgcn_s_sleep(64);

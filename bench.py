@@ -743,13 +743,13 @@ def main():
         from audio_flamingo_amd import _lib
         cu_contention = {}
         hog_stream = torch.cuda.Stream(device=dev)
-        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        flag = torch.zeros(1, dtype=torch.int32).pin_memory()   # host-coherent stop flag: the CPU ends the parked kernel with a plain store
         for n_hog in [int(x) for x in args.cu_contention.split(",") if x.strip() != ""]:
-            flag.zero_()
+            flag[0] = 0
             fence()
             rep = torch.zeros((max(n_hog, 1), 3), device=dev, dtype=torch.int64)
             if n_hog > 0:   # 96 KiB of LDS per parked workgroup: ONE per CU, and a 128 KiB GEMM workgroup cannot share that CU; at most 30 s (100 MHz ticks)
-                _lib.call("afk_cu_hog", n_hog, 96 * 1024, flag.data_ptr(), 3_000_000_000, rep.data_ptr(), hog_stream.cuda_stream)
+                _lib.call("afk_cu_hog", n_hog, 96 * 1024, flag.data_ptr(), 1_000_000_000, rep.data_ptr(), hog_stream.cuda_stream)
                 time.sleep(0.05)   # let the parked workgroups land before the step's kernels arrive
             load_next()
             run()                      # one step for the parked workgroups to settle on their CUs
@@ -763,13 +763,15 @@ def main():
                 model.arena.join_streams()
                 torch.cuda.current_stream().synchronize()
             cu_contention[str(n_hog)] = round(1000.0 * (time.perf_counter() - t_h) / 5, 2)
-            flag.fill_(1)              # from the MAIN stream (a fill on the hog stream would queue behind the parked kernel)
+            t_steps_ms = 1000.0 * (time.perf_counter() - t_h)
+            flag[0] = 1                # host store into pinned memory: the parked workgroups see it through their system-scope acquire loads
             fence()
             if n_hog > 0:              # residency proof: how long the parked workgroups lived (they must span the timed steps) and on how many distinct CUs
                 r = rep.cpu()
                 alive_ms = (r[:, 1].float() / 1e5).tolist()
                 cus = len({(int(v) >> 32, (int(v) >> 8) & 0xF, (int(v) >> 13) & 0x7) for v in r[:, 2].tolist()})   # (XCC, CU_ID bits 11:8, SE_ID bits 15:13)
-                cu_contention[f"{n_hog}_parked_ms_min_max"] = [round(min(alive_ms), 1), round(max(alive_ms), 1)]
+                cu_contention[f"{n_hog}_parked_ms_min_max"] = [round(min(alive_ms), 1), round(max(alive_ms), 1)]   # must exceed the timed steps:
+                cu_contention[f"{n_hog}_timed_steps_ms"] = round(t_steps_ms, 1)
                 cu_contention[f"{n_hog}_distinct_cus"] = cus
         print(f"[bench] cu_contention (ms/step beside n parked CUs): {cu_contention}", file=sys.stderr, flush=True)
 

@@ -55,6 +55,13 @@ def floor_bar(abs_bar: float, floor_values, cap=None, is_grad=False) -> float:
     return b if cap is None else min(float(cap), b)
 
 
+def floor_range_bar(abs_bar: float, floor_values) -> float:
+    """bar for a run of the REFERENCE's own bf16 model (tests/test_hf_plugin_gpu.py: the stock model with only its attention dispatched to libafk.so):
+    both sides are the same noisy bf16 model, so the bar is the stock run's own range over the floor batches - max(abs, FLOOR_FACTOR x its maximum).
+    (Our implementation's golden-batch statistics are held to the tighter floor_bar above.)"""
+    return max(float(abs_bar), FLOOR_FACTOR * max(float(v) for v in floor_values))
+
+
 def median(values):
     v = sorted(float(x) for x in values)
     n = len(v)

@@ -37,7 +37,7 @@ def test_reference_model_with_afk_attention_vs_golden(dev, case):
     bars of tests/_tol.py or by the floor rule of that file (2 x the LARGEST deviation of the stock run over the floor batches of
     tests/test_model_gpu.py::_floor_distribution + this batch; gradient bars capped, noise-dominated tensors reported only), whichever is larger"""
     from audio_flamingo_amd import hf_plugin
-    from tests._tol import GRAD_REL_L2, LOSS_ATOL, NOISE_DOMINATED, floor_bar, logit_tol
+    from tests._tol import GRAD_REL_L2, LOSS_ATOL, NOISE_DOMINATED, floor_range_bar as floor_bar, logit_tol
     from tests.test_host_cpu import TINY
     from tests.test_model_gpu import _floor_distribution
 
