@@ -749,7 +749,10 @@ def main():
             fence()
             rep = torch.zeros((max(n_hog, 1), 3), device=dev, dtype=torch.int64)
             if n_hog > 0:   # 96 KiB of LDS per parked workgroup: ONE per CU, and a 128 KiB GEMM workgroup cannot share that CU; at most 30 s (100 MHz ticks)
-                _lib.call("afk_cu_hog", n_hog, 96 * 1024, flag.data_ptr(), 1_000_000_000, rep.data_ptr(), hog_stream.cuda_stream)
+                # bounded life: 0.9 s per timed step + settle (100 MHz ticks) - the stop flag is best effort (the parked waves poll it with system-scope
+                # acquire loads; on this stack they did not observe the host's store and left at the bound, which is why the bound is tight)
+                ticks = int((0.9 * 6 + 0.6) * 1e8)
+                _lib.call("afk_cu_hog", n_hog, 96 * 1024, flag.data_ptr(), ticks, rep.data_ptr(), hog_stream.cuda_stream)
                 time.sleep(0.05)   # let the parked workgroups land before the step's kernels arrive
             load_next()
             run()                      # one step for the parked workgroups to settle on their CUs

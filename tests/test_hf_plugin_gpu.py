@@ -136,7 +136,11 @@ def test_afk_attention_vs_sdpa_on_device(dev, padded):
     assert served == {"lds": 4, "interval": 0}, served
     assert abs(res["sdpa"][0] - res[name][0]) <= 1e-2, (res["sdpa"][0], res[name][0])
     assert float((res["sdpa"][1] - res[name][1]).abs().max()) <= 4e-2
-    bad = {k: _rel(res[name][2][k], v) for k, v in res["sdpa"][2].items() if v.float().norm() > 0 and _rel(res[name][2][k], v) > 6e-2}
+    # k_proj.bias is left out: its true gradient is identically zero (a bias on k adds q.b to every score of a query - softmax does not see a
+    # per-query constant), so both runs hold pure rounding noise there and their relative distance means nothing (0.061 against the 0.06 bar once
+    # the kernels' summation order changed in round 4)
+    bad = {k: _rel(res[name][2][k], v) for k, v in res["sdpa"][2].items()
+           if v.float().norm() > 0 and not k.endswith("k_proj.bias") and _rel(res[name][2][k], v) > 6e-2}
     assert not bad, bad
 
 
