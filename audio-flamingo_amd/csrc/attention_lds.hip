@@ -209,8 +209,7 @@ constexpr float RESCALE_THR = 8.f;  // log2 domain
 
 // LM (round 4): the row sum l comes out of the matrix pipe - one more accumulator block fed with an all-ones A fragment against the SAME
 // probability fragments (l = P^T . 1: every row of the block equals the per-query sum over the tile's keys, it accumulates over tiles and takes
-// the lazy rescale like O).  4 MFMAs per tile replace 29 VALU adds (the kernels are VALU-co-limited: at head_dim 64 the softmax arithmetic
-// per score is the same as at 128 with half the MFMA work), and the normaliser is the sum of the bf16-ROUNDED probabilities that P.V uses.
+// the lazy rescale like O).  4 MFMAs per tile replace 29 VALU adds, and the normaliser is the sum of the bf16-ROUNDED probabilities that P.V uses.
 template <int D, bool LM>
 __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
@@ -1019,10 +1018,11 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
     hipStream_t st = (hipStream_t)stream;
     afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
-    // row sum on the matrix pipe (kernel template LM): default at head_dim 64, where the kernel is VALU-bound with the matrix pipe a third busy;
+    // row sum on the matrix pipe (kernel template LM): default at head_dim 128 - measured (profiles/r04_kernel_ab.md): -4 % on the 5-minute decoder
+    // shape, neutral at S = 1024; at head_dim 64 it is neutral to +3 % (three waves per SIMD already hide the adds), so it stays off there.
     // AFK_ATTN_LSUM=0 / 1 forces it off / on for both head sizes (A/B)
     static const int lsum_env = [] { const char* e = getenv("AFK_ATTN_LSUM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool lm = lsum_env < 0 ? D == 64 : lsum_env == 1;
+    const bool lm = lsum_env < 0 ? D == 128 : lsum_env == 1;
 #define AFK_FWD(DD, LM_)                                                                      \
     do {                                                                                      \
         constexpr int L = 4 * Tile<DD>::BYTES;                                                \

@@ -844,7 +844,13 @@ def main():
                                                "collectives_forced_at_world_1": bool(engine.force_collectives and world == 1),
                                                "buckets": len(model.arena.bucket_names), "bucket_bytes_max": 2 * max(e - s_ for s_, e in model.arena._bucket_ranges),
                                                "bucket_bytes_total": 2 * model.arena.total, "overlapped_with_backward": overlap is not None or engine.overlap,
-                                               "collectives_per_step": len(model.arena.bucket_names) + 1},
+                                               "collectives_per_step": len(model.arena.bucket_names) + 1,
+                                               "rccl_channel_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None},
+                                               "why_these_defaults": "one c10d all_reduce per layer bucket (466 MB): RCCL itself spreads a large all-reduce over the rings of "
+                                                   "all seven xGMI links - the native reduce-scatter + all-gather form (AFK_DP_COMM=native) moves the same bytes in two launches and "
+                                                   "stays opt-in until a multi-GPU box has timed both; eager enqueue (RCCL inside the captured HIP graph is validated at world 1 only: "
+                                                   "--dp-graph); no RCCL channel cap: parking 32 / 64 persistent workgroups on as many CUs beside this step costs 0 ms "
+                                                   "(profiles/r04_cu_contention.json: the step is power-limited, not CU-limited). No scaling curve has been measured."},
             "long_audio_configs4": long_audio, "long_audio_10min": long_10min, "decode": decode, "cu_contention_ms_per_step": cu_contention,
             "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
             "host_enqueue_ms_idle_gpu": round(1000.0 * host_enqueue_idle, 1),
