@@ -296,15 +296,16 @@ int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     }
     const int64_t nwg = (int64_t)p.ntm * p.ntn;
     const int f = (p.wide && p.splits <= 1) ? p.flags : -1;
-    if (f == -1) afk_count(AFK_CNT_GEMM_GENERIC);   // runtime-flag epilogue (narrow stores / an epilogue outside the training step's list)
     switch (f) {
 #define AFK_CASE(F)                                                                                          \
     case (F):                                                                                                \
+        if ((F) == -1) afk_count(AFK_CNT_GEMM_GENERIC);                                                      \
         hipLaunchKernelGGL(gemm_nt_bf16_k256<(F)>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);        \
         break;
         AFK_EPI_LIST(AFK_CASE)
 #undef AFK_CASE
-        default:
+        default:   // an epilogue outside the list: runtime-flag instantiation
+            afk_count(AFK_CNT_GEMM_GENERIC);
             hipLaunchKernelGGL(gemm_nt_bf16_k256<-1>, dim3((unsigned)nwg), dim3(512), LDS_BYTES, st, p);
     }
     return AFK_OK;

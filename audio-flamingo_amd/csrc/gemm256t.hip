@@ -352,16 +352,17 @@ int afk_launch_gemm256t(const GemmArgs& p, int trans_a, hipStream_t st) {
     const unsigned ns = (unsigned)(p.splits > 1 ? p.splits : 1);
     const int f = p.splits > 1 ? -2 : (p.wide ? p.flags : -1);  // -2: split-K partial sums (the fold kernel applies the epilogue)
     const dim3 grid((unsigned)nwg, ns);
-    if (f == -1) afk_count(AFK_CNT_GEMM_GENERIC);   // runtime-flag epilogue (narrow stores / an epilogue outside the training step's list)
     switch (f) {
 #define AFK_CASE(F)                                                                                                   \
     case (F):                                                                                                         \
+        if ((F) == -1) afk_count(AFK_CNT_GEMM_GENERIC);                                                               \
         if (trans_a) hipLaunchKernelGGL((gemm_xt_bf16_k256<true, (F)>), grid, dim3(512), LDS_BYTES, st, p);          \
         else hipLaunchKernelGGL((gemm_xt_bf16_k256<false, (F)>), grid, dim3(512), LDS_BYTES, st, p);                 \
         break;
         AFK_EPI_LIST(AFK_CASE)
 #undef AFK_CASE
-        default:
+        default:   // an epilogue outside the list: runtime-flag instantiation
+            afk_count(AFK_CNT_GEMM_GENERIC);
             if (trans_a) hipLaunchKernelGGL((gemm_xt_bf16_k256<true, -1>), grid, dim3(512), LDS_BYTES, st, p);
             else hipLaunchKernelGGL((gemm_xt_bf16_k256<false, -1>), grid, dim3(512), LDS_BYTES, st, p);
     }
