@@ -285,3 +285,40 @@ rope.register_autograd(_rope_backward, setup_context=_rope_setup)
 
 REGISTERED = ("linear", "linear_bwd", "rms_norm_fwd", "rms_norm_bwd", "layer_norm_fwd", "layer_norm_bwd", "attention_fwd", "attention_bwd",
               "silu_mul", "silu_mul_bwd", "gelu", "gelu_bwd", "rope")
+
+
+# ---------------------------------------------------------------------------------------------- log-mel frontend and the optimizer launch (round 4)
+# The two remaining pieces of the training step outside the stage operators (stage_ops.py): the on-device log-mel (no gradient: raw audio is an input)
+# and the fused AdamW launch, whose five buffers are MUTATED in place - declared as such, so a tracer orders it after the backward operators that wrote
+# the gradients.  frontend.LogMelFrontend calls afk::logmel.  arena.FusedAdamW keeps the direct C-ABI call: its launches run bucket by bucket INSIDE backward on a
+# side stream, and an operator that declares the parameter arena as mutated bumps the version counter every parameter view shares - autograd would refuse the
+# backward of the layers still to come, and the arena's W^T-shadow freshness stamps would all go stale.  afk::adamw_step is the operator for hosts that step after backward.
+@torch.library.custom_op("afk::logmel", mutates_args=(), device_types=_DEV)
+def logmel(wav: Tensor, cosb: Tensor, sinb: Tensor, melT: Tensor, n_mels: int, nbins_pad: int, bf16_out: bool) -> Tensor:
+    """WhisperFeatureExtractor's torch path (feature_extraction_whisper.py: STFT 400 / 160, power, mel bank, log10 clamp, per-window max - 8, (x + 4) / 4) in one
+    kernel: wav [W, n_samples] fp32 -> [W, n_mels, n_samples / 160] fp32 or bf16"""
+    from . import _lib
+    from .ops import _stream
+
+    W, n = wav.shape
+    T = n // 160
+    raw = torch.empty((W, n_mels, T), device=wav.device, dtype=torch.float32)
+    wmax = torch.empty(W, device=wav.device, dtype=torch.int32)
+    out = raw if not bf16_out else torch.empty((W, n_mels, T), device=wav.device, dtype=torch.bfloat16)
+    _lib.call("afk_logmel", wav.data_ptr(), W, n, cosb.data_ptr(), sinb.data_ptr(), nbins_pad, melT.data_ptr(), n_mels, raw.data_ptr(), wmax.data_ptr(),
+              out.data_ptr(), int(bf16_out), _stream())
+    return out
+
+
+@logmel.register_fake
+def _(wav, cosb, sinb, melT, n_mels, nbins_pad, bf16_out):
+    return wav.new_empty((wav.shape[0], n_mels, wav.shape[1] // 160), dtype=torch.bfloat16 if bf16_out else torch.float32)
+
+
+@torch.library.custom_op("afk::adamw_step", mutates_args=("master", "m", "v", "param"), device_types=_DEV)
+def adamw_step(master: Tensor, m: Tensor, v: Tensor, grad: Tensor, param: Tensor, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float,
+               step: int, grad_scale: float, max_blocks: int, gate: Optional[Tensor] = None, hyper: Optional[Tensor] = None) -> None:
+    """torch.optim.AdamW on a flat range of the arena (fp32 master / m / v, bf16 gradient in, bf16 parameter out: 28 B/param); gate / hyper: device-side launch
+    gate and (lr, bias corrections, clip coefficient) for the HIP-graph-replayed step"""
+    ops.adamw_step(master, m, v, grad, param, lr=lr, beta1=beta1, beta2=beta2, eps=eps, weight_decay=weight_decay, step=step, grad_scale=grad_scale,
+                   max_blocks=max_blocks, gate=gate, hyper=hyper)

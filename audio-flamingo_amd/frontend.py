@@ -77,13 +77,6 @@ class LogMelFrontend:
     def __call__(self, wav: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
         if not wav.is_cuda or wav.dtype != torch.float32:
             raise _lib.AfkError("LogMelFrontend: waveform must be a float32 HIP tensor [W, n_samples]")
-        wav = wav.contiguous()
-        W, n = wav.shape
-        T = n // HOP
-        raw = torch.empty((W, self.n_mels, T), device=wav.device, dtype=torch.float32)
-        wmax = torch.empty(W, device=wav.device, dtype=torch.int32)
-        out = raw if out_dtype == torch.float32 else torch.empty((W, self.n_mels, T), device=wav.device, dtype=torch.bfloat16)
-        _lib.call("afk_logmel", wav.data_ptr(), W, n, self.cosb.data_ptr(), self.sinb.data_ptr(), self.nbins_pad,
-                  self.melT.data_ptr(), self.n_mels, raw.data_ptr(), wmax.data_ptr(), out.data_ptr(),
-                  int(out_dtype == torch.bfloat16), _stream())
-        return out
+        from . import custom_ops  # noqa: F401  (registers torch.ops.afk.logmel)
+
+        return torch.ops.afk.logmel(wav.contiguous(), self.cosb, self.sinb, self.melT, self.n_mels, self.nbins_pad, out_dtype == torch.bfloat16)

@@ -184,3 +184,29 @@ def test_training_step_runs_on_registered_stage_operators_and_traces_under_torch
     torch.cuda.synchronize()
     assert float(l1) == float(l0)
     assert torch.equal(m.arena.grads, eager_grads), "traced step: gradients differ from the eager step"
+
+
+def test_logmel_and_adamw_operators(dev):
+    """afk::logmel (what LogMelFrontend dispatches) and afk::adamw_step (mutating operator for hosts that step after backward) against the direct C-ABI calls"""
+    from audio_flamingo_amd import custom_ops as C  # noqa: F401
+    from audio_flamingo_amd import ops
+    from audio_flamingo_amd.frontend import LogMelFrontend
+
+    fe = LogMelFrontend(dev)
+    g = torch.Generator().manual_seed(0)
+    wav = (0.1 * torch.randn(2, 480000, generator=g)).to(dev)
+    a = fe(wav)
+    b = torch.ops.afk.logmel(wav, fe.cosb, fe.sinb, fe.melT, fe.n_mels, fe.nbins_pad, False)
+    assert a.shape == (2, 128, 3000) and torch.equal(a, b)
+    torch.library.opcheck(torch.ops.afk.logmel.default, (wav, fe.cosb, fe.sinb, fe.melT, fe.n_mels, fe.nbins_pad, True), test_utils=("test_schema", "test_faketensor"))
+    n = 4096
+    st = [torch.randn(n, device=dev) for _ in range(3)]
+    st[2] = st[2].abs()
+    grad = torch.randn(n, device=dev).to(BF)
+    p1, p2 = torch.zeros(n, device=dev, dtype=BF), torch.zeros(n, device=dev, dtype=BF)
+    s1, s2 = [t.clone() for t in st], [t.clone() for t in st]
+    kw = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=3, grad_scale=0.5, max_blocks=0)
+    ops.adamw_step(s1[0], s1[1], s1[2], grad, p1, **kw)
+    torch.ops.afk.adamw_step(s2[0], s2[1], s2[2], grad, p2, kw["lr"], kw["beta1"], kw["beta2"], kw["eps"], kw["weight_decay"], kw["step"], kw["grad_scale"], 0)
+    assert torch.equal(p1, p2) and all(torch.equal(x, y) for x, y in zip(s1, s2))
+    assert "Tensor(a" in str(torch.ops.afk.adamw_step.default._schema)
