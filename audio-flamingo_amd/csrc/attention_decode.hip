@@ -18,11 +18,15 @@ constexpr float NEG_INF = -INFINITY;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int MAXCHUNK = 4096;  // keys per split held in LDS
 
-template <int D>
+// FINAL (round 4, afk_attn_decode_fused): no combine launch - the LAST chunk block of a (batch, head) pair to finish merges the chunks itself.
+// Every block publishes (m, l, o[D]), fences at agent scope (the chunks of one head run on different XCDs whose L2s are not coherent) and bumps the
+// pair's counter; the block that reads nsplit - 1 acquires, folds the partials in chunk order (same arithmetic as attn_decode_combine_kernel: the
+// result does not depend on which block came last), writes the bf16 output and resets the counter for the next call.  Nobody waits for anybody.
+template <int D, bool FINAL>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
                                                                 int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
                                                                 int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
-                                                                float scale, float* __restrict__ ws) {
+                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
     constexpr int LPK = D / 8;        // lanes per key row
     constexpr int KPP = 256 / LPK;    // keys scored per pass of the block
     constexpr int PARTS = 256 / D;    // threads per output feature
@@ -38,9 +42,40 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     const int c0 = a0 + split * chunk, c1 = min(c0 + chunk, hi);  // keys [max(c0, lo), c1)
     const int n = max(c1 - c0, 0);
     float* out = ws + ((int64_t)(b * Hq + h) * nsplit + split) * (D + 2);
+    __shared__ int last_flag;
+    // FINAL: the merge by the last-arriving block of this (batch, head) pair
+    auto finish = [&]() {
+        if (!FINAL) return;
+        int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
+        __threadfence();                                   // release (every writer): this block's (m, l, o) reach memory before the counter moves
+        __syncthreads();
+        if (t == 0) {
+            const int prev = atomicAdd(&counters[b * Hq + h], 1);
+            last_flag = (prev == nsplit - 1);
+            if (last_flag) counters[b * Hq + h] = 0;       // self-resetting: the next call (a HIP-graph replay) starts from zero again
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        __threadfence();                                   // acquire (every reader): drop whatever this CU / XCD cached of the other blocks' slots
+        const float* base = ws + (int64_t)(b * Hq + h) * nsplit * (D + 2);
+        if (t < D) {
+            float M = NEG_INF;
+            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, __builtin_nontemporal_load(base + s * (D + 2)));
+            float L = 0.f, o = 0.f;
+            if (M != NEG_INF) {
+                for (int s = 0; s < nsplit; ++s) {
+                    const float w = __builtin_amdgcn_exp2f(__builtin_nontemporal_load(base + s * (D + 2)) - M);
+                    L += w * __builtin_nontemporal_load(base + s * (D + 2) + 1);
+                    o += w * __builtin_nontemporal_load(base + s * (D + 2) + 2 + t);
+                }
+            }
+            O[b * o_bs + h * o_hs + t] = (bf16)(L > 0.f ? o / L : 0.f);
+        }
+    };
     if (n <= 0 || c1 <= lo) {
         if (t < D) out[2 + t] = 0.f;
         if (t == 0) { out[0] = NEG_INF; out[1] = 0.f; }
+        finish();
         return;
     }
     // ---- scores
@@ -103,6 +138,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
         out[2 + t] = o;
     }
     if (t == 0) { out[0] = m; out[1] = l; }
+    finish();
 }
 
 template <int D>
@@ -125,28 +161,45 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
 
 }  // namespace
 
-extern "C" int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit) { return B * Hq * nsplit * (D + 2); }
+extern "C" int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit) { return B * Hq * nsplit * (D + 2) + B * Hq; }   // + arrival counters (afk_attn_decode_fused)
 
-extern "C" int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
-                               const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
-                               int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
+static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                            const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
+                            int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
     AFK_REQUIRE(Q && Kc && Vt && O && krange && workspace, "afk_attn_decode: null pointer");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128) && nsplit >= 1 && nsplit <= 64, "afk_attn_decode: bad shape");
     AFK_REQUIRE(q_bs % 8 == 0 && q_hs % 8 == 0 && k_bs % 8 == 0 && k_rs % 8 == 0 && k_hs % 8 == 0 && vt_bs % 8 == 0 && spad % 8 == 0,
                 "afk_attn_decode: strides must keep 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)nsplit, (unsigned)Hq, (unsigned)B);
-    if (D == 128) {
-        hipLaunchKernelGGL(attn_decode_split_kernel<128>, grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs,
-                           (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace);
-        hipLaunchKernelGGL(attn_decode_combine_kernel<128>, dim3((unsigned)Hq, (unsigned)B), dim3(128), 0, st, workspace, nsplit, (bf16*)O, o_bs,
-                           o_hs, Hq);
-    } else {
-        hipLaunchKernelGGL(attn_decode_split_kernel<64>, grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs,
-                           (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace);
-        hipLaunchKernelGGL(attn_decode_combine_kernel<64>, dim3((unsigned)Hq, (unsigned)B), dim3(64), 0, st, workspace, nsplit, (bf16*)O, o_bs,
-                           o_hs, Hq);
-    }
+#define AFK_AD(DD)                                                                                                                                      \
+    do {                                                                                                                                                \
+        if (fused) {                                                                                                                                    \
+            hipLaunchKernelGGL((attn_decode_split_kernel<DD, true>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,   \
+                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs);                            \
+        } else {                                                                                                                                        \
+            hipLaunchKernelGGL((attn_decode_split_kernel<DD, false>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,  \
+                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs);                            \
+            hipLaunchKernelGGL(attn_decode_combine_kernel<DD>, dim3((unsigned)Hq, (unsigned)B), dim3(DD), 0, st, workspace, nsplit, (bf16*)O, o_bs,     \
+                               o_hs, Hq);                                                                                                               \
+        }                                                                                                                                               \
+    } while (0)
+    if (D == 128) AFK_AD(128); else AFK_AD(64);
+#undef AFK_AD
     AFK_LAUNCH_CHECK("afk_attn_decode");
     return AFK_OK;
+}
+
+extern "C" int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                               const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
+                               int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
+    return attn_decode_impl(false, Q, q_bs, q_hs, Kc, k_bs, k_rs, k_hs, Vt, vt_bs, spad, O, o_bs, o_hs, krange, B, Hq, Hkv, D, scale, nsplit, workspace, stream);
+}
+
+// one launch: the last chunk block of every (batch, head) pair merges the chunks.  workspace: afk_attn_decode_workspace_floats(...) floats whose LAST B * Hq words are the
+// per-pair arrival counters - they must read ZERO before the first call (the kernel leaves them at zero)
+extern "C" int afk_attn_decode_fused(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                                     const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
+                                     int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
+    return attn_decode_impl(true, Q, q_bs, q_hs, Kc, k_bs, k_rs, k_hs, Vt, vt_bs, spad, O, o_bs, o_hs, krange, B, Hq, Hkv, D, scale, nsplit, workspace, stream);
 }

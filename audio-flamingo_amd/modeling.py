@@ -856,6 +856,48 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                       x.data_ptr(), h.data_ptr(), st)
         return h  # already through the final norm
 
+    decode_chain = os.environ.get("AFK_DECODE_CHAIN", "1") == "1"   # single sequence: one launch per Linear (csrc/decode_chain.hip), five per layer
+
+    def _decode_layers_chain(self, x, cache, pos_rows, krange, start_dev):
+        """one new position of ONE sequence: five launches per decoder layer (round 4; ten on the split-K + glue path above).  Every Linear is one
+        weight-streaming launch in which a wave owns two complete output rows: the qkv launch normalises the residual stream in its prologue and applies
+        bias / RoPE / cache append in its epilogue, o_proj and down_proj add the residual, gate|up normalises in its prologue and multiplies
+        silu(gate) * up in its epilogue; the Q = 1 attention merges its key chunks in the last block to finish (afk_attn_decode_fused)."""
+        a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
+        Kc, Vt = cache
+        Smax, Spad = Kc.shape[2], Vt.shape[4]
+        nq, nk = Hq * D, Hkv * D
+        H = x.shape[1]
+        dev = x.device
+        cos, sin = self._rope_tables(int(self.config.text_config.max_position_embeddings))
+        st = ops._stream()
+        ns = self.decode_splits
+        aws = torch.zeros(_lib.load().afk_attn_decode_workspace_floats(1, Hq, D, ns), device=dev, dtype=torch.float32)   # arrival counters start at zero
+        q = torch.empty((1, nq), device=dev, dtype=torch.bfloat16)
+        o = torch.empty((1, nq), device=dev, dtype=torch.bfloat16)
+        eps = float(self.rms_eps)
+        for i in range(self.dec_layers):
+            A = lambda k: a[f"{lm}layers.{i}.{k}"]
+            wqkv = A("self_attn.qkv.weight").data
+            _lib.call("afk_decode_chain_qkv", x.data_ptr(), A("input_layernorm.weight").data.data_ptr(), eps, wqkv.data_ptr(), wqkv.stride(0), H,
+                      A("self_attn.qkv.bias").data.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos_rows.data_ptr(), q.data_ptr(), Kc[i].data_ptr(),
+                      Vt[i].data_ptr(), Spad, start_dev.data_ptr(), Hq, Hkv, D, st)
+            _lib.call("afk_attn_decode_fused", q.data_ptr(), nq, D, Kc[i].data_ptr(), Smax * nk, nk, D, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                      o.data_ptr(), nq, D, krange.data_ptr(), 1, Hq, Hkv, D, float(D ** -0.5), ns, aws.data_ptr(), st)
+            wo = A("self_attn.o_proj.weight").data
+            x2 = torch.empty_like(x)
+            _lib.call("afk_decode_chain_linear_residual", o.data_ptr(), wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x2.data_ptr(), st)
+            wgu = A("mlp.gate_up.weight").data
+            I = wgu.shape[0] // 2
+            act = torch.empty((1, I), device=dev, dtype=torch.bfloat16)
+            _lib.call("afk_decode_chain_gate_up", x2.data_ptr(), A("post_attention_layernorm.weight").data.data_ptr(), eps, wgu.data_ptr(), wgu.stride(0), I, H,
+                      act.data_ptr(), st)
+            wd = A("mlp.down_proj.weight").data
+            x = torch.empty_like(x2)
+            _lib.call("afk_decode_chain_linear_residual", act.data_ptr(), wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), x.data_ptr(), st)
+        y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
+        return y
+
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
         st["nxt"].copy_(self._select_token(self._decode_logits(st), st.get("sampling")))
@@ -942,7 +984,9 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         x = st["emb"].index_select(0, st["nxt"])
         pos1 = (st["cur"] - st["lo"]).contiguous()
         kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
-        if self.decode_fused_glue and B <= ops.GEMV_MAX_M and self.D in (64, 128) and self.decode_splits > 0 and ops.SPLITK:
+        if self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H <= 4096 and self.H % 8 == 0:
+            y = self._decode_layers_chain(x.contiguous(), st["cache"], pos1, kr1, st["cur"])
+        elif self.decode_fused_glue and B <= ops.GEMV_MAX_M and self.D in (64, 128) and self.decode_splits > 0 and ops.SPLITK:
             y = self._decode_layers_fused(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"])
         else:
             y = self._decode_layers(x, B, 1, None, st["cache"], pos1, kr1, False, start_dev=st["cur"])

@@ -254,6 +254,11 @@ int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit);
 int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                     const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
                     int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
+/* the same in ONE launch: the last chunk block of each (batch, head) pair merges the chunks (agent-scope release / acquire around an arrival counter, no waiting).
+ * The last B * Hq words of the workspace are those counters: zero before the first call, left at zero by every call. */
+int afk_attn_decode_fused(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
+                          const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
+                          int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
 
 /* Decode-step glue (csrc/decode_glue.hip): the weight-streaming first pass alone, and one kernel per Linear of a decoder layer that sums
  * its fp32 partials ws[splits][M][N] and applies everything up to the next Linear's input (one live row per call today: M <= AFK_GEMV_MAX_M; same arithmetic and bf16
@@ -266,6 +271,16 @@ int afk_decode_qkv_finish(const float* ws, int splits, int M, const void* bias, 
 int afk_decode_residual_rmsnorm(const float* ws, int splits, int M, int N, const void* residual, const void* w, float eps, void* x_out,
                                 void* h_out, void* stream);
 int afk_decode_swiglu(const float* ws, int splits, int M, int I, void* a_out, void* stream);
+
+/* Decode step, ONE sequence, one launch per Linear (csrc/decode_chain.hip, round 4): a wave owns two complete output rows (no split-K partials), the
+ * RMSNorm of the consumer's input is computed in its prologue and bias / RoPE / cache append / residual / SwiGLU in the producer's epilogue - five launches
+ * per decoder layer with afk_attn_decode(nsplit = 1).  Same arithmetic and bf16 rounding points as the stand-alone kernels; oracle lines: modeling_qwen2.py:46-48
+ * (SwiGLU), :112-135 (RoPE), :213-214 (cache), :247-252 (RMSNorm), :284-297 (residuals).  x: the residual stream / activation row [K]; K <= 4096 where a norm is fused. */
+int afk_decode_chain_qkv(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int K, const void* bias, const void* cos_t,
+                         const void* sin_t, const int* pos, void* q_out, void* kcache, void* vtcache, int spad, const int* start_dev, int Hq,
+                         int Hkv, int D, void* stream);
+int afk_decode_chain_linear_residual(const void* x, const void* W, int64_t ldw, int N, int K, const void* residual, void* out, void* stream);
+int afk_decode_chain_gate_up(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K, void* act_out, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

@@ -683,11 +683,30 @@ def test_generate_fused_decode_glue_matches_unfused(dev):
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
     m = _model(dev)
     kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=12)
+    m.decode_chain = False  # B = 1 would otherwise take csrc/decode_chain.hip (next test)
     m.decode_fused_glue = True
     a = m.generate(_gen_prompt(g).to(dev), **kw)
     m.decode_fused_glue = False
     b = m.generate(_gen_prompt(g).to(dev), **kw)
     assert torch.equal(a, b), (a[:, -12:], b[:, -12:])
+
+
+def test_generate_decode_chain_matches_glue_path(dev):
+    """single-sequence decode on five launches per layer (csrc/decode_chain.hip: no split-K partials, norm in the consumer's prologue, the Q = 1 attention
+    merged by its last block) produces the same tokens as the ten-launch split-K + glue path - greedy, graph-replayed and eager"""
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m = _model(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev), max_new_tokens=16)
+    outs = {}
+    for chain in (True, False):
+        for graph in (True, False):
+            m.decode_chain = chain
+            outs[(chain, graph)] = m.generate(_gen_prompt(g).to(dev), use_graph=graph, **kw)
+    m.decode_chain = True
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), (k, v[:, -16:], ref[:, -16:])
+    assert len(set(ref[0, -16:].tolist())) >= 6
 
 
 def test_generate_left_padded_batch_matches_single(dev):

@@ -872,6 +872,84 @@ def test_attn_decode_split_kv(dev, D, Hq, Hkv):
             _cmp(f"attn_decode ns={ns} b={b}", o[b], ref, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 28, 4), (64, 4, 4)])
+def test_attn_decode_fused_last_block_merges(dev, D, Hq, Hkv):
+    """afk_attn_decode_fused: ONE launch - the last chunk block of every (batch, head) pair merges the chunks - must give exactly the two-launch
+    result (same fold, chunk order), leave its arrival counters at zero, and do so on repeated calls into the same workspace (HIP-graph replay)"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    B, Smax = 2, 1300
+    spad = ops.pad64(Smax)
+    nk, nq = Hkv * D, Hq * D
+    q = _rand((B, nq), dev, 1.0, 1).to(BF)
+    kc = _rand((B, Smax, nk), dev, 1.0, 2).to(BF)
+    vt = _rand((B, Hkv, D, spad), dev, 1.0, 3).to(BF)
+    kr = torch.tensor([[0, 1300], [41, 900]], device=dev, dtype=torch.int32)
+    for ns in (8, 3, 1):
+        nws = _lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns)
+        o2 = torch.empty((B, nq), device=dev, dtype=BF)
+        ws2 = torch.empty(nws, device=dev, dtype=torch.float32)
+        args = lambda o, ws: (q.data_ptr(), nq, D, kc.data_ptr(), Smax * nk, nk, D, vt.data_ptr(), Hkv * D * spad, spad, o.data_ptr(), nq, D,
+                              kr.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, ws.data_ptr(), ops._stream())
+        _lib.call("afk_attn_decode", *args(o2, ws2))
+        ws1 = torch.zeros(nws, device=dev, dtype=torch.float32)
+        for rep in range(4):
+            o1 = torch.full((B, nq), 7.0, device=dev, dtype=BF)
+            _lib.call("afk_attn_decode_fused", *args(o1, ws1))
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2), (ns, rep, float((o1.float() - o2.float()).abs().max()))
+            assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
+
+
+def test_decode_chain_kernels_vs_standalone_sequence(dev):
+    """csrc/decode_chain.hip (one launch per Linear of a single-sequence decode step, RMSNorm in the consumer's prologue, bias / RoPE / cache append /
+    residual / SwiGLU in the producer's epilogue) against the stand-alone kernel sequence with the same rounding points, at the AF3-7B widths"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    H, Hq, Hkv, D, I = 3584, 28, 4, 128, 18944
+    nq, nk = Hq * D, Hkv * D
+    N = nq + 2 * nk
+    st = ops._stream()
+    x = _rand((1, H), dev, 1.0, 1).to(BF)
+    nw = (1 + 0.1 * _rand((H,), dev, seed=2)).to(BF)
+    w = _rand((N, H), dev, 0.02, 3).to(BF)
+    bias = _rand((N,), dev, 0.1, 4).to(BF)
+    Smax, pos, start = 256, 37, 41
+    spad = ops.pad64(Smax)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    fr = torch.arange(64, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    pos_t = torch.tensor([pos], device=dev, dtype=torch.int32)
+    start_t = torch.tensor([start], device=dev, dtype=torch.int32)
+    # reference: rmsnorm -> gemm + bias -> rope -> cache append, on the stand-alone kernels
+    h, _ = ops.rmsnorm_fwd(x, nw, 1e-6)
+    qkv = ops.gemm_nt(h, w, bias=bias)
+    ops.rope_(qkv, cos, sin, S=1, nheads=Hq + Hkv, D=D, pos=pos_t)
+    Kc = torch.zeros((1, Smax, nk), device=dev, dtype=BF)
+    Vt = torch.zeros((1, Hkv, D, spad), device=dev, dtype=BF)
+    q = torch.zeros((1, nq), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_qkv", x.data_ptr(), nw.data_ptr(), 1e-6, w.data_ptr(), w.stride(0), H, bias.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+              pos_t.data_ptr(), q.data_ptr(), Kc.data_ptr(), Vt.data_ptr(), spad, start_t.data_ptr(), Hq, Hkv, D, st)
+    torch.cuda.synchronize()
+    _cmp("chain q", q[0], qkv[0, :nq].float(), atol=3e-2, rtol=2e-2)
+    _cmp("chain k", Kc[0, start], qkv[0, nq:nq + nk].float(), atol=3e-2, rtol=2e-2)
+    _cmp("chain v", Vt[0, :, :, start].reshape(-1), qkv[0, nq + nk:].float(), atol=3e-2, rtol=2e-2)
+    assert float(Kc.float().abs().sum() - Kc[0, start].float().abs().sum()) == 0.0, "only the new cache slot may be written"
+    # o_proj / down: linear + residual
+    for K_ in (nq, I):
+        a = _rand((1, K_), dev, 1.0, 5).to(BF)
+        wl = _rand((H, K_), dev, 0.02, 6).to(BF)
+        out = torch.empty((1, H), device=dev, dtype=BF)
+        _lib.call("afk_decode_chain_linear_residual", a.data_ptr(), wl.data_ptr(), wl.stride(0), H, K_, x.data_ptr(), out.data_ptr(), st)
+        _cmp(f"chain linear+residual K={K_}", out, ops.gemm_nt(a, wl, residual=x).float(), atol=3e-2, rtol=2e-2)
+    # gate|up: rmsnorm prologue + SwiGLU epilogue
+    wgu = _rand((2 * I, H), dev, 0.02, 7).to(BF)
+    act = torch.empty((1, I), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_gate_up", x.data_ptr(), nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), st)
+    _cmp("chain gate|up", act, ops.silu_mul_fwd(ops.gemm_nt(h, wgu)).float(), atol=3e-2, rtol=3e-2)
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()
