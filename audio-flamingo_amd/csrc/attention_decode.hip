@@ -19,14 +19,19 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int MAXCHUNK = 4096;  // keys per split held in LDS
 
 // FINAL (round 4, afk_attn_decode_fused): no combine launch - the LAST chunk block of a (batch, head) pair to finish merges the chunks itself.
-// Every block publishes (m, l, o[D]), fences at agent scope (the chunks of one head run on different XCDs whose L2s are not coherent) and bumps the
-// pair's counter; the block that reads nsplit - 1 acquires, folds the partials in chunk order (same arithmetic as attn_decode_combine_kernel: the
-// result does not depend on which block came last), writes the bf16 output and resets the counter for the next call.  Nobody waits for anybody.
+// The chunks of one head run on different XCDs whose L2s are not coherent, so the hand-over goes through memory:
+//   sync 1 (default): every (m, l, o) word is an agent-scope atomic store (write-through, `sc1`), each wave drains its stores (vmcnt 0) before the block
+//           barrier, thread 0 then bumps the pair's counter; the block that reads nsplit - 1 loads the slots with agent-scope atomic loads (they bypass
+//           the non-coherent cache levels).  No cache-wide operation anywhere.
+//   sync 0: plain stores, thread 0 brackets the counter update with agent-scope fences after / before the block barrier (L2 write-back + invalidate of
+//           the whole XCD L2: measured 29 us per launch when EVERY thread fenced, profiles/r04_decode_chain.md).
+// The merge folds the partials in chunk order with the arithmetic of attn_decode_combine_kernel - the result does not depend on which block came last -
+// and resets the counter for the next call.  Nobody waits for anybody.
 template <int D, bool FINAL>
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
                                                                 int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
                                                                 int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
-                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
+                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs, int sync) {
     constexpr int LPK = D / 8;        // lanes per key row
     constexpr int KPP = 256 / LPK;    // keys scored per pass of the block
     constexpr int PARTS = 256 / D;    // threads per output feature
@@ -44,65 +49,105 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     float* out = ws + ((int64_t)(b * Hq + h) * nsplit + split) * (D + 2);
     __shared__ int last_flag;
     // FINAL: the merge by the last-arriving block of this (batch, head) pair
+    const bool wt = FINAL && sync == 1;
+    auto put = [&](float* dst, float v) {
+        if (wt) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = v;
+    };
+    auto get = [&](const float* src) -> float {
+        return wt ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : __builtin_nontemporal_load(src);
+    };
     auto finish = [&]() {
         if (!FINAL) return;
         int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
-        __threadfence();                                   // release (every writer): this block's (m, l, o) reach memory before the counter moves
+        if (wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores have completed
         __syncthreads();
         if (t == 0) {
-            const int prev = atomicAdd(&counters[b * Hq + h], 1);
+            if (!wt) __threadfence();                      // release: the block's (m, l, o) leave this XCD's L2 before the counter moves
+            const int prev = __hip_atomic_fetch_add(&counters[b * Hq + h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last_flag = (prev == nsplit - 1);
-            if (last_flag) counters[b * Hq + h] = 0;       // self-resetting: the next call (a HIP-graph replay) starts from zero again
+            if (last_flag) {
+                __hip_atomic_store(&counters[b * Hq + h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting: the next call (a HIP-graph replay) starts from zero
+                if (!wt) __threadfence();                  // acquire: drop what this CU / XCD cached of the other blocks' slots
+            }
         }
         __syncthreads();
         if (!last_flag) return;
-        __threadfence();                                   // acquire (every reader): drop whatever this CU / XCD cached of the other blocks' slots
+        // all nsplit x (D + 2) words in parallel (4 independent loads per thread and round: a loop of dependent round trips to memory costs ~1 us each),
+        // staged in the score buffer - nobody reads scores any more
         const float* base = ws + (int64_t)(b * Hq + h) * nsplit * (D + 2);
+        const int tot = nsplit * (D + 2);
+        for (int i = t; i < tot; i += 1024) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + 256 * u < tot) sc[i + 256 * u] = v[u];
+        }
+        __syncthreads();
         if (t < D) {
             float M = NEG_INF;
-            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, __builtin_nontemporal_load(base + s * (D + 2)));
+            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, sc[s * (D + 2)]);
             float L = 0.f, o = 0.f;
             if (M != NEG_INF) {
                 for (int s = 0; s < nsplit; ++s) {
-                    const float w = __builtin_amdgcn_exp2f(__builtin_nontemporal_load(base + s * (D + 2)) - M);
-                    L += w * __builtin_nontemporal_load(base + s * (D + 2) + 1);
-                    o += w * __builtin_nontemporal_load(base + s * (D + 2) + 2 + t);
+                    const float w = __builtin_amdgcn_exp2f(sc[s * (D + 2)] - M);
+                    L += w * sc[s * (D + 2) + 1];
+                    o += w * sc[s * (D + 2) + 2 + t];
                 }
             }
             O[b * o_bs + h * o_hs + t] = (bf16)(L > 0.f ? o / L : 0.f);
         }
     };
     if (n <= 0 || c1 <= lo) {
-        if (t < D) out[2 + t] = 0.f;
-        if (t == 0) { out[0] = NEG_INF; out[1] = 0.f; }
+        if (t < D) put(out + 2 + t, 0.f);
+        if (t == 0) { put(out, NEG_INF); put(out + 1, 0.f); }
         finish();
         return;
     }
-    // ---- scores
-    const int sub = t % LPK;
+    // ---- every load of the first 128 keys of the chunk is issued before anything is computed (round 4: the one-load-per-pass loops spent a memory
+    // round trip per 16 keys - 10 us for a 100-key chunk); longer chunks continue in batches of the same depth
+    constexpr int UK = 128 / KPP;     // key passes per batch
+    constexpr int UV = 128 / (PARTS * 8);   // value loads per batch and thread
+    const int sub = t % LPK, krow = t / LPK;
     const bf16x8 qv = *(const bf16x8*)(Q + b * q_bs + h * q_hs + sub * 8);
-    const bf16* kbase = Kc + b * k_bs + hk * k_hs + sub * 8;
+    const bf16* kbase = Kc + b * k_bs + hk * k_hs + sub * 8 + (int64_t)c0 * k_rs;
+    const int d = t % D, pt = t / D;
+    const bf16* vrow = Vt + b * vt_bs + ((int64_t)hk * D + d) * spad + c0;  // c0 % 8 == 0
+    bf16x8 kv[UK], vv[UV];
+    auto load_k = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < UK; ++u) kv[u] = *(const bf16x8*)(kbase + (int64_t)min(i0 + u * KPP + krow, n - 1) * k_rs);   // clamped: valid memory, masked below
+    };
+    auto load_v = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < UV; ++u) {
+            const int g = g0 + (u * PARTS + pt) * 8;
+            vv[u] = *(const bf16x8*)(vrow + (g < n ? g : 0));
+        }
+    };
+    load_k(0);
+    load_v(0);
     const float c2 = scale * LOG2E;
     float mx = NEG_INF;
-    for (int i0 = 0; i0 < n; i0 += KPP) {
-        const int i = i0 + t / LPK;
-        const int key = c0 + i;
-        float s = 0.f;
-        if (i < n) {
-            const bf16x8 kv = *(const bf16x8*)(kbase + (int64_t)key * k_rs);
+    for (int i0 = 0; i0 < n; i0 += 128) {
+        if (i0) load_k(i0);
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int i = i0 + u * KPP + krow;
+            const int key = c0 + i;
+            float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bf16x2 a = {qv[2 * e], qv[2 * e + 1]}, c = {kv[2 * e], kv[2 * e + 1]};
+                const bf16x2 a = {qv[2 * e], qv[2 * e + 1]}, c = {kv[u][2 * e], kv[u][2 * e + 1]};
                 s = __builtin_amdgcn_fdot2_f32_bf16(a, c, s, false);
             }
-        }
 #pragma unroll
-        for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        if (i < n && sub == 0) {
-            const float v = (key >= lo) ? s * c2 : NEG_INF;  // log2 domain
-            sc[i] = v;
+            for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (i < n && sub == 0) sc[i] = (key >= lo) ? s * c2 : NEG_INF;  // log2 domain
+            if (i < n && key >= lo) mx = fmaxf(mx, s * c2);
         }
-        if (i < n && key >= lo) mx = fmaxf(mx, s * c2);
     }
     mx = wave_max(mx);
     if ((t & 63) == 0) red[t >> 6] = mx;
@@ -120,14 +165,16 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     __syncthreads();
     const float l = red[4] + red[5] + red[6] + red[7];
     // ---- partial output: thread -> feature d, part -> every PARTS-th group of 8 keys
-    const int d = t % D, pt = t / D;
-    const bf16* vrow = Vt + b * vt_bs + ((int64_t)hk * D + d) * spad + c0;  // c0 % 8 == 0
     float acc = 0.f;
-    for (int g = pt * 8; g < n; g += PARTS * 8) {
-        const bf16x8 vv = *(const bf16x8*)(vrow + g);
+    for (int g0 = 0; g0 < n; g0 += 128) {
+        if (g0) load_v(g0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (g + e < n) acc += sc[g + e] * (float)vv[e];
+        for (int u = 0; u < UV; ++u) {
+            const int g = g0 + (u * PARTS + pt) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (g + e < n) acc += sc[g + e] * (float)vv[u][e];
+        }
     }
     part[t] = acc;
     __syncthreads();
@@ -135,9 +182,9 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
         float o = 0.f;
 #pragma unroll
         for (int q = 0; q < PARTS; ++q) o += part[t + q * D];
-        out[2 + t] = o;
+        put(out + 2 + t, o);
     }
-    if (t == 0) { out[0] = m; out[1] = l; }
+    if (t == 0) { put(out, m); put(out + 1, l); }
     finish();
 }
 
@@ -168,18 +215,20 @@ static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_h
                             int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
     AFK_REQUIRE(Q && Kc && Vt && O && krange && workspace, "afk_attn_decode: null pointer");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && (D == 64 || D == 128) && nsplit >= 1 && nsplit <= 64, "afk_attn_decode: bad shape");
+    AFK_REQUIRE(!fused || nsplit * (D + 2) <= MAXCHUNK, "afk_attn_decode_fused: nsplit * (D + 2) <= %d (the merge stages the partials in the score buffer)", MAXCHUNK);
     AFK_REQUIRE(q_bs % 8 == 0 && q_hs % 8 == 0 && k_bs % 8 == 0 && k_rs % 8 == 0 && k_hs % 8 == 0 && vt_bs % 8 == 0 && spad % 8 == 0,
                 "afk_attn_decode: strides must keep 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)nsplit, (unsigned)Hq, (unsigned)B);
+    static const int sync = [] { const char* e = getenv("AFK_ATTN_DECODE_SYNC"); return e ? atoi(e) : 1; }();
 #define AFK_AD(DD)                                                                                                                                      \
     do {                                                                                                                                                \
         if (fused) {                                                                                                                                    \
             hipLaunchKernelGGL((attn_decode_split_kernel<DD, true>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,   \
-                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs);                            \
+                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs, sync);                      \
         } else {                                                                                                                                        \
             hipLaunchKernelGGL((attn_decode_split_kernel<DD, false>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,  \
-                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs);                            \
+                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs, sync);                      \
             hipLaunchKernelGGL(attn_decode_combine_kernel<DD>, dim3((unsigned)Hq, (unsigned)B), dim3(DD), 0, st, workspace, nsplit, (bf16*)O, o_bs,     \
                                o_hs, Hq);                                                                                                               \
         }                                                                                                                                               \

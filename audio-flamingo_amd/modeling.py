@@ -858,11 +858,13 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     decode_chain = os.environ.get("AFK_DECODE_CHAIN", "1") == "1"   # single sequence: one launch per Linear (csrc/decode_chain.hip), five per layer
 
-    def _decode_layers_chain(self, x, cache, pos_rows, krange, start_dev):
+    def _decode_layers_chain(self, x, cache, pos_rows, krange, start_dev, aws=None, head=None):
         """one new position of ONE sequence: five launches per decoder layer (round 4; ten on the split-K + glue path above).  Every Linear is one
-        weight-streaming launch in which a wave owns two complete output rows: the qkv launch normalises the residual stream in its prologue and applies
-        bias / RoPE / cache append in its epilogue, o_proj and down_proj add the residual, gate|up normalises in its prologue and multiplies
-        silu(gate) * up in its epilogue; the Q = 1 attention merges its key chunks in the last block to finish (afk_attn_decode_fused)."""
+        weight-streaming launch in which a group of waves owns eight complete output rows: the qkv launch normalises the residual stream in its prologue
+        and applies bias / RoPE / cache append in its epilogue, o_proj and down_proj add the residual, gate|up normalises in its prologue and multiplies
+        silu(gate) * up in its epilogue; the Q = 1 attention merges its key chunks in the last block to finish (afk_attn_decode_fused).  With `head`
+        (lm_head weight, rows % 8 == 0) the final RMSNorm + lm_head are one more launch of the same kind and the fp32 logits [1, V] come back; otherwise
+        the normalised hidden row."""
         a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
         Kc, Vt = cache
         Smax, Spad = Kc.shape[2], Vt.shape[4]
@@ -872,7 +874,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         cos, sin = self._rope_tables(int(self.config.text_config.max_position_embeddings))
         st = ops._stream()
         ns = self.decode_splits
-        aws = torch.zeros(_lib.load().afk_attn_decode_workspace_floats(1, Hq, D, ns), device=dev, dtype=torch.float32)   # arrival counters start at zero
+        if aws is None:
+            aws = self._decode_attn_workspace(dev)
         q = torch.empty((1, nq), device=dev, dtype=torch.bfloat16)
         o = torch.empty((1, nq), device=dev, dtype=torch.bfloat16)
         eps = float(self.rms_eps)
@@ -895,13 +898,22 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             wd = A("mlp.down_proj.weight").data
             x = torch.empty_like(x2)
             _lib.call("afk_decode_chain_linear_residual", act.data_ptr(), wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), x.data_ptr(), st)
+        if head is not None:
+            logits = torch.empty((1, head.shape[0]), device=dev, dtype=torch.float32)
+            _lib.call("afk_decode_chain_lm_head", x.data_ptr(), a[lm + "norm.weight"].data.data_ptr(), eps, head.data_ptr(), head.stride(0), head.shape[0], H,
+                      logits.data_ptr(), st)
+            return logits
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
+
+    def _decode_attn_workspace(self, dev):
+        """partials + arrival counters of afk_attn_decode_fused for one sequence; the counters start at zero and every launch leaves them at zero"""
+        return torch.zeros(_lib.load().afk_attn_decode_workspace_floats(1, self.Hq, self.D, self.decode_splits), device=dev, dtype=torch.float32)
 
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
         st["nxt"].copy_(self._select_token(self._decode_logits(st), st.get("sampling")))
-        st["cur"].add_(1)
+        (st["advance"] if "advance" in st else st["cur"]).add_(1)   # single sequence: cur, position and the key-range end live in one tensor (generate())
 
     @torch.no_grad()
     def _beam_search(self, ids, last_hidden, cache, lo, nb, max_new, eos_token_id, pad_token_id, length_penalty, early_stopping):
@@ -982,10 +994,18 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         """logits [B, V] (fp32) of the position after st["nxt"]: one pass over the decoder weights, cache append at st["cur"] (not advanced here)"""
         B = st["nxt"].shape[0]
         x = st["emb"].index_select(0, st["nxt"])
-        pos1 = (st["cur"] - st["lo"]).contiguous()
-        kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
-        if self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H <= 4096 and self.H % 8 == 0:
-            y = self._decode_layers_chain(x.contiguous(), st["cache"], pos1, kr1, st["cur"])
+        if "pos1" in st:   # single sequence (generate()): views of the step-state tensor, advanced by ONE add per step
+            pos1, kr1 = st["pos1"], st["kr1"]
+        else:
+            pos1 = (st["cur"] - st["lo"]).contiguous()
+            kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
+        if self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H % 8 == 0 and (self.decode_splits * (self.D + 2)) <= 4096:
+            if "aws" not in st:
+                st["aws"] = self._decode_attn_workspace(x.device)
+            head = st["head"] if st["head"].shape[0] % 8 == 0 else None
+            y = self._decode_layers_chain(x.contiguous(), st["cache"], pos1, kr1, st["cur"], aws=st["aws"], head=head)
+            if head is not None:
+                return y
         elif self.decode_fused_glue and B <= ops.GEMV_MAX_M and self.D in (64, 128) and self.decode_splits > 0 and ops.SPLITK:
             y = self._decode_layers_fused(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"])
         else:
@@ -1075,6 +1095,9 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
               "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling,
               "nxt": self._select_token(ops.gemm_nt(last, self.arena["lm_head.weight"].data).float(), sampling)}
+        if B == 1:   # one device tensor [lo, key-range end, cache slot, position] -> the views the kernels read; one add per step moves the last three
+            state = torch.cat([lo, torch.tensor([S0 + 1, S0], device=dev, dtype=torch.int32), S0 - lo]).contiguous()
+            st.update(cur=state[2:3], kr1=state[0:2], pos1=state[3:4], advance=state[1:4])
         toks = [st["nxt"].clone()]
         if use_graph is None:
             use_graph = max_new_tokens > 3

@@ -281,6 +281,9 @@ int afk_decode_chain_qkv(const void* x, const void* norm_w, float eps, const voi
                          int Hkv, int D, void* stream);
 int afk_decode_chain_linear_residual(const void* x, const void* W, int64_t ldw, int N, int K, const void* residual, void* out, void* stream);
 int afk_decode_chain_gate_up(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K, void* act_out, void* stream);
+/* final RMSNorm (Qwen2Model.norm, modeling_qwen2.py:383) + lm_head (modeling_audioflamingo3.py lm_head on the last position) of one row in one launch:
+ * logits[N] fp32 = float(bf16(W . (norm_w * bf16(x * rstd))))  - the values `lm_head(norm(x)).float()` holds.  N % 8 == 0, K % 8 == 0. */
+int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

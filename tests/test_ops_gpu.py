@@ -901,11 +901,14 @@ def test_attn_decode_fused_last_block_merges(dev, D, Hq, Hkv):
             assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
 
 
-def test_decode_chain_kernels_vs_standalone_sequence(dev):
+@pytest.mark.parametrize("knobs", ["", "S=1,1,1,1,1", "S=2,2,2,2,2 R=4,4,4,4,4", "S=8,8,8,8,8", "S=4,4,4,4,4 R=4,4,4,4,4"])
+def test_decode_chain_kernels_vs_standalone_sequence(dev, knobs, monkeypatch):
     """csrc/decode_chain.hip (one launch per Linear of a single-sequence decode step, RMSNorm in the consumer's prologue, bias / RoPE / cache append /
     residual / SwiGLU in the producer's epilogue) against the stand-alone kernel sequence with the same rounding points, at the AF3-7B widths"""
     from audio_flamingo_amd import _lib
     ops = _ops()
+    for kv in knobs.split():   # rows per group / waves per group of every launch form (csrc/decode_chain.hip chain_knob)
+        monkeypatch.setenv("AFK_CHAIN_" + kv[0], kv[2:])
     H, Hq, Hkv, D, I = 3584, 28, 4, 128, 18944
     nq, nk = Hq * D, Hkv * D
     N = nq + 2 * nk
@@ -948,6 +951,13 @@ def test_decode_chain_kernels_vs_standalone_sequence(dev):
     act = torch.empty((1, I), device=dev, dtype=BF)
     _lib.call("afk_decode_chain_gate_up", x.data_ptr(), nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), st)
     _cmp("chain gate|up", act, ops.silu_mul_fwd(ops.gemm_nt(h, wgu)).float(), atol=3e-2, rtol=3e-2)
+    # final norm + lm_head: fp32 logits holding bf16 values
+    V = 4096
+    wh = _rand((V, H), dev, 0.02, 8).to(BF)
+    logits = torch.empty((1, V), device=dev, dtype=torch.float32)
+    _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), st)
+    assert torch.equal(logits, logits.to(BF).float())
+    _cmp("chain lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
 
 
 # ------------------------------------------------------------------------------------------------ CE
