@@ -18,6 +18,17 @@ constexpr float NEG_INF = -INFINITY;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int MAXCHUNK = 4096;  // keys per split held in LDS
 
+#ifdef AFK_PROBES
+// timing probe (PROBES=1 builds only, tools/probes/probe_attn_decode.py): thread 0 of every block stamps the 100 MHz wall clock at the phase boundaries
+__device__ long long* g_stamps = nullptr;
+#define AFK_STAMP(k)                                                                                                      \
+    do {                                                                                                                  \
+        if (g_stamps && threadIdx.x == 0) g_stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define AFK_STAMP(k)
+#endif
+
 // FINAL (round 4, afk_attn_decode_fused): no combine launch - the LAST chunk block of a (batch, head) pair to finish merges the chunks itself.
 // The chunks of one head run on different XCDs whose L2s are not coherent, so the hand-over goes through memory:
 //   sync 1 (default): every (m, l, o) word is an agent-scope atomic store (write-through, `sc1`), each wave drains its stores (vmcnt 0) before the block
@@ -27,19 +38,20 @@ constexpr int MAXCHUNK = 4096;  // keys per split held in LDS
 //           the whole XCD L2: measured 29 us per launch when EVERY thread fenced, profiles/r04_decode_chain.md).
 // The merge folds the partials in chunk order with the arithmetic of attn_decode_combine_kernel - the result does not depend on which block came last -
 // and resets the counter for the next call.  Nobody waits for anybody.
-template <int D, bool FINAL>
+template <int D, int FINAL>   // FINAL: 0 = partials only (afk_attn_decode), 1 = merge by the last block, write-through hand-over, 2 = the same with agent-scope fences
 __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
                                                                 int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
                                                                 int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
-                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs, int sync) {
+                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
     constexpr int LPK = D / 8;        // lanes per key row
     constexpr int KPP = 256 / LPK;    // keys scored per pass of the block
     constexpr int PARTS = 256 / D;    // threads per output feature
-    __shared__ float sc[MAXCHUNK];
+    __shared__ __attribute__((aligned(16))) float sc[MAXCHUNK + 8];
     __shared__ float red[8];
     __shared__ float part[256];
     const int split = blockIdx.x, nsplit = gridDim.x, h = blockIdx.y, b = blockIdx.z, hk = h / (Hq / Hkv);
     const int t = threadIdx.x;
+    AFK_STAMP(0);
     const int lo = krange[2 * b], hi = krange[2 * b + 1];
     // chunk boundaries on multiples of 8 keys (16-byte alignment of the transposed value rows)
     const int a0 = lo & ~7, total = max(hi - a0, 0);
@@ -49,7 +61,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     float* out = ws + ((int64_t)(b * Hq + h) * nsplit + split) * (D + 2);
     __shared__ int last_flag;
     // FINAL: the merge by the last-arriving block of this (batch, head) pair
-    const bool wt = FINAL && sync == 1;
+    constexpr bool wt = FINAL == 1;
     auto put = [&](float* dst, float v) {
         if (wt) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *dst = v;
@@ -62,6 +74,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
         int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
         if (wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores have completed
         __syncthreads();
+        AFK_STAMP(5);
         if (t == 0) {
             if (!wt) __threadfence();                      // release: the block's (m, l, o) leave this XCD's L2 before the counter moves
             const int prev = __hip_atomic_fetch_add(&counters[b * Hq + h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -72,6 +85,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
             }
         }
         __syncthreads();
+        AFK_STAMP(6);
         if (!last_flag) return;
         // all nsplit x (D + 2) words in parallel (4 independent loads per thread and round: a loop of dependent round trips to memory costs ~1 us each),
         // staged in the score buffer - nobody reads scores any more
@@ -80,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
         for (int i = t; i < tot; i += 1024) {
             float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));
+            for (int u = 0; u < 4; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));   // clamped: four loads in flight, no branch between them
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (i + 256 * u < tot) sc[i + 256 * u] = v[u];
@@ -99,6 +113,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
             }
             O[b * o_bs + h * o_hs + t] = (bf16)(L > 0.f ? o / L : 0.f);
         }
+        AFK_STAMP(7);
     };
     if (n <= 0 || c1 <= lo) {
         if (t < D) put(out + 2 + t, 0.f);
@@ -127,6 +142,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
             vv[u] = *(const bf16x8*)(vrow + (g < n ? g : 0));
         }
     };
+    AFK_STAMP(1);
     load_k(0);
     load_v(0);
     const float c2 = scale * LOG2E;
@@ -152,6 +168,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     mx = wave_max(mx);
     if ((t & 63) == 0) red[t >> 6] = mx;
     __syncthreads();
+    AFK_STAMP(2);
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     const float msafe = (m == NEG_INF) ? 0.f : m;
     float ls = 0.f;
@@ -164,20 +181,29 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     if ((t & 63) == 0) red[4 + (t >> 6)] = ls;
     __syncthreads();
     const float l = red[4] + red[5] + red[6] + red[7];
+    AFK_STAMP(3);
     // ---- partial output: thread -> feature d, part -> every PARTS-th group of 8 keys
+    // (branch-free: written as `if (g + e < n) acc += ...` the compiler emitted one branch + one LDS round trip per key - 2.7 us of a 11 us launch)
     float acc = 0.f;
     for (int g0 = 0; g0 < n; g0 += 128) {
         if (g0) load_v(g0);
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
-            const int g = g0 + (u * PARTS + pt) * 8;
+            const int g = g0 + (u * PARTS + pt) * 8;   // wave-uniform
+            const int gg = g < n ? g : 0;
+            const f32x4 p0 = *(const f32x4*)&sc[gg], p1 = *(const f32x4*)&sc[gg + 4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (g + e < n) acc += sc[g + e] * (float)vv[u][e];
+            for (int e = 0; e < 8; ++e) {
+                const bool in = g + e < n;
+                const float pe = in ? (e < 4 ? p0[e & 3] : p1[e & 3]) : 0.f;
+                const float ve = in ? (float)vv[u][e] : 0.f;   // what lies behind the last key may be anything
+                acc = fmaf(pe, ve, acc);
+            }
         }
     }
     part[t] = acc;
     __syncthreads();
+    AFK_STAMP(4);
     if (t < D) {
         float o = 0.f;
 #pragma unroll
@@ -221,20 +247,22 @@ static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_h
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)nsplit, (unsigned)Hq, (unsigned)B);
     static const int sync = [] { const char* e = getenv("AFK_ATTN_DECODE_SYNC"); return e ? atoi(e) : 1; }();
-#define AFK_AD(DD)                                                                                                                                      \
-    do {                                                                                                                                                \
-        if (fused) {                                                                                                                                    \
-            hipLaunchKernelGGL((attn_decode_split_kernel<DD, true>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,   \
-                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs, sync);                      \
-        } else {                                                                                                                                        \
-            hipLaunchKernelGGL((attn_decode_split_kernel<DD, false>), grid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs,  \
-                               k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs, sync);                      \
-            hipLaunchKernelGGL(attn_decode_combine_kernel<DD>, dim3((unsigned)Hq, (unsigned)B), dim3(DD), 0, st, workspace, nsplit, (bf16*)O, o_bs,     \
-                               o_hs, Hq);                                                                                                               \
-        }                                                                                                                                               \
+#define AFK_AD_ARGS (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs
+#define AFK_AD(DD)                                                                                                                       \
+    do {                                                                                                                                 \
+        if (fused && sync == 1) {                                                                                                        \
+            hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1>), grid, dim3(256), 0, st, AFK_AD_ARGS);                                  \
+        } else if (fused) {                                                                                                              \
+            hipLaunchKernelGGL((attn_decode_split_kernel<DD, 2>), grid, dim3(256), 0, st, AFK_AD_ARGS);                                  \
+        } else {                                                                                                                         \
+            hipLaunchKernelGGL((attn_decode_split_kernel<DD, 0>), grid, dim3(256), 0, st, AFK_AD_ARGS);                                  \
+            hipLaunchKernelGGL(attn_decode_combine_kernel<DD>, dim3((unsigned)Hq, (unsigned)B), dim3(DD), 0, st, workspace, nsplit, (bf16*)O, o_bs, \
+                               o_hs, Hq);                                                                                                \
+        }                                                                                                                                \
     } while (0)
     if (D == 128) AFK_AD(128); else AFK_AD(64);
 #undef AFK_AD
+#undef AFK_AD_ARGS
     AFK_LAUNCH_CHECK("afk_attn_decode");
     return AFK_OK;
 }
@@ -244,6 +272,12 @@ extern "C" int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const 
                                int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
     return attn_decode_impl(false, Q, q_bs, q_hs, Kc, k_bs, k_rs, k_hs, Vt, vt_bs, spad, O, o_bs, o_hs, krange, B, Hq, Hkv, D, scale, nsplit, workspace, stream);
 }
+
+#ifdef AFK_PROBES
+extern "C" int afk_probe_attn_decode_stamps(long long* device_buffer) {   // [blocks][8] int64, or null to switch the stamps off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &device_buffer, sizeof(device_buffer)) == hipSuccess ? AFK_OK : AFK_ERR_LAUNCH;
+}
+#endif
 
 // one launch: the last chunk block of every (batch, head) pair merges the chunks.  workspace: afk_attn_decode_workspace_floats(...) floats whose LAST B * Hq words are the
 // per-pair arrival counters - they must read ZERO before the first call (the kernel leaves them at zero)

@@ -17,6 +17,17 @@
 
 namespace {
 
+#ifdef AFK_PROBES
+// timing probe (PROBES=1 builds only, tools/probes/probe_decode_chain.py): lane 0 of every wave stamps the 100 MHz wall clock at the phase boundaries
+__device__ long long* g_chain_stamps = nullptr;
+#define AFK_STAMP(k)                                                                                                              \
+    do {                                                                                                                          \
+        if (g_chain_stamps && (threadIdx.x & 63) == 0) g_chain_stamps[((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define AFK_STAMP(k)
+#endif
+
 enum { PRO_PLAIN = 0, PRO_RMS = 1 };
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
 
@@ -38,7 +49,9 @@ struct ChainArgs {
     int spad, Hq, Hkv, D;
     const bf16* residual; // EPI_RESID [N]
     bf16* out;            // EPI_RESID [N], EPI_SWIGLU [N / 2]
-    float* out_f32;       // EPI_LOGITS [N]
+    float* out_f32;       // EPI_LOGITS [N] (or null)
+    float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
+    int* part_idx;        //             ... and its row (lowest row among equals); or null
 };
 
 __device__ __forceinline__ float dot8(const bf16x8 a, const bf16x8 b, float acc) {
@@ -54,13 +67,20 @@ __device__ __forceinline__ float dot8(const bf16x8 a, const bf16x8 b, float acc)
 // S waves share one group and split its K chunks (chunk = 512 elements = one 16-byte load per lane and row) round-robin; a 256-thread block holds
 // 4 / S groups (S = 8: 512 threads, one group).  S and R trade waves in flight against per-wave work: the narrow Linears of a 7B decoder (qkv: 4 608
 // rows, o_proj / down: 3 584) need S = 4 / 8 to put >= 2 300 waves on the chip, gate|up (37 888 rows) and the lm_head (152 064) run S = 1.
+#ifdef AFK_CHAIN_WPE
+#define AFK_CHAIN_WPE_ATTR __attribute__((amdgpu_waves_per_eu(AFK_CHAIN_WPE)))
+#else
+#define AFK_CHAIN_WPE_ATTR
+#endif
 template <int PRO, int EPI, int S, int R>
-__global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_kernel(ChainArgs p, int ngroups) {
+__global__ __launch_bounds__(64 * (S > 4 ? S : 4)) AFK_CHAIN_WPE_ATTR void gemv_chain_kernel(ChainArgs p, int ngroups) {
     constexpr int G = S >= 4 ? 1 : 4 / S;   // groups per block
     constexpr int HR = R / 2;
     constexpr int LPR = 64 / R;             // after the reduce-scatter lane LPR * j holds row j
     __shared__ float red[G][S][R];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // the wave index as a scalar: rows, row pointers and chunk indices stay in SGPRs
+    AFK_STAMP(0);
     const int gi = w / S, ks = w % S;
     const int grp = blockIdx.x * G + gi;
     const bool live = grp < ngroups;
@@ -166,6 +186,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_kernel(ChainA
         ss = wave_sum(ss);
         rstd = rsqrtf(ss * (1.f / (float)p.K) + p.eps);
     }
+    AFK_STAMP(1);
     auto fma_chunk = [&](const Chunk& q) {
         bf16x8 xv = q.x;
         if (PRO == PRO_RMS) {
@@ -178,6 +199,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_kernel(ChainA
     if (live) {
         for (int cc = c; cc < nch; cc += 2 * S) {
             fma_chunk(q0);
+            if (cc == c) AFK_STAMP(2);
             if (cc + 2 * S < nch) load_chunk(q0, cc + 2 * S);
             if (cc + S < nch) {
                 fma_chunk(q1);
@@ -206,8 +228,10 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_kernel(ChainA
             }
         }
     }
+    AFK_STAMP(3);
     if ((lane & (LPR - 1)) == 0) red[gi][ks][lane / LPR] = acc[0];
     __syncthreads();
+    AFK_STAMP(4);
     if (ks != 0 || !live) return;
     // wave 0 of the group: lane r < R finishes row r (K slices summed in slice order)
     float tot = 0.f;
@@ -235,9 +259,62 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_kernel(ChainA
         if (lane >= HR) return;
         p.out[erow] = (bf16)(rbf(mine * sigmoid_f(mine)) * u);
     } else {
-        if (lane >= R) return;
-        p.out_f32[erow] = rbf(tot);   // the bf16 logit nn.Linear returns, widened (what .float() of it gives)
+        const float mine = rbf(tot);   // the bf16 logit nn.Linear returns, widened (what .float() of it gives)
+        if (p.out_f32 && lane < R) p.out_f32[erow] = mine;
+        if (p.part_val) {              // greedy decoding: the group's (max, argmax), ties to the lowest row (torch.argmax's order) - lanes 0 .. R-1 hold rows in order
+            float bv = mine;
+            int bi = erow;
+#pragma unroll
+            for (int o = R / 2; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { p.part_val[g] = bv; p.part_idx[g] = bi; }
+        }
     }
+}
+
+// greedy token selection + everything else between two decode steps of ONE sequence, in one launch (round 4: argmax, the copy into the next-token buffer, the
+// position update and the embedding lookup of the next step were four launches of ~5-10 us each): reduce the lm_head launch's per-group (max, argmax) pairs,
+// write the token (next_token, tokens_out[cur + tok_off]), advance [key-range end, cache slot, position] and fetch the token's embedding row for the next step
+__global__ __launch_bounds__(1024) void decode_select_greedy_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int nparts,
+                                                                    long long* __restrict__ next_token, long long* __restrict__ tokens_out, int tok_off,
+                                                                    int* __restrict__ state, const bf16* __restrict__ emb, int64_t ld_emb, int H,
+                                                                    bf16* __restrict__ x_out) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int tok;
+    const int t = threadIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = t; i < nparts; i += 1024) {
+        const float v = part_val[i];
+        const int ix = part_idx[i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((t & 63) == 0) { sv[t >> 6] = bv; si[t >> 6] = bi; }
+    __syncthreads();
+    if (t == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;   // every logit NaN / -inf: torch.argmax answers 0 for an all -inf row
+        tok = bi;
+        next_token[0] = bi;
+        if (tokens_out) tokens_out[state[2] + tok_off] = bi;
+        state[1] += 1;   // key-range end
+        state[2] += 1;   // cache slot of the next token
+        state[3] += 1;   // its position
+    }
+    __syncthreads();
+    const bf16* row = emb + (int64_t)tok * ld_emb;
+    for (int k = t * 4; k < H; k += 4096) *(bf16x4*)(x_out + k) = *(const bf16x4*)(row + k);
 }
 
 // AFK_CHAIN_S / AFK_CHAIN_R = "qkv,linear(K<=4096),linear(K>4096),gate_up,lm_head" (measurement knobs; 0 = default)
@@ -253,7 +330,7 @@ template <int PRO, int EPI>
 int launch_chain(const ChainArgs& p, int rows, int which, int S_dflt, int R_dflt, bool r4_ok, hipStream_t st) {
     const int S = chain_knob(which, S_dflt, false);
     int R_ = chain_knob(which, R_dflt, true);
-    if (R_ == 4 && !r4_ok) R_ = 8;
+    if (!r4_ok) R_ = 8;
     const int ngroups = rows / R_;
 #define AFK_CHAIN(S_, R__)                                                                                                                          \
     {                                                                                                                                               \
@@ -280,6 +357,12 @@ int launch_chain(const ChainArgs& p, int rows, int which, int S_dflt, int R_dflt
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+#ifdef AFK_PROBES
+extern "C" int afk_probe_decode_chain_stamps(long long* device_buffer) {   // [waves][8] int64, or null to switch the stamps off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps), &device_buffer, sizeof(device_buffer)) == hipSuccess ? AFK_OK : AFK_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int afk_decode_chain_qkv(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int K, const void* bias, const void* cos_t,
                                     const void* sin_t, const int* pos, void* q_out, void* kcache, void* vtcache, int spad, const int* start_dev, int Hq,
@@ -313,12 +396,26 @@ extern "C" int afk_decode_chain_gate_up(const void* x, const void* norm_w, float
     return AFK_OK;
 }
 
-// final RMSNorm (Qwen2Model.norm) + lm_head on one row: logits[N] fp32 = float(bf16(W h)) - the values `lm_head(norm(x)).float()` holds
-extern "C" int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits, void* stream) {
-    AFK_REQUIRE(x && norm_w && W && logits && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0, "afk_decode_chain_lm_head: unsupported shape (N %% 8 == 0, K %% 8 == 0)");
+// final RMSNorm (Qwen2Model.norm) + lm_head on one row: logits[N] fp32 = float(bf16(W h)) - the values `lm_head(norm(x)).float()` holds (logits may be null);
+// part_val / part_idx [N / 8] (or null): largest logit and its row per group of eight rows, for afk_decode_select_greedy
+extern "C" int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits, float* part_val,
+                                        int* part_idx, void* stream) {
+    AFK_REQUIRE(x && norm_w && W && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0, "afk_decode_chain_lm_head: unsupported shape (N %% 8 == 0, K %% 8 == 0)");
+    AFK_REQUIRE((logits || part_val) && (!part_val == !part_idx), "afk_decode_chain_lm_head: logits and / or both partial-argmax buffers");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.out_f32 = logits; p.D = 2;
-    launch_chain<PRO_RMS, EPI_LOGITS>(p, N, 4, N / 8 >= 2048 ? 1 : 4, 8, true, ST);
+    p.part_val = part_val; p.part_idx = part_idx;
+    launch_chain<PRO_RMS, EPI_LOGITS>(p, N, 4, N / 8 >= 2048 ? 1 : 4, 8, false, ST);   // always eight rows per group: part_* are indexed by it
     AFK_LAUNCH_CHECK("afk_decode_chain_lm_head");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_select_greedy(const float* part_val, const int* part_idx, int nparts, int64_t* next_token, int64_t* tokens_out, int tok_off, int* state,
+                                        const void* emb, int64_t ld_emb, int H, void* x_out, void* stream) {
+    AFK_REQUIRE(part_val && part_idx && nparts > 0 && next_token && state && emb && x_out && H > 0 && H % 4 == 0 && ld_emb % 4 == 0,
+                "afk_decode_select_greedy: bad arguments (H %% 4 == 0)");
+    hipLaunchKernelGGL(decode_select_greedy_kernel, dim3(1), dim3(1024), 0, ST, part_val, part_idx, nparts, (long long*)next_token, (long long*)tokens_out, tok_off,
+                       state, (const bf16*)emb, ld_emb, H, (bf16*)x_out);
+    AFK_LAUNCH_CHECK("afk_decode_select_greedy");
     return AFK_OK;
 }

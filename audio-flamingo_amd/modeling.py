@@ -858,7 +858,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     decode_chain = os.environ.get("AFK_DECODE_CHAIN", "1") == "1"   # single sequence: one launch per Linear (csrc/decode_chain.hip), five per layer
 
-    def _decode_layers_chain(self, x, cache, pos_rows, krange, start_dev, aws=None, head=None):
+    def _decode_layers_chain(self, x, cache, pos_rows, krange, start_dev, aws=None, head=None, greedy=None):
         """one new position of ONE sequence: five launches per decoder layer (round 4; ten on the split-K + glue path above).  Every Linear is one
         weight-streaming launch in which a group of waves owns eight complete output rows: the qkv launch normalises the residual stream in its prologue
         and applies bias / RoPE / cache append in its epilogue, o_proj and down_proj add the residual, gate|up normalises in its prologue and multiplies
@@ -898,13 +898,25 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             wd = A("mlp.down_proj.weight").data
             x = torch.empty_like(x2)
             _lib.call("afk_decode_chain_linear_residual", act.data_ptr(), wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), x.data_ptr(), st)
+        if greedy is not None:   # generate()'s state dict: the lm_head launch leaves (max, argmax) per eight rows, the select launch does everything up to the next step
+            g = greedy
+            _lib.call("afk_decode_chain_lm_head", x.data_ptr(), a[lm + "norm.weight"].data.data_ptr(), eps, head.data_ptr(), head.stride(0), head.shape[0], H,
+                      None, g["part_val"].data_ptr(), g["part_idx"].data_ptr(), st)
+            _lib.call("afk_decode_select_greedy", g["part_val"].data_ptr(), g["part_idx"].data_ptr(), g["part_val"].numel(), g["nxt"].data_ptr(),
+                      g["tok_buf"].data_ptr(), g["tok_off"], g["state"].data_ptr(), g["emb"].data_ptr(), g["emb"].stride(0), H, g["x0"].data_ptr(), st)
+            return None
         if head is not None:
             logits = torch.empty((1, head.shape[0]), device=dev, dtype=torch.float32)
             _lib.call("afk_decode_chain_lm_head", x.data_ptr(), a[lm + "norm.weight"].data.data_ptr(), eps, head.data_ptr(), head.stride(0), head.shape[0], H,
-                      logits.data_ptr(), st)
+                      logits.data_ptr(), None, None, st)
             return logits
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
+
+    def _chain_ok(self, B):
+        """single-sequence decode on csrc/decode_chain.hip: one launch per Linear (head sizes of the decode attention kernel, 16-byte rows)"""
+        return (self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H % 8 == 0
+                and self.decode_splits * (self.D + 2) <= 4096)
 
     def _decode_attn_workspace(self, dev):
         """partials + arrival counters of afk_attn_decode_fused for one sequence; the counters start at zero and every launch leaves them at zero"""
@@ -912,6 +924,9 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     def _decode_step(self, st):
         """one greedy decode step on static buffers (everything position-dependent lives on the device): HIP-graph capturable"""
+        if "x0" in st:   # greedy, one sequence: 5 launches per layer + lm_head + ONE launch for argmax / token / positions / the next embedding row
+            self._decode_layers_chain(st["x0"], st["cache"], st["pos1"], st["kr1"], st["cur"], aws=st["aws"], head=st["head"], greedy=st)
+            return
         st["nxt"].copy_(self._select_token(self._decode_logits(st), st.get("sampling")))
         (st["advance"] if "advance" in st else st["cur"]).add_(1)   # single sequence: cur, position and the key-range end live in one tensor (generate())
 
@@ -999,7 +1014,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         else:
             pos1 = (st["cur"] - st["lo"]).contiguous()
             kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
-        if self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H % 8 == 0 and (self.decode_splits * (self.D + 2)) <= 4096:
+        if self._chain_ok(B):
             if "aws" not in st:
                 st["aws"] = self._decode_attn_workspace(x.device)
             head = st["head"] if st["head"].shape[0] % 8 == 0 else None
@@ -1097,13 +1112,21 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
               "nxt": self._select_token(ops.gemm_nt(last, self.arena["lm_head.weight"].data).float(), sampling)}
         if B == 1:   # one device tensor [lo, key-range end, cache slot, position] -> the views the kernels read; one add per step moves the last three
             state = torch.cat([lo, torch.tensor([S0 + 1, S0], device=dev, dtype=torch.int32), S0 - lo]).contiguous()
-            st.update(cur=state[2:3], kr1=state[0:2], pos1=state[3:4], advance=state[1:4])
+            st.update(cur=state[2:3], kr1=state[0:2], pos1=state[3:4], advance=state[1:4], state=state)
+            if sampling is None and self._chain_ok(1) and st["head"].shape[0] % 8 == 0:   # greedy: token selection and step bookkeeping stay on the device
+                tok_buf = torch.zeros(max_new_tokens, device=dev, dtype=torch.int64)
+                tok_buf[0] = st["nxt"][0]
+                st.update(x0=st["emb"].index_select(0, st["nxt"]).contiguous(), aws=self._decode_attn_workspace(dev), tok_buf=tok_buf, tok_off=1 - S0,
+                          part_val=torch.empty(st["head"].shape[0] // 8, device=dev, dtype=torch.float32),
+                          part_idx=torch.empty(st["head"].shape[0] // 8, device=dev, dtype=torch.int32))
+        on_device = "x0" in st
+        n_new = 1
         toks = [st["nxt"].clone()]
         if use_graph is None:
             use_graph = max_new_tokens > 3
         graph = None
         for t in range(1, max_new_tokens):
-            if eos_token_id is not None and t % 8 == 0 and bool((torch.stack(toks, 1) == eos_token_id).any(1).all()):
+            if eos_token_id is not None and t % 8 == 0 and bool(((st["tok_buf"][None, :t] if on_device else torch.stack(toks, 1)) == eos_token_id).any(1).all()):
                 break
             if use_graph and t == 2:  # step 1 ran eagerly (lazy one-time initialisation inside the library happens outside the capture)
                 torch.cuda.synchronize()
@@ -1115,8 +1138,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 graph.replay()
             else:
                 self._decode_step(st)
-            toks.append(st["nxt"].clone())
-        new = torch.stack(toks, 1)
+            if not on_device:
+                toks.append(st["nxt"].clone())
+            n_new = t + 1
+        new = st["tok_buf"][None, :n_new].clone() if on_device else torch.stack(toks, 1)
         if eos_token_id is not None:  # everything after a row's first EOS becomes padding (GenerationMixin semantics)
             after = (new == eos_token_id).cumsum(1) - (new == eos_token_id).long() > 0
             new = torch.where(after, torch.full_like(new, pad_token_id if pad_token_id is not None else eos_token_id), new)

@@ -282,8 +282,16 @@ int afk_decode_chain_qkv(const void* x, const void* norm_w, float eps, const voi
 int afk_decode_chain_linear_residual(const void* x, const void* W, int64_t ldw, int N, int K, const void* residual, void* out, void* stream);
 int afk_decode_chain_gate_up(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K, void* act_out, void* stream);
 /* final RMSNorm (Qwen2Model.norm, modeling_qwen2.py:383) + lm_head (modeling_audioflamingo3.py lm_head on the last position) of one row in one launch:
- * logits[N] fp32 = float(bf16(W . (norm_w * bf16(x * rstd))))  - the values `lm_head(norm(x)).float()` holds.  N % 8 == 0, K % 8 == 0. */
-int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits, void* stream);
+ * logits[N] fp32 = float(bf16(W . (norm_w * bf16(x * rstd))))  - the values `lm_head(norm(x)).float()` holds (logits may be null when only the token is wanted).
+ * part_val / part_idx [N / 8] (both or neither): largest logit and its row of every group of eight consecutive rows (ties: lowest row) - the first stage of the
+ * greedy selection GenerationMixin._sample does with torch.argmax (transformers/generation/utils.py:2790).  N % 8 == 0, K % 8 == 0. */
+int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits, float* part_val, int* part_idx,
+                             void* stream);
+/* second stage + the bookkeeping between two decode steps of one sequence, one launch: token = argmax over the nparts pairs (ties: lowest row);
+ * next_token[0] = token; tokens_out[state[2] + tok_off] = token (tokens_out may be null); state = int32 [key-range start, key-range end, cache slot, position]:
+ * the last three += 1; x_out[H] = emb[token][:H] (the embedding lookup of the next step, Qwen2Model.embed_tokens). */
+int afk_decode_select_greedy(const float* part_val, const int* part_idx, int nparts, int64_t* next_token, int64_t* tokens_out, int tok_off, int* state,
+                             const void* emb, int64_t ld_emb, int H, void* x_out, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

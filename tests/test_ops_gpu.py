@@ -955,9 +955,30 @@ def test_decode_chain_kernels_vs_standalone_sequence(dev, knobs, monkeypatch):
     V = 4096
     wh = _rand((V, H), dev, 0.02, 8).to(BF)
     logits = torch.empty((1, V), device=dev, dtype=torch.float32)
-    _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), st)
+    pv = torch.empty(V // 8, device=dev, dtype=torch.float32)
+    pi = torch.empty(V // 8, device=dev, dtype=torch.int32)
+    _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), pv.data_ptr(), pi.data_ptr(), st)
     assert torch.equal(logits, logits.to(BF).float())
     _cmp("chain lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
+    # greedy selection on the device: per-group (max, argmax) + the select launch == torch.argmax (ties: lowest index), state advanced, embedding row fetched
+    assert torch.equal(pv, logits.view(V // 8, 8).max(-1).values)
+    assert torch.equal(pi.long(), logits.view(V // 8, 8).argmax(-1) + 8 * torch.arange(V // 8, device=dev))
+    emb = _rand((V, H), dev, 1.0, 9).to(BF)
+    for tie in (False, True):
+        if tie:   # the maximum twice: the lower row wins
+            top = int(logits.argmax())
+            wh[(top + 1234) % V] = wh[top]
+            _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), pv.data_ptr(), pi.data_ptr(), st)
+            assert int((logits == logits.max()).sum()) >= 2
+        nxt = torch.full((1,), -1, device=dev, dtype=torch.int64)
+        toks = torch.full((8,), -1, device=dev, dtype=torch.int64)
+        state = torch.tensor([3, 41, 40, 37], device=dev, dtype=torch.int32)
+        x0 = torch.zeros((1, H), device=dev, dtype=BF)
+        _lib.call("afk_decode_select_greedy", pv.data_ptr(), pi.data_ptr(), V // 8, nxt.data_ptr(), toks.data_ptr(), 5 - 40, state.data_ptr(), emb.data_ptr(), emb.stride(0), H,
+                  x0.data_ptr(), st)
+        want = int((logits[0] == logits[0].max()).nonzero()[0])
+        assert int(nxt) == want and toks.tolist() == [-1] * 5 + [want, -1, -1] and state.tolist() == [3, 42, 41, 38]
+        assert torch.equal(x0[0], emb[want])
 
 
 # ------------------------------------------------------------------------------------------------ CE

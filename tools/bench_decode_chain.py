@@ -38,7 +38,7 @@ def k_gu(i): _lib.call("afk_decode_chain_gate_up", x.data_ptr(), nw.data_ptr(), 
 Vv = 152064
 Wh = [rnd(Vv, H) for _ in range(2)]
 logits = torch.empty(1, Vv, device=dev, dtype=torch.float32)
-def k_head(i): _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, Wh[i % 2].data_ptr(), H, Vv, H, logits.data_ptr(), st)
+def k_head(i): _lib.call("afk_decode_chain_lm_head", x.data_ptr(), nw.data_ptr(), 1e-6, Wh[i % 2].data_ptr(), H, Vv, H, logits.data_ptr(), None, None, st)
 def k_d(i): _lib.call("afk_decode_chain_linear_residual", actr.data_ptr(), W[i]["d"].data_ptr(), I, H, I, x.data_ptr(), x2.data_ptr(), st)
 
 bytes_ = dict(qkv=2.0 * (nq + 2 * nk) * H, attn=2.0 * 2 * (keys + 1) * nk, attn_two_launches=2.0 * 2 * (keys + 1) * nk, o_proj=2.0 * H * nq, gate_up=2.0 * 2 * I * H, down=2.0 * H * I, lm_head=2.0 * Vv * H)
