@@ -49,7 +49,11 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer._in_capture = True   # the capture pass must not advance t nor record the write of the step scalars into the graph
         try:
-            with torch.cuda.graph(self.graph):
+            # a live process group has a watchdog THREAD that polls its work events; under the default "global" capture mode such a call from another thread
+            # while this one captures invalidates the capture and the watchdog's exception aborts the process (seen 2 / 8 runs of the 1-rank RCCL graph test)
+            import torch.distributed as dist
+            mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.loss = step_body()
         finally:
             optimizer._in_capture = False
