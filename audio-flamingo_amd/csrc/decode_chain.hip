@@ -288,10 +288,18 @@ __global__ __launch_bounds__(1024) void decode_select_greedy_kernel(const float*
     const int t = threadIdx.x;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = t; i < nparts; i += 1024) {
-        const float v = part_val[i];
-        const int ix = part_idx[i];
-        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    for (int i = t; i < nparts; i += 8 * 1024) {   // eight pairs per thread and round trip (19 008 pairs for the AF3 vocabulary: three rounds)
+        float v[8];
+        int ix[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = min(i + 1024 * u, nparts - 1);   // clamped: a repeated pair never changes the result
+            v[u] = part_val[j];
+            ix[u] = part_idx[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > bv || (v[u] == bv && ix[u] < bi)) { bv = v[u]; bi = ix[u]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
