@@ -232,9 +232,16 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const bf16* __restrict__ in
 
 // column sums (bias gradient straight from the row-major output gradient): out[c] (+)= sum_r in[r][c]
 // stage 1: block = 64 columns x one row slice; 32 row-lanes x 8 column-lanes of bf16x8, LDS fold -> partial[slice][c]
+// FUSED (round 4, afk_colsum_bf16_fused): no fold launch - the LAST row slice of a 64-column block to finish folds the slices itself (the hand-over of
+// attention_decode.hip: partials as agent-scope write-through stores, drained before the block barrier, one counter bump per block, the last block reads
+// the slices with agent-scope loads in slice order - the result does not depend on which block came last - and resets the counter).  The fold launch
+// was 6.6 us x 158 bias gradients per step.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ in, int64_t ld, int64_t rows, int cols,
-                                                             float* __restrict__ partial, int rows_per_slice) {
+                                                             float* __restrict__ partial, int rows_per_slice, int* __restrict__ counters,
+                                                             bf16* __restrict__ out, int accumulate) {
     __shared__ float red[32][65];
+    __shared__ int last_flag;
     const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
     const int c0 = blockIdx.x * 64 + cl * 8;
     const int64_t r_begin = (int64_t)blockIdx.y * rows_per_slice;
@@ -252,15 +259,37 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = acc[e];
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int c = blockIdx.x * 64 + threadIdx.x;
-        if (c < cols) {
-            float s = 0.f;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && c < cols) {
+        float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
-            partial[(int64_t)blockIdx.y * cols + c] = s;
-        }
+        for (int k = 0; k < 32; ++k) s += red[k][threadIdx.x];
+        float* dst = partial + (int64_t)blockIdx.y * cols + c;
+        if (FUSED) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = s;
     }
+    if (!FUSED) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores have completed
+    __syncthreads();
+    const int nslices = gridDim.y;
+    if (threadIdx.x == 0) {
+        const int prev = __hip_atomic_fetch_add(&counters[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (prev == nslices - 1);
+        if (last_flag) __hip_atomic_store(&counters[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next call (a graph replay) starts from zero
+    }
+    __syncthreads();
+    if (!last_flag || threadIdx.x >= 64 || c >= cols) return;
+    float s = 0.f;
+    for (int k0 = 0; k0 < nslices; k0 += 8) {   // eight slices per round trip, summed in slice order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(partial + (int64_t)min(k0 + u, nslices - 1) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nslices) s += v[u];
+    }
+    if (accumulate) s += (float)out[c];
+    out[c] = (bf16)s;
 }
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partial, int nslices, int cols, bf16* __restrict__ out,
                                                           int accumulate) {
@@ -836,16 +865,30 @@ extern "C" int afk_colsum_slices(int64_t rows) {
     return (int)s;
 }
 
-extern "C" int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace,
-                               void* stream) {
+static int colsum_impl(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, int* counters, void* stream) {
     AFK_REQUIRE(in && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "afk_colsum_bf16: bad args");
     const int ns = afk_colsum_slices(rows);
     const int rps = (int)afk_cdiv(rows, ns);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)afk_cdiv(cols, 64), (unsigned)ns), dim3(256), 0, ST, (const bf16*)in, ld, rows,
-                       cols, workspace, rps);
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)afk_cdiv(cols, 256)), dim3(256), 0, ST, workspace, ns, cols, (bf16*)out, accumulate);
+    const dim3 grid((unsigned)afk_cdiv(cols, 64), (unsigned)ns);
+    if (counters) {
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, ST, (const bf16*)in, ld, rows, cols, workspace, rps, counters, (bf16*)out, accumulate);
+    } else {
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, ST, (const bf16*)in, ld, rows, cols, workspace, rps, (int*)nullptr, (bf16*)out, accumulate);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)afk_cdiv(cols, 256)), dim3(256), 0, ST, workspace, ns, cols, (bf16*)out, accumulate);
+    }
     AFK_LAUNCH_CHECK("afk_colsum_bf16");
     return AFK_OK;
+}
+
+extern "C" int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, void* stream) {
+    return colsum_impl(in, ld, rows, cols, out, accumulate, workspace, nullptr, stream);
+}
+
+// one launch: counters = ceil(cols / 64) ints that read ZERO before the first call (the kernel leaves them at zero); one counter array per stream
+extern "C" int afk_colsum_bf16_fused(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, int* counters,
+                                     void* stream) {
+    AFK_REQUIRE(counters, "afk_colsum_bf16_fused: null counters");
+    return colsum_impl(in, ld, rows, cols, out, accumulate, workspace, counters, stream);
 }
 
 extern "C" int afk_im2col_conv1(const void* x, int x_is_f32, void* col, int W, int C, int T, void* stream) {

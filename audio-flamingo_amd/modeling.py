@@ -1062,6 +1062,14 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         The decode step is launch-bound in eager mode (~370 small launches per token), so it is captured once into a HIP graph and
         replayed (use_graph=None: whenever more than 3 tokens are requested)."""
         self._require_hip()
+        procs, criteria, streamer = kwargs.pop("logits_processor", None), kwargs.pop("stopping_criteria", None), kwargs.pop("streamer", None)
+        for k in ("return_dict_in_generate", "output_scores", "output_logits", "synced_gpus", "use_model_defaults", "tokenizer", "assistant_model"):
+            if kwargs.get(k):
+                raise AfkError(f"generate({k}=...) is not supported by this implementation")
+            kwargs.pop(k, None)
+        if kwargs:
+            raise AfkError(f"generate(): unknown / unsupported arguments {sorted(kwargs)}")
+        hooks = bool(procs) or bool(criteria) or streamer is not None   # GenerationMixin's per-step callbacks: host code between the steps -> eager steps
         gc = generation_config if generation_config is not None else getattr(self, "generation_config", None)
         if gc is not None:  # explicit arguments win; anything still at its default is taken from the generation config
             pick = lambda cur, default, name: getattr(gc, name, None) if (cur == default and getattr(gc, name, None) is not None) else cur
@@ -1071,6 +1079,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             eos_token_id, pad_token_id = pick(eos_token_id, None, "eos_token_id"), pick(pad_token_id, None, "pad_token_id")
         if num_beams > 1 and (do_sample or not use_cache):
             raise AfkError("generate(num_beams > 1): beam search is deterministic and runs on the KV cache (no do_sample, no use_cache=False)")
+        if hooks and (num_beams > 1 or not use_cache):
+            raise AfkError("generate(logits_processor / stopping_criteria / streamer): greedy or sampled decoding on the KV cache only")
         sampling = None
         if do_sample:
             gen = torch.Generator(device=self.device_)
@@ -1107,18 +1117,22 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         last = y.reshape(B, S0, -1)[:, -1, :].contiguous()
         if num_beams > 1:
             return self._beam_search(ids, last, (Kc, Vt), lo, int(num_beams), int(max_new_tokens), eos_token_id, pad_token_id, float(length_penalty), early_stopping)
+        first_logits = ops.gemm_nt(last, self.arena["lm_head.weight"].data).float()
+        if procs:
+            first_logits = procs(ids, first_logits)
         st = {"cache": (Kc, Vt), "lo": lo, "head": self.arena["lm_head.weight"].data, "emb": self.arena[self._lm + "embed_tokens.weight"].data,
-              "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling,
-              "nxt": self._select_token(ops.gemm_nt(last, self.arena["lm_head.weight"].data).float(), sampling)}
+              "cur": torch.full((1,), S0, device=dev, dtype=torch.int32), "sampling": sampling, "nxt": self._select_token(first_logits, sampling)}
         if B == 1:   # one device tensor [lo, key-range end, cache slot, position] -> the views the kernels read; one add per step moves the last three
             state = torch.cat([lo, torch.tensor([S0 + 1, S0], device=dev, dtype=torch.int32), S0 - lo]).contiguous()
             st.update(cur=state[2:3], kr1=state[0:2], pos1=state[3:4], advance=state[1:4], state=state)
-            if sampling is None and self._chain_ok(1) and st["head"].shape[0] % 8 == 0:   # greedy: token selection and step bookkeeping stay on the device
+            if sampling is None and not hooks and self._chain_ok(1) and st["head"].shape[0] % 8 == 0:   # greedy: token selection and step bookkeeping stay on the device
                 tok_buf = torch.zeros(max_new_tokens, device=dev, dtype=torch.int64)
                 tok_buf[0] = st["nxt"][0]
                 st.update(x0=st["emb"].index_select(0, st["nxt"]).contiguous(), aws=self._decode_attn_workspace(dev), tok_buf=tok_buf, tok_off=1 - S0,
                           part_val=torch.empty(st["head"].shape[0] // 8, device=dev, dtype=torch.float32),
                           part_idx=torch.empty(st["head"].shape[0] // 8, device=dev, dtype=torch.int32))
+        if hooks:
+            return self._generate_with_hooks(ids, st, first_logits, int(max_new_tokens), procs, criteria, streamer, eos_token_id, pad_token_id)
         on_device = "x0" in st
         n_new = 1
         toks = [st["nxt"].clone()]
@@ -1146,6 +1160,43 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             after = (new == eos_token_id).cumsum(1) - (new == eos_token_id).long() > 0
             new = torch.where(after, torch.full_like(new, pad_token_id if pad_token_id is not None else eos_token_id), new)
         return torch.cat([ids, new], dim=1)
+
+    @torch.no_grad()
+    def _generate_with_hooks(self, ids, st, logits, max_new, procs, criteria, streamer, eos_token_id, pad_token_id):
+        """GenerationMixin._sample's loop with its per-step callbacks (transformers/generation/utils.py:2730-2830): scores = logits_processor(input_ids,
+        logits); token = argmax / multinomial; finished rows emit pad_token_id; streamer.put(tokens) (the prompt first, streamer.end() at the end);
+        a row finishes on EOS or when stopping_criteria(input_ids, scores) says so.  Host code runs between the steps, so they are enqueued eagerly
+        (no HIP graph, token selection through torch) - the decode kernels are the ones of the graph path."""
+        B = ids.shape[0]
+        dev = ids.device
+        eos = None if eos_token_id is None else torch.as_tensor(eos_token_id, device=dev).reshape(-1)
+        pad = pad_token_id if pad_token_id is not None else (int(eos[0]) if eos is not None else 0)
+        done = torch.zeros(B, device=dev, dtype=torch.bool)
+        seq = ids
+        if streamer is not None:
+            streamer.put(ids.cpu())
+        for t in range(max_new):
+            if t > 0:
+                logits = self._decode_logits(st)        # appends the K / V of st["nxt"] at the cache slot st["cur"]
+                (st["advance"] if "advance" in st else st["cur"]).add_(1)
+                if procs:
+                    logits = procs(seq, logits)
+            tok = self._select_token(logits, st.get("sampling"))
+            tok = torch.where(done, torch.full_like(tok, pad), tok)
+            seq = torch.cat([seq, tok[:, None]], dim=1)
+            if streamer is not None:
+                streamer.put(tok.cpu())
+            if eos is not None:
+                done = done | torch.isin(tok, eos)
+            if criteria:
+                r = criteria(seq, logits)
+                done = done | (r.to(dev).reshape(-1).bool() if torch.is_tensor(r) else torch.full_like(done, bool(r)))
+            if bool(done.all()):
+                break
+            st["nxt"].copy_(tok)
+        if streamer is not None:
+            streamer.end()
+        return seq
 
     @torch.no_grad()
     def _generate_recompute(self, ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id):

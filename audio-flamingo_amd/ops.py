@@ -223,12 +223,30 @@ def splitk_plan_256(M, N, K):
     return max(1, min(16, K // 512, SPLITK_ROUND // t256))
 
 
+COLSUM_FUSED = os.environ.get("AFK_COLSUM_FUSED", "1") == "1"   # one launch (the last row slice folds); 0: partial + fold launches (rounds 1-3)
+_COLSUM_COUNTERS = {}
+
+
+def _colsum_counters(dev, n):
+    """arrival counters of afk_colsum_bf16_fused: zero before the first launch, left at zero by every launch; one array per (device, stream) because
+    launches on different streams may overlap in time"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _COLSUM_COUNTERS.get(key)
+    if t is None or t.numel() < n:
+        t = _COLSUM_COUNTERS[key] = torch.zeros(max(n, 4096), device=dev, dtype=torch.int32)
+    return t
+
+
 def colsum(x, out, *, accumulate=False):
     """out[c] (+)= sum_r x[r][c]   (bias gradient)"""
     rows, cols = x.shape
     ns = _lib.load().afk_colsum_slices(rows)
     ws = torch.empty(ns * cols, device=x.device, dtype=torch.float32)
-    _lib.call("afk_colsum_bf16", x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), int(accumulate), ws.data_ptr(), _stream())
+    if COLSUM_FUSED:
+        cnt = _colsum_counters(x.device, (cols + 63) // 64)
+        _lib.call("afk_colsum_bf16_fused", x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), int(accumulate), ws.data_ptr(), cnt.data_ptr(), _stream())
+    else:
+        _lib.call("afk_colsum_bf16", x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), int(accumulate), ws.data_ptr(), _stream())
     return out
 
 

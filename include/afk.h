@@ -144,6 +144,10 @@ int afk_rowsum_bf16(const void* in, int64_t ld, int C, void* out, int rows, int 
  * workspace = afk_colsum_slices(rows) * cols floats */
 int afk_colsum_slices(int64_t rows);
 int afk_colsum_bf16(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, void* stream);
+/* the same in ONE launch: the last row slice of every 64-column block folds the slices (fixed slice order: bit-identical to afk_colsum_bf16).
+ * counters: ceil(cols / 64) ints that must read zero before the first call; the kernel leaves them at zero.  Launches that may overlap in time
+ * (different streams) need different counter arrays. */
+int afk_colsum_bf16_fused(const void* in, int64_t ld, int64_t rows, int cols, void* out, int accumulate, float* workspace, int* counters, void* stream);
 
 /* ---- Flamingo glue (BASELINE config 4; stand-in oracle lines: transformers/models/idefics) --------------------------------
  * ReLU of the Perceiver MLP (perceiver.py:171-187); tanh-gated residual of the gated cross-attention layer

@@ -173,6 +173,16 @@ def test_colsum(dev):
         out = torch.ones(cols, device=dev, dtype=BF)
         ops.colsum(x, out, accumulate=True)
         _cmp("colsum", out, x.float().sum(0) + 1.0, atol=0.02 * math.sqrt(rows) + 0.05, rtol=1e-2)
+        # one launch (the last row slice of a column block folds, round 4) == partial + fold launches, bit for bit, call after call on the same counters
+        assert ops.COLSUM_FUSED
+        try:
+            ops.COLSUM_FUSED = False
+            two = ops.colsum(x, torch.ones(cols, device=dev, dtype=BF), accumulate=True)
+        finally:
+            ops.COLSUM_FUSED = True
+        for _ in range(3):
+            assert torch.equal(ops.colsum(x, torch.ones(cols, device=dev, dtype=BF), accumulate=True), two)
+        assert int(ops._colsum_counters(dev, 1).abs().sum()) == 0
 
 
 def test_gemm_identity_layout(dev):
