@@ -28,6 +28,7 @@ __device__ long long* g_chain_stamps = nullptr;
 #define AFK_STAMP(k)
 #endif
 
+#define AFK_CHAIN_BATCH_MAX 8
 enum { PRO_PLAIN = 0, PRO_RMS = 1 };
 enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
 
@@ -50,6 +51,9 @@ struct ChainArgs {
     const bf16* residual; // EPI_RESID [N]
     bf16* out;            // EPI_RESID [N], EPI_SWIGLU [N / 2]
     float* out_f32;       // EPI_LOGITS [N] (or null)
+    // batched form (gemv_chain_batched_kernel): M input rows, row strides in elements
+    int M, pos_stride;
+    int64_t ldx, ld_res, ld_out, ldq, k_bs, vt_bs;
     float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
     int* part_idx;        //             ... and its row (lowest row among equals); or null
 };
@@ -325,6 +329,302 @@ __global__ __launch_bounds__(1024) void decode_select_greedy_kernel(const float*
     for (int k = t * 4; k < H; k += 4096) *(bf16x4*)(x_out + k) = *(const bf16x4*)(row + k);
 }
 
+// 2 .. 8 sequences per step: the same row groups and K split, MB input rows against every weight vector (the weights are still read once per step).
+// The inputs arrive normalised (the RMSNorm of MB rows in every wave's prologue would cost more VALU than the dot products): PRO_PLAIN only, eight rows per
+// group; R x MB sums per lane, reduce-scattered so that lane (r * MB + m) finishes row r of sequence m.
+template <int EPI, int S, int MB>
+__global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_batched_kernel(ChainArgs p, int ngroups) {
+    constexpr int R = 8, HR = 4, V = R * MB;
+    constexpr int G = S >= 4 ? 1 : 4 / S;
+    constexpr int LPV = 64 / V;
+    static_assert(V <= 64 && (MB & (MB - 1)) == 0, "R x MB sums are reduce-scattered over one wave");
+    __shared__ float red[G][S][V];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gi = w / S, ks = w % S;
+    const int grp = blockIdx.x * G + gi;
+    const bool live = grp < ngroups;
+    const int g = live ? grp : 0;
+    int rA, rB;
+    const int half = p.D >> 1, nq = p.Hq * p.D, nk = p.Hkv * p.D;
+    const int rot_groups = (p.Hq + p.Hkv) * half / HR;
+    if (EPI == EPI_QKV) {
+        if (g < rot_groups) {
+            const int per_head = half / HR;
+            rA = (g / per_head) * p.D + (g % per_head) * HR;
+            rB = rA + half;
+        } else {
+            rA = nq + nk + R * (g - rot_groups);
+            rB = rA + HR;
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        rA = HR * g;
+        rB = (p.N >> 1) + rA;
+    } else {
+        rA = R * g;
+        rB = rA + HR;
+    }
+    const bf16* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = p.W + (int64_t)(r < HR ? rA + r : rB + r - HR) * p.ldw;
+    const int nch = (p.K + 511) >> 9;
+    auto load_w = [&](bf16x8(&dst)[R], int c) {
+        const int k = (c << 9) + lane * 8;
+        const int kk = k < p.K ? k : 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dst[r] = __builtin_nontemporal_load((const bf16x8*)(wrow[r] + kk));
+    };
+    float acc[R * MB];
+#pragma unroll
+    for (int i = 0; i < R * MB; ++i) acc[i] = 0.f;
+    bf16x8 w0[R], w1[R];
+    const int c = ks;
+    if (live && c < nch) load_w(w0, c);
+    if (live && c + S < nch) load_w(w1, c + S);
+    auto fma_chunk = [&](const bf16x8(&wv)[R], int cc) {
+        const int k = (cc << 9) + lane * 8;
+        const bool ok = k < p.K;
+        const int kk = ok ? k : 0;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            bf16x8 xv = *(const bf16x8*)(p.x + (int64_t)min(m, p.M - 1) * p.ldx + kk);   // rows >= M repeat the last row; their sums are dropped
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = (bf16)0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r * MB + m] = dot8(wv[r], xv, acc[r * MB + m]);
+        }
+    };
+    if (live) {
+        for (int cc = c; cc < nch; cc += 2 * S) {
+            fma_chunk(w0, cc);
+            if (cc + 2 * S < nch) load_w(w0, cc + 2 * S);
+            if (cc + S < nch) {
+                fma_chunk(w1, cc + S);
+                if (cc + 3 * S < nch) load_w(w1, cc + 3 * S);
+            }
+        }
+    }
+    {   // reduce-scatter of the V per-lane sums: lane LPV * j ends up with sum j = r * MB + m
+        int n = V;
+#pragma unroll
+        for (int sft = 5; sft >= 0; --sft) {
+            const int st = 1 << sft;
+            const bool up = (lane >> sft) & 1;
+            if (n > 1) {
+                const int h = n >> 1;
+#pragma unroll
+                for (int i = 0; i < V / 2; ++i)
+                    if (i < h) {
+                        const float lo = acc[i], hi_ = acc[i + h];
+                        acc[i] = (up ? hi_ : lo) + __shfl_xor(up ? lo : hi_, st, 64);
+                    }
+                n = h;
+            } else {
+                acc[0] += __shfl_xor(acc[0], st, 64);
+            }
+        }
+    }
+    if ((lane & (LPV - 1)) == 0) red[gi][ks][lane / LPV] = acc[0];
+    __syncthreads();
+    if (ks != 0 || !live) return;
+    const int j = lane & (V - 1);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < S; ++q) tot += red[gi][q][j];
+    const int r = j / MB, m = j % MB;
+    const int row = r < HR ? rA + r : rB + r - HR;
+    const bool mine_ok = lane < V && m < p.M;
+    if (EPI == EPI_QKV) {
+        const float mine = rbf(tot + (float)p.bias[row]);
+        const float other = __shfl_xor(mine, HR * MB, 64);
+        if (!mine_ok) return;
+        const int start = *p.start;
+        if (g < rot_groups) {
+            const int64_t ps = (int64_t)p.pos[m * p.pos_stride] * p.D + row % p.D;
+            const float rot = r < HR ? -other : other;
+            const float o = rbf(rbf(mine * (float)p.cos_t[ps]) + rbf(rot * (float)p.sin_t[ps]));
+            if (row < nq) p.q_out[m * p.ldq + row] = (bf16)o;
+            else p.Kc[m * p.k_bs + (int64_t)start * nk + (row - nq)] = (bf16)o;
+        } else {
+            p.Vt[m * p.vt_bs + (int64_t)(row - nq - nk) * p.spad + start] = (bf16)mine;
+        }
+    } else if (EPI == EPI_RESID) {
+        if (!mine_ok) return;
+        p.out[m * p.ld_out + row] = (bf16)(rbf(tot) + (float)p.residual[m * p.ld_res + row]);
+    } else if (EPI == EPI_SWIGLU) {
+        const float mine = rbf(tot);
+        const float u = __shfl_xor(mine, HR * MB, 64);
+        if (!mine_ok || r >= HR) return;
+        p.out[m * p.ld_out + row] = (bf16)(rbf(mine * sigmoid_f(mine)) * u);
+    } else {
+        if (!mine_ok) return;
+        p.out_f32[m * p.ld_out + row] = rbf(tot);
+    }
+}
+
+// The batched form on the matrix pipe.  With 8 input rows the dot-product form above issues 256 v_dot2 per 8 KiB of weights and wave - it is VALU-bound at
+// ~5 TB/s (gate|up 53.6 us against 42.5 us for one row).  v_mfma_f32_32x32x16_bf16 does the same contraction for 32 weight rows x up to 32 input rows in 32
+// cycles per KiB of weights and wave.  A group = 32 output rows (two runs of 16); S waves of a block split K into contiguous slices of 64-element blocks.
+// The weights cannot feed the MFMA straight from global memory at speed: its A operand wants lane -> (row l & 31, 16-byte piece l >> 5), i.e. 32 rows x 32
+// bytes per load instruction - measured 2.4 TB/s (quarter lines).  So a wave loads row-contiguous (8 rows x 128 bytes per instruction, non-temporal), parks two
+// 64-element blocks in its PRIVATE 8 KiB of LDS (16-byte pieces xor-swizzled by (row >> 1) & 7: conflict-free writes and fragment reads, as gemm.hip) and
+// reads the fragments back - LDS operations of one wave execute in order, so no barrier is involved until the slices' 32 x M sums meet at the end.  The next
+// two blocks' loads are issued before the current ones are multiplied.  The B operand (lane -> sequence l & 31, same piece) comes from the L2-resident input
+// rows; lanes beyond M repeat row M - 1 and feed result columns nobody reads.
+// RG = 16 (the narrow Linears: twice the groups, so twice the waves and bytes in flight): rows 16 .. 31 of the A operand repeat rows 0 .. 15 and their results are dropped.
+template <int EPI, int S, int RG>
+__global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
+    constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
+    constexpr int JR = RG / 8;          // load instructions per 64-element block (8 rows x 128 bytes each)
+    constexpr int NB = 8 / JR;          // blocks per stage: eight loads in flight per register set either way
+    constexpr int BLK = RG * 128;       // bytes of a staged block
+    static_assert(S >= 4 && S <= 16 && (RG == 32 || RG == 16), "256 finishing threads; S x 8 KiB of (dynamic) LDS");
+    extern __shared__ __attribute__((aligned(16))) char stage_dyn[];
+    char(*stage)[8192] = (char(*)[8192])stage_dyn;
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = blockIdx.x;
+    int rA, rB;
+    const int half = p.D >> 1, nq = p.Hq * p.D, nk = p.Hkv * p.D;
+    const int rot_groups = (p.Hq + p.Hkv) * half / HR;
+    if (EPI == EPI_QKV) {
+        if (g < rot_groups) {
+            const int per_head = half / HR;
+            rA = (g / per_head) * p.D + (g % per_head) * HR;
+            rB = rA + half;
+        } else {
+            rA = nq + nk + R * (g - rot_groups);
+            rB = rA + HR;
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        rA = HR * g;
+        rB = (p.N >> 1) + rA;
+    } else {
+        rA = R * g;
+        rB = rA + HR;
+    }
+    // this wave's K slice in blocks of 64 elements (K % 64 == 0)
+    const int nkb = p.K >> 6;
+    const int per = (nkb + S - 1) / S;
+    const int b0 = w * per, b1 = min(b0 + per, nkb);
+    // global side: load j of a block covers group rows 8 j + (lane >> 3), 16-byte piece lane & 7
+    const int rowl = lane >> 3, piece = lane & 7;
+    const bf16* wp[JR];
+    uint32_t wr_off[JR];
+    char* my = &stage[w][0];
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+        const int r = 8 * j + rowl;
+        wp[j] = p.W + (int64_t)(r < HR ? rA + r : rB + r - HR) * p.ldw + piece * 8;
+        wr_off[j] = r * 128 + ((piece ^ ((r >> 1) & 7)) << 4);
+    }
+    const int fr = l31 & (RG - 1);
+    const uint32_t rd_row = fr * 128, rd_swz = (fr >> 1) & 7;
+    const bf16* xp = p.x + (int64_t)min(l31, p.M - 1) * p.ldx + hi * 8;
+    auto gload = [&](bf16x8(&dst)[8], int kb) {   // NB blocks; a block past the slice repeats the slice's last one (valid memory) and is skipped below
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int kk = min(kb + b, b1 - 1) << 6;
+#pragma unroll
+            for (int j = 0; j < JR; ++j) dst[b * JR + j] = __builtin_nontemporal_load((const bf16x8*)(wp[j] + kk));
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    bf16x8 ga[8], gb[8];
+    auto xload2 = [&](bf16x8(&dst)[8], int kb) {   // the B fragments of two blocks (L2-resident input rows)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int kk = min(kb + b, b1 - 1) << 6;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) dst[b * 4 + st] = *(const bf16x8*)(xp + kk + st * 16);
+        }
+    };
+    auto mma2 = [&](const bf16x8(&xv)[8], int kb, int bb) {   // blocks bb, bb + 1 of the stage
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (kb + bb + b < b1) {   // wave-uniform
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const bf16x8 wf = *(const bf16x8*)(my + (bb + b) * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xv[b * 4 + st], acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto consume = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], int kb) {
+        bf16x8 xv[8];
+        xload2(xv, kb);                              // ahead of the next stage's weight loads: loads return in order
+        if (kb + NB < b1) gload(nxt, kb + NB);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
+        mma2(xv, kb, 0);
+        if (NB == 4) {
+            xload2(xv, kb + 2);
+            mma2(xv, kb, 2);
+        }
+    };
+    if (b0 < b1) {
+        gload(ga, b0);
+        for (int kb = b0; kb < b1; kb += 2 * NB) {
+            consume(ga, gb, kb);
+            if (kb + NB < b1) consume(gb, ga, kb + NB);
+        }
+    }
+    // D[i][j]: lane holds column j = l31 (the sequence), rows i = 8 q + 4 hi + e in acc[4 q + e]; the wave's sums go to the head of its own staging area
+    float* red = (float*)my;   // [R][MBX]
+    if (l31 < MBX) {
+#pragma unroll
+        for (int q = 0; q < RG / 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(8 * q + 4 * hi + e) * MBX + l31] = acc[4 * q + e];
+    }
+    __syncthreads();
+    if (threadIdx.x >= R * MBX) return;
+    const int r = threadIdx.x / MBX, m = threadIdx.x % MBX;
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < S; ++q) tot += ((const float*)&stage[q][0])[r * MBX + m];   // K slices summed in slice order
+    float* fin = (float*)&stage[0][4096];   // [R][MBX], nobody's sums live there
+    const int row = r < HR ? rA + r : rB + r - HR;
+    const bool valid = m < p.M;
+    if (EPI == EPI_QKV) {
+        const float mine = rbf(tot + (float)p.bias[row]);
+        fin[r * MBX + m] = mine;
+        __syncthreads();
+        if (!valid) return;
+        const float other = fin[(r ^ HR) * MBX + m];
+        const int start = *p.start;
+        if (g < rot_groups) {
+            const int64_t ps = (int64_t)p.pos[m * p.pos_stride] * p.D + row % p.D;
+            const float rot = r < HR ? -other : other;
+            const float o = rbf(rbf(mine * (float)p.cos_t[ps]) + rbf(rot * (float)p.sin_t[ps]));
+            if (row < nq) p.q_out[m * p.ldq + row] = (bf16)o;
+            else p.Kc[m * p.k_bs + (int64_t)start * nk + (row - nq)] = (bf16)o;
+        } else {
+            p.Vt[m * p.vt_bs + (int64_t)(row - nq - nk) * p.spad + start] = (bf16)mine;
+        }
+    } else if (EPI == EPI_RESID) {
+        if (!valid) return;
+        p.out[m * p.ld_out + row] = (bf16)(rbf(tot) + (float)p.residual[m * p.ld_res + row]);
+    } else if (EPI == EPI_SWIGLU) {
+        const float mine = rbf(tot);
+        fin[r * MBX + m] = mine;
+        __syncthreads();
+        if (!valid || r >= HR) return;
+        const float u = fin[(r + HR) * MBX + m];
+        p.out[m * p.ld_out + row] = (bf16)(rbf(mine * sigmoid_f(mine)) * u);
+    } else {
+        if (!valid) return;
+        p.out_f32[m * p.ld_out + row] = rbf(tot);
+    }
+}
+
 // AFK_CHAIN_S / AFK_CHAIN_R = "qkv,linear(K<=4096),linear(K>4096),gate_up,lm_head" (measurement knobs; 0 = default)
 int chain_knob(int which, int dflt, bool is_r) {   // read per launch (a getenv; nothing inside a replayed graph): the tests switch forms in-process
     int v[5] = {0, 0, 0, 0, 0};
@@ -359,6 +659,61 @@ int launch_chain(const ChainArgs& p, int rows, int which, int S_dflt, int R_dflt
     }
 #undef AFK_CHAIN_R
 #undef AFK_CHAIN
+    return AFK_OK;
+}
+
+template <int EPI>
+int launch_chain_batched(const ChainArgs& p, int rows, int which, int S_dflt, hipStream_t st) {
+    // matrix-pipe form when the shape allows (32- / 16-row groups, 64-element blocks); AFK_CHAIN_MFMA=0 / 1 forces the dot-product / the matrix-pipe form (A/B, tests)
+    const char* e = getenv("AFK_CHAIN_MFMA");
+    const bool shape_ok = rows % 32 == 0 && p.K % 64 == 0 && (EPI != EPI_QKV || ((p.D / 2) % 16 == 0 && (p.Hkv * p.D) % 32 == 0)) && (EPI != EPI_SWIGLU || (rows / 2) % 16 == 0);
+    // measured on the AF3-7B decode step (ms per step, B = 2 / 4 / 8): dot-product form 3.32 / 3.73 / 4.75, matrix-pipe form 3.66 / 3.89 / 4.43 -> MFMA from five rows on
+    const bool use_mfma = e ? e[0] == '1' : p.M >= 5;
+    if (shape_ok && use_mfma) {
+        // 1 184 / 4 752 groups of 32 rows (gate|up, lm_head): 4 K slices.  The narrow Linears need more waves than 32-row groups x 8 slices give: K <= 4 096
+        // (qkv, o_proj): 32-row groups x 8 slices; longer K (down: 296 blocks per row): 16-row groups x 16 slices = 3 584 waves, one 1024-thread block per CU.
+        // AFK_CHAIN_MFMA_NARROW = "rg,s" overrides the narrow form (measurement knob)
+        int rg = p.K > 4096 ? 16 : 32, sl = p.K > 4096 ? 16 : 8;
+        if (const char* c = getenv("AFK_CHAIN_MFMA_NARROW")) sscanf(c, "%d,%d", &rg, &sl);
+#define AFK_MFMA(S_, RG_)                                                                                                                                \
+    do {                                                                                                                                                 \
+        static bool attr_set = false;                                                                                                                    \
+        if (S_ * 8192 > 65536 && !attr_set) {                                                                                                            \
+            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S_, RG_>, hipFuncAttributeMaxDynamicSharedMemorySize, S_ * 8192);              \
+            attr_set = true;                                                                                                                             \
+        }                                                                                                                                                \
+        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S_, RG_>), dim3((unsigned)(rows / RG_)), dim3(64 * S_), S_ * 8192, st, p);                      \
+    } while (0)
+        if (rows / 32 >= 1024) AFK_MFMA(4, 32);
+        else if (rg == 16 && sl == 16) AFK_MFMA(16, 16);
+        else if (rg == 16) AFK_MFMA(8, 16);
+        else AFK_MFMA(8, 32);
+#undef AFK_MFMA
+        return AFK_OK;
+    }
+    const int S = chain_knob(which, S_dflt, false);
+    const int ngroups = rows / 8;
+    const int MB = p.M <= 2 ? 2 : p.M <= 4 ? 4 : 8;
+#define AFK_CHAINB(S_, MB_)                                                                                                                             \
+    {                                                                                                                                                   \
+        constexpr int G_ = S_ >= 4 ? 1 : 4 / S_;                                                                                                        \
+        hipLaunchKernelGGL((gemv_chain_batched_kernel<EPI, S_, MB_>), dim3((unsigned)afk_cdiv(ngroups, G_)), dim3(64 * (S_ > 4 ? S_ : 4)), 0, st, p,    \
+                           ngroups);                                                                                                                    \
+    }
+#define AFK_CHAINB_M(S_)                    \
+    case S_:                                \
+        if (MB == 2) AFK_CHAINB(S_, 2)      \
+        else if (MB == 4) AFK_CHAINB(S_, 4) \
+        else AFK_CHAINB(S_, 8)              \
+        break;
+    switch (S) {
+        AFK_CHAINB_M(1)
+        AFK_CHAINB_M(2)
+        AFK_CHAINB_M(4)
+        AFK_CHAINB_M(8)
+    }
+#undef AFK_CHAINB_M
+#undef AFK_CHAINB
     return AFK_OK;
 }
 
@@ -425,5 +780,55 @@ extern "C" int afk_decode_select_greedy(const float* part_val, const int* part_i
     hipLaunchKernelGGL(decode_select_greedy_kernel, dim3(1), dim3(1024), 0, ST, part_val, part_idx, nparts, (long long*)next_token, (long long*)tokens_out, tok_off,
                        state, (const bf16*)emb, ld_emb, H, (bf16*)x_out);
     AFK_LAUNCH_CHECK("afk_decode_select_greedy");
+    return AFK_OK;
+}
+
+// ---------------------------------------------------------------- 2 .. 8 sequences per step (inputs already normalised where the Linear follows a norm)
+extern "C" int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int K, const void* bias, const void* cos_t,
+                                            const void* sin_t, const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs, void* vtcache, int64_t vt_bs,
+                                            int spad, const int* start_dev, int Hq, int Hkv, int D, void* stream) {
+    AFK_REQUIRE(h && W && bias && cos_t && sin_t && pos && q_out && kcache && vtcache && start_dev, "afk_decode_chain_qkv_batched: null pointer");
+    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_BATCH_MAX && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 && Hq > 0 && Hkv > 0 && D % 16 == 0 && spad > 0,
+                "afk_decode_chain_qkv_batched: unsupported shape (1 <= M <= 8, K %% 8 == 0, head_dim %% 16 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = (Hq + 2 * Hkv) * D; p.K = K;
+    p.bias = (const bf16*)bias; p.cos_t = (const bf16*)cos_t; p.sin_t = (const bf16*)sin_t; p.pos = pos; p.pos_stride = 1; p.start = start_dev;
+    p.q_out = (bf16*)q_out; p.ldq = ldq; p.Kc = (bf16*)kcache; p.k_bs = k_bs; p.Vt = (bf16*)vtcache; p.vt_bs = vt_bs; p.spad = spad; p.Hq = Hq; p.Hkv = Hkv; p.D = D;
+    launch_chain_batched<EPI_QKV>(p, p.N, 0, 4, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_qkv_batched");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual,
+                                                        int64_t ld_res, void* out, int64_t ld_out, void* stream) {
+    AFK_REQUIRE(x && W && residual && out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_batched: bad arguments (1 <= M <= 8, N %% 8 == 0, K %% 8 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
+    p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2;
+    launch_chain_batched<EPI_RESID>(p, N, K > 4096 ? 2 : 1, K > 4096 ? 8 : 4, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_batched");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_chain_gate_up_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int I, int K, void* act_out, int64_t ld_act,
+                                                void* stream) {
+    AFK_REQUIRE(h && W && act_out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && I > 0 && I % 4 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
+                "afk_decode_chain_gate_up_batched: unsupported shape (1 <= M <= 8, I %% 4 == 0, K %% 8 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = 2 * I; p.K = K; p.out = (bf16*)act_out; p.ld_out = ld_act; p.D = 2;
+    launch_chain_batched<EPI_SWIGLU>(p, 2 * I, 3, I / 4 >= 2048 ? 1 : 4, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_gate_up_batched");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_chain_lm_head_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int N, int K, float* logits, int64_t ld_logits,
+                                                void* stream) {
+    AFK_REQUIRE(h && W && logits && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
+                "afk_decode_chain_lm_head_batched: unsupported shape (1 <= M <= 8, N %% 8 == 0, K %% 8 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.out_f32 = logits; p.ld_out = ld_logits; p.D = 2;
+    launch_chain_batched<EPI_LOGITS>(p, N, 4, N / 8 >= 2048 ? 1 : 4, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_lm_head_batched");
     return AFK_OK;
 }

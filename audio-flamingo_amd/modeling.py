@@ -913,6 +913,49 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
 
+    decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
+
+    def _decode_layers_chain_batched(self, x, B, cache, pos_rows, krange, start_dev, aws, head):
+        """one new position of 2 .. 8 sequences: the single-sequence chain with M input rows per launch (`afk_decode_chain_*_batched`: the weights are still
+        read once per step) - RMSNorm stays a launch of its own here (normalising M rows in every wave's prologue would cost more than the dot products): 7
+        launches per layer against ~12 on the split-K + glue path.  -> fp32 logits [B, V]"""
+        a, lm, Hq, Hkv, D = self.arena, self._lm, self.Hq, self.Hkv, self.D
+        Kc, Vt = cache
+        Smax, Spad = Kc.shape[2], Vt.shape[4]
+        nq, nk = Hq * D, Hkv * D
+        H = x.shape[1]
+        dev = x.device
+        cos, sin = self._rope_tables(int(self.config.text_config.max_position_embeddings))
+        st = ops._stream()
+        ns = self.decode_splits
+        eps = float(self.rms_eps)
+        q = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
+        o = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
+        for i in range(self.dec_layers):
+            A = lambda k: a[f"{lm}layers.{i}.{k}"]
+            h, _ = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
+            wqkv = A("self_attn.qkv.weight").data
+            _lib.call("afk_decode_chain_qkv_batched", h.data_ptr(), h.stride(0), B, wqkv.data_ptr(), wqkv.stride(0), H, A("self_attn.qkv.bias").data.data_ptr(),
+                      cos.data_ptr(), sin.data_ptr(), pos_rows.data_ptr(), q.data_ptr(), nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                      start_dev.data_ptr(), Hq, Hkv, D, st)
+            _lib.call("afk_attn_decode_fused", q.data_ptr(), nq, D, Kc[i].data_ptr(), Smax * nk, nk, D, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                      o.data_ptr(), nq, D, krange.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, aws.data_ptr(), st)
+            wo = A("self_attn.o_proj.weight").data
+            x2 = torch.empty_like(x)
+            _lib.call("afk_decode_chain_linear_residual_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H, st)
+            h2, _ = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
+            wgu = A("mlp.gate_up.weight").data
+            I = wgu.shape[0] // 2
+            act = torch.empty((B, I), device=dev, dtype=torch.bfloat16)
+            _lib.call("afk_decode_chain_gate_up_batched", h2.data_ptr(), h2.stride(0), B, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), I, st)
+            wd = A("mlp.down_proj.weight").data
+            x = torch.empty_like(x2)
+            _lib.call("afk_decode_chain_linear_residual_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, st)
+        y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, eps)
+        logits = torch.empty((B, head.shape[0]), device=dev, dtype=torch.float32)
+        _lib.call("afk_decode_chain_lm_head_batched", y.data_ptr(), y.stride(0), B, head.data_ptr(), head.stride(0), head.shape[0], H, logits.data_ptr(), head.shape[0], st)
+        return logits
+
     def _chain_ok(self, B):
         """single-sequence decode on csrc/decode_chain.hip: one launch per Linear (head sizes of the decode attention kernel, 16-byte rows)"""
         return (self.decode_chain and B == 1 and self.D in (64, 128) and self.decode_splits > 0 and self.H % 8 == 0
@@ -1014,6 +1057,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         else:
             pos1 = (st["cur"] - st["lo"]).contiguous()
             kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
+        if (self._chain_ok(1) and 2 <= B <= min(self.decode_chain_batch, 8) and st["head"].shape[0] % 8 == 0 and self.I % 4 == 0):
+            if "aws" not in st:
+                st["aws"] = torch.zeros(_lib.load().afk_attn_decode_workspace_floats(B, self.Hq, self.D, self.decode_splits), device=x.device, dtype=torch.float32)
+            return self._decode_layers_chain_batched(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"], st["aws"], st["head"])
         if self._chain_ok(B):
             if "aws" not in st:
                 st["aws"] = self._decode_attn_workspace(x.device)

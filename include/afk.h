@@ -296,6 +296,16 @@ int afk_decode_chain_lm_head(const void* x, const void* norm_w, float eps, const
  * the last three += 1; x_out[H] = emb[token][:H] (the embedding lookup of the next step, Qwen2Model.embed_tokens). */
 int afk_decode_select_greedy(const float* part_val, const int* part_idx, int nparts, int64_t* next_token, int64_t* tokens_out, int tok_off, int* state,
                              const void* emb, int64_t ld_emb, int H, void* x_out, void* stream);
+/* The same launches for 2 .. 8 sequences decoded together (one new position each; the weights are still read once per step): M input rows h [M][K] (row stride
+ * ldh) that are ALREADY normalised where the Linear follows a norm (Qwen2DecoderLayer :270 / :294, Qwen2Model.norm); pos[M] = position of each sequence's new token,
+ * *start_dev = the cache slot all of them write; q_out [M][Hq*D] (row stride ldq); k_bs / vt_bs = batch strides of the K / V^T caches (elements).  Rounding points as above. */
+int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int K, const void* bias, const void* cos_t, const void* sin_t,
+                                 const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs, void* vtcache, int64_t vt_bs, int spad, const int* start_dev,
+                                 int Hq, int Hkv, int D, void* stream);
+int afk_decode_chain_linear_residual_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
+                                             void* out, int64_t ld_out, void* stream);
+int afk_decode_chain_gate_up_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int I, int K, void* act_out, int64_t ld_act, void* stream);
+int afk_decode_chain_lm_head_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int N, int K, float* logits, int64_t ld_logits, void* stream);
 
 /* ---- loss: ForCausalLMLoss / fixed_cross_entropy, loss/loss_utils.py:33-72 ----------------------------- 
  * logits chunk [rows, V] bf16 is overwritten with d(loss)/d(logits) when write_grad; row_loss[rows] fp32;

@@ -709,6 +709,22 @@ def test_generate_decode_chain_matches_glue_path(dev):
     assert len(set(ref[0, -16:].tolist())) >= 6
 
 
+def test_generate_batched_decode_chain_matches_glue_path(dev):
+    """2 .. 8 sequences per decode step on the one-launch-per-Linear kernels (`afk_decode_chain_*_batched`) produce the tokens of the split-K + glue path:
+    the processor's left-padded two-row batch and a batch of five copies at different paddings, graph-replayed and eager"""
+    g = torch.load(os.path.join(G, "tiny64_caseC.pt"))
+    m = _model(dev)
+    kw = dict(input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), attention_mask=g["att"].to(dev), max_new_tokens=12)
+    outs = {}
+    for nb in (8, 0):
+        for graph in (True, False):
+            m.decode_chain_batch = nb
+            outs[(nb, graph)] = m.generate(g["ids"].to(dev), use_graph=graph, **kw)
+    m.decode_chain_batch = 8
+    for k, v in outs.items():
+        assert torch.equal(v, outs[(0, False)]), (k, v[:, -12:], outs[(0, False)][:, -12:])
+
+
 def test_generate_logits_processor_stopping_criteria_streamer(dev):
     """GenerationMixin's per-step callbacks (VERDICT r03 'missing' 3): transformers' own LogitsProcessorList / StoppingCriteriaList objects and a
     streamer, on the cache path.  Identity hooks leave the greedy ids unchanged; a suppressed token never appears and changes the continuation from
