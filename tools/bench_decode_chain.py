@@ -11,7 +11,7 @@ BF = torch.bfloat16
 H, Hq, Hkv, D, I = 3584, 28, 4, 128, 18944
 nq, nk = Hq * D, Hkv * D
 keys = int(sys.argv[1]) if len(sys.argv) > 1 else 800
-NSET, ITERS = 6, 60
+NSET, ITERS = 6, int(os.environ.get("ITERS", "60"))
 g = torch.Generator(device=dev).manual_seed(0)
 rnd = lambda *s, sc=0.02: (torch.randn(*s, device=dev, generator=g) * sc).to(BF)
 W = [dict(qkv=rnd(nq + 2 * nk, H), o=rnd(H, nq), gu=rnd(2 * I, H), d=rnd(H, I)) for _ in range(NSET)]
