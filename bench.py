@@ -936,6 +936,11 @@ def main():
     drain()
     if use_dp:
         dist.barrier()
+        torch.cuda.synchronize()
+        if use_graph:   # a captured graph keeps the communicator's kernels and buffers referenced: let it go BEFORE the communicator is destroyed (the 1-rank
+            run.graph.reset()   # RCCL graph run of tests/test_dp_gpu.py died with SIGABRT from a c10 worker thread in 3 of 11 full-suite runs; teardown order is the suspect)
+            run = None
+            torch.cuda.synchronize()
         dist.destroy_process_group()
         drain()
     if line is not None:
