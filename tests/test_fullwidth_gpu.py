@@ -117,6 +117,60 @@ def test_fullwidth_depth_reduced_model_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ attention values at the AF3 shapes
+@pytest.mark.parametrize("B", [1, 2, 8])
+def test_fullwidth_decode_step_vs_recompute(dev, B, monkeypatch):
+    """The decode step at the widths of the 7B model (hidden 3584, 28:4 x 128 heads, ffn 18 944, vocabulary 152 064; one decoder layer): logits of the new
+    position from the KV-cache paths - B = 1: one launch per Linear (csrc/decode_chain.hip); B = 2: the same launches with M input rows on v_dot2; B = 8: on the
+    matrix pipe through wave-private LDS; and the round-3 split-K + glue / generic paths - against the NO-cache forward of the extended sequence through the
+    training-path kernels (which test_fullwidth_depth_reduced_model_vs_oracle pins to the oracle).  Tolerance: LOGIT_TOL of test_model_gpu (4e-2 at logit scale ~1)."""
+    import bench
+    from audio_flamingo_amd import _lib
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    m = Mine(bench.af3_7b_config(enc_layers=1, dec_layers=1), device=dev, init_seed=5)
+    g = torch.Generator(device=dev).manual_seed(6)
+    with torch.no_grad():
+        for blk in m.arena.order:
+            if blk.key.endswith(".bias"):
+                blk.data.copy_((0.02 * torch.randn(blk.shape, device=dev, generator=g)).to(BF))
+            elif blk.key.endswith("norm.weight"):
+                blk.data.copy_((1 + 0.05 * torch.randn(blk.shape, device=dev, generator=g)).to(BF))
+    m.arena.step_counter += 1
+    m.eval()
+    S0 = 200
+    ids = torch.randint(0, 151643, (B, S0), generator=torch.Generator().manual_seed(12)).to(dev)
+    with torch.no_grad():
+        pre = m(input_ids=ids, use_cache=True, logits_to_keep=1)
+        nxt = pre.logits[:, -1].float().argmax(-1)
+        ref = m(input_ids=torch.cat([ids, nxt[:, None]], 1), logits_to_keep=1).logits[:, -1].float()
+        c = pre.past_key_values
+        st = {"cache": (c.K, c.Vt), "lo": c.lo, "head": m.arena["lm_head.weight"].data, "emb": m.arena[m._lm + "embed_tokens.weight"].data,
+              "cur": torch.full((1,), int(c.length), device=dev, dtype=torch.int32), "nxt": nxt, "sampling": None}
+        called = []
+        real = _lib.call
+        monkeypatch.setattr(_lib, "call", lambda name, *a: (called.append(name), real(name, *a))[1])
+        bar = 4e-2 * max(1.0, float(ref.abs().max()))
+        got = {}
+        for chain in (True, False):
+            m.decode_chain = chain
+            st.pop("aws", None)
+            del called[:]
+            got[chain] = m._decode_logits(st).float()
+            torch.cuda.synchronize()
+            names = set(called)
+            if chain:
+                want = "afk_decode_chain_qkv" if B == 1 else "afk_decode_chain_qkv_batched"
+                assert want in names and "afk_attn_decode_fused" in names and "afk_gemv_partials" not in names, names
+            else:
+                assert not any(n.startswith("afk_decode_chain") for n in names), names
+            err = float((got[chain] - ref).abs().max())
+            assert err <= bar, (B, chain, err, bar)
+        assert float((got[True] - got[False]).abs().max()) <= bar
+        top2 = ref.topk(2, -1).values
+        conf = (top2[:, 0] - top2[:, 1]) > 2 * 4e-2
+        assert bool((got[True].argmax(-1)[conf] == ref.argmax(-1)[conf]).all())
+
+
 def _attn_ref(q, k, v, do, scale, causal):
     """fp32 torch reference for one sample: q [Hq, S, D], k / v [Hkv, S, D] -> o, dq, dk, dv (GQA by repeat)"""
     Hq, S, D = q.shape
