@@ -72,7 +72,11 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     auto finish = [&]() {
         if (!FINAL) return;
         int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
-        if (wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores have completed
+        // every storing wave drains its agent-scope write-through stores itself (vmcnt counts stores on gfx9 and falls when the write has been acknowledged at the
+        // coherence point).  A workgroup-scope release fence does NOT do this on gfx950 outside tgsplit mode - it emits no vmcnt wait (round-4 ISA: store sc1 ->
+        // s_barrier -> atomic add, nothing in between) - so the wait is written out; the block barrier below then orders all of the block's stores before
+        // thread 0's counter bump.
+        if (wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         AFK_STAMP(5);
         if (t == 0) {

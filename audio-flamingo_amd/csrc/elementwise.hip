@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
         else *dst = s;
     }
     if (!FUSED) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): this wave's write-through stores have completed
+    // explicit drain of this wave's agent-scope write-through stores (a workgroup-scope release fence emits no vmcnt wait on gfx950 - see attention_decode.hip)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int nslices = gridDim.y;
     if (threadIdx.x == 0) {

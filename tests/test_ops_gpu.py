@@ -911,6 +911,65 @@ def test_attn_decode_fused_last_block_merges(dev, D, Hq, Hkv):
             assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
 
 
+def test_last_block_hand_over_under_memory_load(dev):
+    """Stress of the lock-free "last block merges" hand-over (afk_colsum_bf16_fused, afk_attn_decode_fused): the partials are agent-scope write-through
+    stores that every storing wave drains with an explicit s_waitcnt vmcnt(0) before the block barrier and the counter bump (the workgroup-scope
+    fence that used to stand there emits no wait on gfx950).  Hundreds of launches on two streams while a third stream saturates HBM with copies, fresh
+    (poisoned) workspaces every launch so that a partial read before it landed shows up as a wrong - not merely stale-but-equal - result."""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    load_stream, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big_a = torch.empty(1 << 28, device=dev, dtype=torch.float32)   # 1 GiB each way: far beyond the 8 x 4 MiB of L2 and the 256 MiB of MALL
+    big_b = torch.empty_like(big_a)
+    rows, cols = 8192, 4608
+    x = _rand((rows, cols), dev, seed=11).to(BF)
+    try:
+        ops.COLSUM_FUSED = False
+        want = ops.colsum(x, torch.zeros(cols, device=dev, dtype=BF)).clone()
+    finally:
+        ops.COLSUM_FUSED = True
+    ns = _lib.load().afk_colsum_slices(rows)
+    cnt = {None: torch.zeros(4096, device=dev, dtype=torch.int32), s2: torch.zeros(4096, device=dev, dtype=torch.int32)}
+    # decode attention at the 7B head geometry
+    B, Smax, D, Hq, Hkv, nsplit = 8, 1300, 128, 28, 4, 8
+    spad = ops.pad64(Smax)
+    nk, nq = Hkv * D, Hq * D
+    q = _rand((B, nq), dev, 1.0, 1).to(BF)
+    kc = _rand((B, Smax, nk), dev, 1.0, 2).to(BF)
+    vt = _rand((B, Hkv, D, spad), dev, 1.0, 3).to(BF)
+    kr = torch.tensor([[0, 1300 - 37 * b] for b in range(B)], device=dev, dtype=torch.int32)
+    nws = _lib.load().afk_attn_decode_workspace_floats(B, Hq, D, nsplit)
+    dargs = lambda o, ws, st: (q.data_ptr(), nq, D, kc.data_ptr(), Smax * nk, nk, D, vt.data_ptr(), Hkv * D * spad, spad, o.data_ptr(), nq, D,
+                               kr.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), nsplit, ws.data_ptr(), st)
+    o_want = torch.empty((B, nq), device=dev, dtype=BF)
+    _lib.call("afk_attn_decode", *dargs(o_want, torch.empty(nws, device=dev, dtype=torch.float32), ops._stream()))
+    torch.cuda.synchronize()
+    N = 150
+    outs, douts = [], []
+    with torch.cuda.stream(load_stream):
+        for _ in range(60):
+            big_b.copy_(big_a)
+            big_a.copy_(big_b)
+    for i in range(N):
+        for st in (None, s2):
+            ctx = torch.cuda.stream(st) if st is not None else torch.cuda.stream(torch.cuda.current_stream())
+            with ctx:
+                ws = torch.full((ns * cols,), float("nan"), device=dev, dtype=torch.float32)
+                out = torch.zeros(cols, device=dev, dtype=BF)
+                _lib.call("afk_colsum_bf16_fused", x.data_ptr(), x.stride(0), rows, cols, out.data_ptr(), 0, ws.data_ptr(), cnt[st].data_ptr(), ops._stream())
+                outs.append(out)
+                dws = torch.full((nws,), float("nan"), device=dev, dtype=torch.float32)
+                dws[-B * Hq:].view(torch.int32).zero_()
+                o = torch.full((B, nq), 7.0, device=dev, dtype=BF)
+                _lib.call("afk_attn_decode_fused", *dargs(o, dws, ops._stream()))
+                douts.append((o, dws))
+    torch.cuda.synchronize()
+    bad = sum(int(not torch.equal(o, want)) for o in outs)
+    dbad = sum(int(not torch.equal(o, o_want)) for o, _ in douts)
+    assert bad == 0 and dbad == 0, f"hand-over lost partials: colsum {bad}/{len(outs)}, decode attention {dbad}/{len(douts)} launches differ"
+    assert all(int(w[-B * Hq:].view(torch.int32).abs().sum()) == 0 for _, w in douts) and all(int(c.abs().sum()) == 0 for c in cnt.values())
+
+
 @pytest.mark.parametrize("knobs", ["", "S=1,1,1,1,1", "S=2,2,2,2,2 R=4,4,4,4,4", "S=8,8,8,8,8", "S=4,4,4,4,4 R=4,4,4,4,4"])
 def test_decode_chain_kernels_vs_standalone_sequence(dev, knobs, monkeypatch):
     """csrc/decode_chain.hip (one launch per Linear of a single-sequence decode step, RMSNorm in the consumer's prologue, bias / RoPE / cache append /
