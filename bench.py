@@ -223,6 +223,9 @@ def eager_rocm_baseline(dev, feats, ids, labels, steps=3, clip=0.0):
     torch.manual_seed(0)
     with torch.device(dev):
         model = AudioFlamingo3ForConditionalGeneration(af3_7b_config()).to(torch.bfloat16)
+    from tools.parity_fulldepth import restore_rope_buffers
+
+    restore_rope_buffers(model)   # .to(bf16) rounds the rotary inv_freq buffer; a from_pretrained(dtype=bf16) model keeps it in fp32
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, fused=True)
     B = ids.shape[0]
@@ -485,6 +488,9 @@ def main():
     ap.add_argument("--clip", type=float, default=0.0, help="global-norm gradient clipping (HF Trainer default: 1.0); 0 = off, as the eager reference leg runs")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
     ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) and the 10-minute leg of the default run")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed full-depth parity leg of the default run (tools/parity_fulldepth.py: this model against the live "
+                    "reference in fp32 and bf16 on the BASELINE configs[1] batch, one shared state_dict; forward-only on the configs[4] shape) -> `parity_fulldepth`")
+    ap.add_argument("--parity-fulldepth", action="store_true", help="run ONLY the full-depth parity leg and print its summary as the JSON line")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the decode leg (KV-cache generate, B = 1 and 8) and the configs[3] ICL leg of the default run")
     ap.add_argument("--batches", type=int, default=0, help="distinct synthetic batches resident in HBM, one per step (0 = warm-up + steps + 8: no batch is ever "
                     "trained on twice inside the run, so nothing is memorised in the timed region; 1 = the same batch every step)")
@@ -526,6 +532,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     waited = 0.0 if args.no_settle else settle_hbm(dev)
+    if args.parity_fulldepth:
+        from tools import parity_fulldepth as _pf
+
+        rec = _pf.run(dev)
+        _pf.write_record(rec)
+        print(json.dumps({"parity_fulldepth": _pf.summary(rec)}), flush=True)
+        return
     if args.eager_only:
         from audio_flamingo_amd.frontend import LogMelFrontend
 
@@ -880,7 +893,8 @@ def main():
         }
         want_eager = not args.no_eager_baseline and world == 1 and args.workload == "clip30"
         want_icl = not args.no_extra_legs and world == 1 and args.workload == "clip30" and full_model
-        if want_eager or want_icl:
+        want_parity = not args.no_parity and world == 1 and args.workload == "clip30" and full_model and args.batch == 8
+        if want_eager or want_icl or want_parity:
             # both need the HBM of our replica (the ICL model: 4.3 B parameters + fp32 AdamW state; the reference model: 125 GiB): free it first
             feats_b = frontend(waves, out_dtype=torch.bfloat16)
             model.arena.on_bucket_ready = None
@@ -892,6 +906,19 @@ def main():
 
             gc.collect()
             torch.cuda.empty_cache()
+        if want_parity:
+            # UNTIMED: the configuration timed above against the live reference (fp32 = truth, bf16 = noise floor) with ONE shared state_dict
+            try:
+                from tools import parity_fulldepth as _pf
+
+                rec = _pf.run(dev)
+                _pf.write_record(rec)
+                res["parity_fulldepth"] = _pf.summary(rec)
+                del rec
+                gc.collect()
+                torch.cuda.empty_cache()
+            except Exception as e:
+                res["parity_fulldepth"] = {"green": None, "error": repr(e)[:400]}
         if want_icl:
             # BASELINE configs[3] (AF1/AF2-style ICL step) in the driver-visible line: builder-declared shapes, parity UNPINNED (no AF1/AF2 code
             # exists in the mount: SURVEY.md §0) - see run_icl4

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import json, os, sys, torch, torch.distributed as dist
-ROOT, backend = sys.argv[1], sys.argv[2]
+ROOT, backend, kind = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from transformers import AudioFlamingo3Config
@@ -38,9 +38,14 @@ dev = torch.device("cuda", rank if backend == "nccl" else 0)
 torch.cuda.set_device(dev)
 dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 G = os.path.join(ROOT, "tests", "golden")
-g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
-sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt"))
+# kind "sharp": the TRAINED tiny reference on golden case A (sharp softmax: after step 0 the gradients inherit AdamW's sign-flip noise by tens of percent -
+#   that run is about the mechanics: uneven / all-text steps, gates, clip, collective order, identical replicas);
+# kind "smooth": random-init weights on golden case D (logits O(1), smooth loss surface, tests/_tol.py): the TRAJECTORY check with teeth - the averaged
+#   DP gradient must equal the single-process gradient to <= 3e-2 rel-L2 at EVERY step (VERDICT r04 item 2), step 0 to 5e-3
+g = torch.load(os.path.join(G, "tiny64_caseA.pt" if kind == "sharp" else "tiny64_caseD.pt"))
+sd = torch.load(os.path.join(G, "tiny64_state_bf16.pt" if kind == "sharp" else "tiny64_smooth_state_bf16.pt"))
 LR, WD = 1e-3, 0.01
+GRAD_BARS = (5e-3, 0.25, 0.25, 2.0) if kind == "sharp" else (5e-3, 3e-2, 3e-2, 3e-2)
 
 def model(seed):
     m = Mine(AudioFlamingo3Config(**TINY), device=dev, init_seed=seed)
@@ -142,7 +147,7 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         # round 4: steps 1 and 2 compare gradients taken at parameters that already differ by AdamW's sign-flip noise; across rounds 2-4 and the
         # four modes the same code measured 0.009 ... 0.076 there (a heavy-tailed noise realisation, not a trend: the first two modes of the failing
         # run sat at 0.02) - the sharp check is step 0 (identical parameters: 1.3e-3 against a 5e-3 bar), steps 1-2 are held to an order of magnitude
-        assert gr <= ((5e-3, 0.25, 0.25, 2.0)[step]), (mode, step, "grad rel-L2", gr)
+        assert gr <= GRAD_BARS[step], (kind, mode, step, "grad rel-L2", gr)
         dp = (m.arena.params.float() - ref.arena.params.float()).abs()
         assert float(dp.max()) <= min(2.5 * LR * (step + 1) + 2 ** -7, (2 ** -7, 2 ** -6, 2 ** -6, 2 ** -6)[step]) * 1.0001, (mode, step, float(dp.max()))
         assert float(dp.mean()) <= (1.5e-6, 3e-5, 8e-5, 1.6e-4)[step], (mode, step, float(dp.mean()))
@@ -164,7 +169,7 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
 dist.barrier()
 if rank == 0:
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"dp_equivalence_{backend}.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"dp_equivalence_{backend}_{kind}.json"), "w") as f:
         json.dump(report, f, indent=1)
 dist.destroy_process_group()
 print("DP_OK", rank, flush=True)
@@ -179,13 +184,13 @@ def _free_port():
     return p
 
 
-def _run(backend, world=2, timeout=600):
+def _run(backend, world=2, timeout=600, kind="sharp"):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER, ROOT, backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER, ROOT, backend, kind], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     outs = []
     try:
@@ -200,8 +205,10 @@ def _run(backend, world=2, timeout=600):
         assert p.returncode == 0 and f"DP_OK {r}" in o, f"rank {r} failed (rc {p.returncode}):\n{o[-4000:]}"
 
 
-def test_dp_two_ranks_one_gpu_gloo(dev):
-    _run("gloo")
+@pytest.mark.parametrize("kind", ["sharp", "smooth"])
+def test_dp_two_ranks_one_gpu_gloo(dev, kind):
+    """kind = smooth: the 4-step trajectory on the random-init model, gradient rel-L2 <= 3e-2 at every step (5e-3 at step 0)"""
+    _run("gloo", kind=kind)
 
 
 @pytest.mark.parametrize("comm", ["torch", "native"])
@@ -212,6 +219,7 @@ def test_dp_two_ranks_rccl(dev, comm):
         pytest.skip("needs >= 2 GPUs (the driver's multi-GPU box): RCCL over xGMI")
     os.environ["AFK_DP_COMM"] = comm
     try:
+        _run("nccl", kind="smooth")
         _run("nccl")
     finally:
         os.environ.pop("AFK_DP_COMM", None)

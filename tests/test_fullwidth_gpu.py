@@ -116,6 +116,34 @@ def test_fullwidth_depth_reduced_model_vs_oracle(dev):
     assert not bad, (bad, rep)
 
 
+def test_fulldepth_parity_vs_live_reference_on_the_benchmark_configuration(dev):
+    """the configuration bench.py times (BASELINE configs[1]: 32 + 28 layers, B = 8, S = 1024) against the LIVE reference
+    (transformers.AudioFlamingo3ForConditionalGeneration, modeling_audioflamingo3.py:584-642) with ONE shared state_dict - the reference in fp32 on this
+    GPU is the truth, its own bf16 run the noise floor (ours <= 2 x floor).  First-step loss, logits on the 2 048 labelled rows, argmax on
+    the rows whose fp32 top-1/top-2 gap exceeds the measured bf16 noise, EVERY parameter gradient (829 tensors), per-bucket gradient norms, the first
+    AdamW update; forward-only on the BASELINE configs[4] shape (10 windows, S = 7 774).  ~25 s, ~230 GiB of HBM at its peak.  The same record rides in
+    bench.py's JSON line (`parity_fulldepth`)."""
+    import gc
+    import json
+
+    from tools import parity_fulldepth as pf
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info()
+    if free < 240 * 2 ** 30:
+        pytest.skip(f"needs ~230 GiB of free HBM, {free / 2 ** 30:.0f} GiB free")
+    rec = pf.run(dev)
+    pf.write_record(rec)
+    s = pf.summary(rec)
+    assert rec["green"], json.dumps({k: s[k] for k in ("checks", "loss", "loss_ref_fp32", "logits", "logits_floor_ref_bf16")} | {"over_bar": s["gradients"]["over_bar"]})
+    # ours must not be systematically noisier than the reference's own bf16 run (the harness bug this test exists to catch: a rotary inv_freq
+    # rounded by `.to(bfloat16)` put EVERY tensor at 1.1-2.2 x the floor; with fp32 inv_freq the median sits at 0.9)
+    assert s["gradients"]["ours_over_floor"]["median"] <= 1.25, s["gradients"]["ours_over_floor"]
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------------ attention values at the AF3 shapes
 @pytest.mark.parametrize("B", [1, 2, 8])
 def test_fullwidth_decode_step_vs_recompute(dev, B, monkeypatch):

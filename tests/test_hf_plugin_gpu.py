@@ -27,7 +27,9 @@ def _hf_model(cfg_dict, dev, state=None, seed=0):
     m = AudioFlamingo3ForConditionalGeneration(AudioFlamingo3Config(**cfg_dict))
     if state is not None:
         m.load_state_dict(state)
-    return m.to(dev).to(torch.bfloat16)
+    from tools.parity_fulldepth import restore_rope_buffers   # .to(bfloat16) rounds the rotary inv_freq buffer; from_pretrained(dtype=bf16) keeps it fp32
+
+    return restore_rope_buffers(m.to(dev).to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("case", ["A", "B", "C"])

@@ -63,7 +63,9 @@ def _ref_bf16(dev):
 
     ref_m = AudioFlamingo3ForConditionalGeneration(_cfg())
     ref_m.load_state_dict(torch.load(os.path.join(G, "tiny64_state_bf16.pt")))
-    return ref_m.to(dev).to(torch.bfloat16).train()
+    from tools.parity_fulldepth import restore_rope_buffers   # .to(bfloat16) rounds the rotary inv_freq buffer; from_pretrained(dtype=bf16) keeps it fp32
+
+    return restore_rope_buffers(ref_m.to(dev).to(torch.bfloat16)).train()
 
 
 def _stats(err):
@@ -307,7 +309,9 @@ def test_smooth_goldens_every_parameter_gradient(dev, case):
     # context: the reference itself in bf16 on this device
     refb = AudioFlamingo3ForConditionalGeneration(_cfg())
     refb.load_state_dict(sd)
-    refb = refb.to(dev).to(torch.bfloat16).train()
+    from tools.parity_fulldepth import restore_rope_buffers
+
+    refb = restore_rope_buffers(refb.to(dev).to(torch.bfloat16)).train()
     ro = refb(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), attention_mask=g["att"].to(dev),
               labels=g["labels"].to(dev))
     ro.loss.backward()
