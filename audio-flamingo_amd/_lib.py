@@ -31,7 +31,7 @@ def parse_header(path: str = HEADER_PATH):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|int)\s+(afk_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"(const char\*|int64_t|int)\s+(afk_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes, argnames = [], []
         if args and args != "void":
@@ -47,7 +47,7 @@ def parse_header(path: str = HEADER_PATH):
                     parts = a.replace("const ", "").split()
                     argtypes.append(_CTYPE[parts[0]])
                     argnames.append(parts[-1])
-        protos[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int, argtypes, argnames)
+        protos[name] = (ctypes.c_char_p if ret.startswith("const char") else ctypes.c_int64 if ret == "int64_t" else ctypes.c_int, argtypes, argnames)
     return protos
 
 

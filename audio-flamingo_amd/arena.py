@@ -430,3 +430,133 @@ class FusedAdamW:
 
     def zero_grad(self):
         self.arena.zero_grad()
+
+
+def comm_share(n: int, world: int, itemsize: int = 2) -> int:
+    """elements of a bucket of n that each rank owns: (n / world) rounded down to a multiple of 128 bytes - include/afk.h afk_comm_share
+    (tests/test_host_cpu.py holds the two to each other).  Rank r owns [r * share, (r + 1) * share); [share * world, n) is a replicated tail."""
+    if n <= 0 or world <= 0:
+        return 0
+    align = 128 // itemsize
+    return (n // world) // align * align
+
+
+class ShardedAdamW(FusedAdamW):
+    """FusedAdamW with the optimizer SHARDED over the data-parallel ranks (AFK_DP_FORM=rs_adamw_ag).
+
+    Per gradient bucket (= transformer layer) the step is   reduce-scatter(grads) -> AdamW on THIS rank's share -> all-gather(bf16 params)
+    instead of   all-reduce(grads) -> AdamW on the whole bucket   on every rank.  Same bytes on the wire (a reduce-scatter + an all-gather IS an
+    all-reduce), but every GPU streams 1 / world of the 28 B/param optimizer traffic (AF3-7B: 231 GB -> 29 GB per step at 8 ranks) and holds 1 / world of
+    the fp32 master / m / v (99.2 GB -> 12.4 GB).  The oracle's DDP replicates the optimizer (TORCH/nn/parallel/distributed.py:662-666, 828-834); the hook
+    point it exposes for this is the communication hook (ddp_comm_hooks/default_hooks.py:18-35).
+
+    AdamW is elementwise, so the parameters are BIT-IDENTICAL to the replicated path whenever the reduced gradient values are (same reduce-scatter as the
+    replicated rs_ag form; at world 2 any summation order gives the same bits).  The tail of a bucket that does not divide (afk_comm_share: shares are
+    multiples of 128 bytes) is all-reduced and updated by every rank - replicated state of < world * 64 elements per bucket.
+
+    State lives in ONE compact fp32 array per moment: for every bucket, this rank's share followed by the bucket's tail.  `engine` (dp.DataParallelEngine)
+    supplies rank / world and the collectives; after this rank's launches of a bucket it all-gathers the bucket's parameters on the same stream.
+    Global-norm clipping: every rank sums the squares of its own shares (the tail on rank 0 only), one extra SUM all-reduce of the per-bucket partial
+    sums closes the norm - identical on every rank, NOT bit-identical to the replicated path's norm (other summation order)."""
+
+    def __init__(self, arena: Arena, engine, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.arena = arena
+        self.engine = engine
+        self.rank, self.world = int(engine.rank), int(engine.world)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        # owned intervals of the arena, ascending: (arena start, arena end, state offset)
+        self.owned: List[tuple] = []
+        off = 0
+        for i in range(len(arena.bucket_names)):
+            s, e = arena.bucket_range(i)
+            share = comm_share(e - s, self.world)
+            for a0, a1 in ((s + self.rank * share, s + (self.rank + 1) * share), (s + share * self.world, e)):
+                if a1 > a0:
+                    self.owned.append((a0, a1, off))
+                    off += a1 - a0
+        self.state_numel = off
+        self.master = torch.empty(off, device=arena.device, dtype=torch.float32)
+        self.m = torch.zeros(off, device=arena.device, dtype=torch.float32)
+        self.v = torch.zeros(off, device=arena.device, dtype=torch.float32)
+        self.t = 0
+        self.hyper = torch.zeros(4, device=arena.device, dtype=torch.float32) if arena.device.type == "cuda" else None
+        self._in_capture = False
+        self.clip_norm: Optional[float] = None
+        self._sumsq = torch.zeros(len(arena.bucket_names), device=arena.device, dtype=torch.float32)
+        self.grad_norm = torch.zeros(1, device=arena.device, dtype=torch.float32)
+        self._sumsq_ws = torch.empty(ops.sumsq_workspace_floats(), device=arena.device, dtype=torch.float32) if arena.device.type == "cuda" else None
+        self.fuse_shadow = False   # the transposed-shadow launch needs whole weights; a share cuts through them
+        self._plan_key = None
+        self.sync_master()
+
+    # ------------------------------------------------------------------ ownership
+    def _pieces(self, s: int, e: int):
+        """the parts of arena range [s, e) this rank owns -> (arena start, arena end, state start)"""
+        out = []
+        for a0, a1, off in self.owned:
+            if a1 <= s:
+                continue
+            if a0 >= e:
+                break
+            lo, hi = max(a0, s), min(a1, e)
+            if hi > lo:
+                out.append((lo, hi, off + lo - a0))
+        return out
+
+    def state_bytes(self) -> int:
+        return 12 * self.state_numel
+
+    def sync_master(self):
+        for a0, a1, off in self.owned:
+            self.master[off: off + a1 - a0].copy_(self.arena.params[a0:a1])
+        self._mark_synced()
+
+    # ------------------------------------------------------------------ launches
+    def _launch(self, s, e, wd, grad_scale, max_blocks=0, gate=None):
+        a = self.arena
+        for lo, hi, off in self._pieces(s, e):
+            n = hi - lo
+            ops.adamw_step(self.master[off: off + n], self.m[off: off + n], self.v[off: off + n], a.grads[lo:hi], a.params[lo:hi], lr=self.lr,
+                           beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=wd, step=self.t,
+                           grad_scale=grad_scale, max_blocks=max_blocks, gate=gate, hyper=self.hyper)
+
+    def add_sumsq(self, i: int, gate=None, written_only: bool = True):
+        """this rank's part of sum(g^2) of bucket i: its own share, and the replicated tail on rank 0 only (counted once in the all-rank sum).
+        Data parallel: every slice of a reduced bucket holds a reduced gradient (zeros where nobody contributed), so `written_only` does not apply."""
+        a = self.arena
+        s, e = a.bucket_range(i)
+        share = comm_share(e - s, self.world)
+        tail0 = s + share * self.world
+        for lo, hi, _ in self._pieces(s, e):
+            if lo >= tail0 and self.rank != 0:
+                continue
+            ops.sumsq_(a.grads[lo:hi], self._sumsq[i:i + 1], gate=gate, ws=self._sumsq_ws)
+
+    def set_clip_coef(self, grad_scale: float = 1.0):
+        self.engine.allreduce_small_sum_(self._sumsq)   # per-bucket partial sums of squares over the ranks' shares -> the full gradient's
+        super().set_clip_coef(grad_scale)
+
+    def step_bucket(self, i: int, grad_scale: float = 1.0, max_blocks: int = 0, gate=None, written_only: bool = False):
+        """AdamW on this rank's share (+ the tail) of bucket i, then the all-gather of the bucket's bf16 parameters - both on the CURRENT stream"""
+        # written_only arises in single-process use only (a bucket backward touched partly); a reduced bucket is defined everywhere
+        plan = self._plan([b for b in self.arena.bucket_blocks(i) if not b.fresh]) if written_only else self.bucket_segments[i]
+        self._exec(plan, grad_scale, max_blocks, gate)
+        self.engine.allgather_params_(i)
+        return set()
+
+    def step(self, grad_scale: float = 1.0, refresh_shadows: bool = True, gates=None):
+        self._check_master()
+        self.advance()
+        a = self.arena
+        a.join_streams()
+        n = len(a.bucket_names)
+        if self.clip_norm:
+            for i in range(n):
+                self.add_sumsq(i, gate=gates[i:i + 1] if gates is not None else None)
+            self.set_clip_coef(grad_scale)
+        for i in range(n):
+            self.step_bucket(i, grad_scale, gate=gates[i:i + 1] if gates is not None else None, written_only=gates is None)
+        a.step_counter += 1
+        self._mark_synced()
+        if refresh_shadows:
+            a.refresh_shadows(force=True)

@@ -127,23 +127,27 @@ extern "C" int afk_allreduce_bucket(void* comm, void* buf, int64_t n, int dtype,
     return AFK_OK;
 }
 
-// the same result as afk_allreduce_bucket (SUM) by reduce-scatter + all-gather (both in place): every GPU reduces 1/world of the bucket
-// and then collects the other shares - on the xGMI mesh all seven links of a GPU work at once.  The tail that does not divide by the
-// world size is all-reduced.
-extern "C" int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream) {
-    AFK_REQUIRE(comm && buf && n > 0, "afk_reduce_scatter_allgather_bucket: bad args");
+// Partition of a bucket over the ranks: shares start on 128-byte boundaries; what does not divide is a replicated tail.
+extern "C" int64_t afk_comm_share(int64_t n, int world, int dtype) {
+    if (n <= 0 || world <= 0) return 0;
+    const int64_t eb = dtype == AFK_COMM_BF16 ? 2 : 4;
+    const int64_t align = 128 / eb;
+    return (n / world) / align * align;
+}
+
+// in-place reduce-scatter of buf[0 .. n): rank r's share (and the replicated tail, by all-reduce) holds the SUM afterwards
+extern "C" int afk_reduce_scatter_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream) {
+    AFK_REQUIRE(comm && buf && n > 0, "afk_reduce_scatter_bucket: bad args");
     AfkComm* c = (AfkComm*)comm;
     ncclDataType_t t;
     size_t eb;
     if (int e = dtype_of(dtype, &t, &eb)) return e;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t align = 128 / (int64_t)eb;  // shares start on 128-byte boundaries
-    const int64_t share = (n / c->world) / align * align;
+    const int64_t share = afk_comm_share(n, c->world, dtype);
     char* base = (char*)buf;
     if (share > 0) {
         void* mine = base + (size_t)c->rank * share * eb;
         AFK_NCCL(g_rccl.ReduceScatter(buf, mine, (size_t)share, t, ncclSum, c->comm, st), "ncclReduceScatter");
-        AFK_NCCL(g_rccl.AllGather(mine, buf, (size_t)share, t, c->comm, st), "ncclAllGather");
     }
     const int64_t done = share * c->world;
     if (done < n) {
@@ -151,6 +155,29 @@ extern "C" int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_
         AFK_NCCL(g_rccl.AllReduce(tail, tail, (size_t)(n - done), t, ncclSum, c->comm, st), "ncclAllReduce (tail)");
     }
     return AFK_OK;
+}
+
+// in-place all-gather of the ranks' own shares of buf[0 .. n); the replicated tail is not touched
+extern "C" int afk_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream) {
+    AFK_REQUIRE(comm && buf && n > 0, "afk_allgather_bucket: bad args");
+    AfkComm* c = (AfkComm*)comm;
+    ncclDataType_t t;
+    size_t eb;
+    if (int e = dtype_of(dtype, &t, &eb)) return e;
+    const int64_t share = afk_comm_share(n, c->world, dtype);
+    if (share > 0) {
+        void* mine = (char*)buf + (size_t)c->rank * share * eb;
+        AFK_NCCL(g_rccl.AllGather(mine, buf, (size_t)share, t, c->comm, (hipStream_t)stream), "ncclAllGather");
+    }
+    return AFK_OK;
+}
+
+// the same result as afk_allreduce_bucket (SUM) by reduce-scatter + all-gather (both in place): every GPU reduces 1/world of the bucket
+// and then collects the other shares - on the xGMI mesh all seven links of a GPU work at once.  The tail that does not divide by the
+// world size is all-reduced.
+extern "C" int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream) {
+    if (int e = afk_reduce_scatter_bucket(comm, buf, n, dtype, stream)) return e;
+    return afk_allgather_bucket(comm, buf, n, dtype, stream);
 }
 
 extern "C" int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, void* stream) {

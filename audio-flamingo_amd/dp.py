@@ -28,7 +28,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-from .arena import Arena
+from .arena import Arena, comm_share
 
 
 def _flags_on_device(flags, device) -> torch.Tensor:
@@ -98,6 +98,24 @@ class NativeComm:
             _lib.call("afk_allreduce_bucket", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], int(op_max), _stream())
         return t
 
+    def reduce_scatter_(self, t: torch.Tensor):
+        """in place: this rank's share (afk_comm_share) and the replicated tail of `t` hold the SUM over the ranks afterwards"""
+        from . import _lib
+        from .ops import _stream
+
+        assert t.is_cuda and t.is_contiguous() and t.dtype in self._DT
+        _lib.call("afk_reduce_scatter_bucket", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], _stream())
+        return t
+
+    def allgather_(self, t: torch.Tensor):
+        """in place: every rank's own share of `t` is distributed to all ranks (the tail is left alone)"""
+        from . import _lib
+        from .ops import _stream
+
+        assert t.is_cuda and t.is_contiguous() and t.dtype in self._DT
+        _lib.call("afk_allgather_bucket", self.handle, t.data_ptr(), t.numel(), self._DT[t.dtype], _stream())
+        return t
+
     def broadcast_(self, t: torch.Tensor, root: int = 0):
         from . import _lib
         from .ops import _stream
@@ -132,6 +150,12 @@ class DataParallelEngine:
 
         self.comm_kind = comm or _os.environ.get("AFK_DP_COMM", "torch")
         self.form = _os.environ.get("AFK_DP_FORM", "rs_ag")
+        # AFK_DP_FORM=rs_adamw_ag (opt-in, round 5): the optimizer is SHARDED over the ranks - per bucket reduce-scatter(grads) -> AdamW on this rank's
+        # share (arena.ShardedAdamW) -> all-gather(bf16 params); with either communicator library.  After reduce_bucket_() only this rank's share and
+        # the replicated tail of a gradient bucket hold reduced values.
+        self.sharded = self.form == "rs_adamw_ag"
+        self._gate_vec: Optional[torch.Tensor] = None
+        self.poison_unowned = False   # tests: where the exchange is emulated by an all-reduce (gloo), put the LOCAL values back into the shares this rank does not own
         self.native = NativeComm.from_process_group(process_group) if (self.comm_kind == "native" and self.cuda and not self.staged) else None
         self.overlap = overlap and self.cuda
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
@@ -191,13 +215,125 @@ class DataParallelEngine:
         dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg)
         buf.copy_(f.to(buf.device))
 
+    # ------------------------------------------------------------------ sharded form: reduce-scatter / all-gather halves
+    def make_optimizer(self, **kw):
+        """the optimizer that matches this engine's exchange form: arena.ShardedAdamW for rs_adamw_ag, arena.FusedAdamW otherwise"""
+        from .arena import FusedAdamW, ShardedAdamW
+
+        return ShardedAdamW(self.arena, self, **kw) if self.sharded else FusedAdamW(self.arena, **kw)
+
+    def _shares(self, i: int):
+        s, e = self.arena.bucket_range(i)
+        return s, e, comm_share(e - s, self.world)
+
+    def reduce_bucket_(self, i: int):
+        """SUM of gradient bucket i over the ranks, ordered on the CURRENT stream.  Replicated forms: the whole bucket is reduced everywhere.
+        Sharded form: reduce-scatter - afterwards only this rank's share and the replicated tail hold reduced values."""
+        buf = self.arena.bucket_grads(i)
+        if not self.sharded:
+            return self.allreduce_sum_(buf)
+        s, e, share = self._shares(i)
+        n, r, w = e - s, self.rank, self.world
+        if self.native is not None:
+            self.native.reduce_scatter_(buf)
+        elif self.cuda and not self.staged:
+            if share:
+                dist.reduce_scatter_tensor(buf[r * share:(r + 1) * share], buf[: share * w], op=dist.ReduceOp.SUM, group=self.pg)
+            if share * w < n:
+                dist.all_reduce(buf[share * w:], op=dist.ReduceOp.SUM, group=self.pg)
+        else:
+            # gloo (host staging / CPU arenas: correctness runs only) has no reduce-scatter: all-reduce; with poison_unowned (tests) the shares this
+            # rank does not own then get their LOCAL values back - what an in-place ncclReduceScatter leaves there - so that an update which read
+            # an un-owned share would differ from the replicated path (NaN would do too, but never-written slices such as the padding between
+            # blocks or the k third of the fused encoder qkv bias are updated by the launches as well and must stay finite)
+            local = buf.clone() if (self.poison_unowned and share) else None
+            if self.cuda:
+                self.allreduce_sum_(buf)
+            elif self._native_bf16:
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
+            else:
+                f = buf.float()
+                dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg)
+                buf.copy_(f)
+            if local is not None:
+                if r > 0:
+                    buf[: r * share].copy_(local[: r * share])
+                if r + 1 < w:
+                    buf[(r + 1) * share: share * w].copy_(local[(r + 1) * share: share * w])
+
+    def allgather_params_(self, i: int):
+        """sharded form, after this rank's AdamW launches of bucket i (same stream): every rank's share of the bucket's bf16 parameters to all ranks"""
+        if not self.sharded:
+            return
+        s, e, share = self._shares(i)
+        if share == 0 or (self.world == 1 and not self.force_collectives):
+            return
+        # `.data`: same storage, its OWN version counter - the parameter views are saved tensors of backward nodes that have not run yet (this call
+        # sits inside backward), and an in-place torch op on the arena itself would invalidate them for autograd; the AdamW kernels write through
+        # raw pointers for the same reason
+        p = self.arena.params.data[s:e]
+        r, w = self.rank, self.world
+        if self.native is not None:
+            self.native.allgather_(p)
+        elif self.cuda and not self.staged:
+            dist.all_gather_into_tensor(p[: share * w], p[r * share:(r + 1) * share], group=self.pg)
+        else:
+            mine = p[r * share:(r + 1) * share].detach().cpu().contiguous().view(torch.int32)   # bit pattern (shares are multiples of 128 bytes): gloo moves bytes
+            outs = [torch.empty_like(mine) for _ in range(w)]
+            dist.all_gather(outs, mine, group=self.pg)
+            p[: share * w].copy_(torch.cat(outs).view(torch.bfloat16).to(p.device))
+
+    def exchange_bucket_flag_(self, i: int, touched: bool) -> torch.Tensor:
+        """sharded form inside BackwardOverlap: MAX over the ranks of "this rank produced a gradient for bucket i", on the CURRENT stream, right behind the
+        bucket's reduce-scatter -> device int32[1] that gates the bucket's AdamW launches.  Why per bucket: the parameter all-gather that follows the
+        update is a collective too, so every rank must issue  RS_i, flag_i, AG_i  in the same order for every bucket - a rank that skipped part of the
+        model (text-only batch) issues them from finish(), the others from inside backward, and the one closing MAX over all flags of the replicated forms
+        would sit at different places of the two sequences."""
+        if self._gate_vec is None:
+            self._gate_vec = torch.zeros(len(self.arena.bucket_names), device=self.arena.device, dtype=torch.int32)
+        g = self._gate_vec[i:i + 1]
+        if self.staged or not self.cuda:
+            h = torch.tensor([int(touched)], dtype=torch.int32)
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.pg)
+            g.copy_(h.to(g.device))
+        else:
+            g.fill_(int(touched))    # a fill launch: capturable into a HIP graph (the flag is a constant of a static-shape step)
+            if self.native is not None:
+                self.native.allreduce_(g, op_max=True)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.MAX, group=self.pg)
+        return g
+
+    def allreduce_small_sum_(self, t: torch.Tensor):
+        """SUM over the ranks of a small fp32 device vector on the CURRENT stream (the sharded optimizer's partial sums of squares)"""
+        if self.world == 1 and not self.force_collectives:
+            return t
+        if self.native is not None:
+            self.native.allreduce_(t, form="allreduce")
+        elif self.staged:
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.pg)
+            t.copy_(h.to(t.device))
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+        return t
+
     def _reduce(self, i: int):
         buf = self.arena.bucket_grads(i)
         if buf.numel() == 0:
             return
         self.arena.zero_unwritten(i)  # zero_grad() only flips flags: slices nobody wrote this step still hold the last step's values
         self.issued.append(i)
-        if self.staged:
+        if self.sharded:
+            if self.staged or not self.cuda:
+                self.reduce_bucket_(i)
+            else:
+                evs = self.arena.ready_events()
+                with torch.cuda.stream(self.comm_stream):
+                    for ev in evs:
+                        self.comm_stream.wait_event(ev)
+                    self.reduce_bucket_(i)   # enqueued on (c10d: ordered behind and ahead of) the communication stream; finish() joins it
+        elif self.staged:
             self.allreduce_sum_(buf)
         elif self.cuda:
             evs = self.arena.ready_events()
@@ -324,7 +460,9 @@ class BackwardOverlap:
                 buf = self.arena.bucket_grads(i)
                 if buf.numel():
                     self.engine.issued.append(i)
-                    self.engine.allreduce_sum_(buf)  # ordered on the side stream
+                    self.engine.reduce_bucket_(i)  # ordered on the side stream (all-reduce, or reduce-scatter in the sharded form)
+                if self.engine.sharded:            # RS_i, flag_i, [AdamW on this rank's share], AG_i: the same sequence on every rank (exchange_bucket_flag_)
+                    gate, written_only = self.engine.exchange_bucket_flag_(i, True), False
             self._step_or_defer(i, gate, written_only)
 
     def _step_or_defer(self, i, gate, written_only):
@@ -346,6 +484,24 @@ class BackwardOverlap:
                 self.arena.refresh_bucket_shadows(i, skip=fused)
         self._clip_pending = []
 
+    def _exchange_flags_and_step(self, touched, deferred):
+        """replicated forms: ONE MAX over all per-bucket flags behind the last reduction, then the gated optimizer launches of the deferred buckets"""
+        eng = self.engine
+        with torch.cuda.stream(self.side):
+            if eng.staged:
+                gate = torch.tensor(touched, dtype=torch.int32)
+                dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
+                gate = gate.to(self.arena.device)
+            else:
+                gate = _flags_on_device(touched, self.arena.device)
+                if eng.native is not None:
+                    eng.native.allreduce_(gate, op_max=True)
+                else:
+                    dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
+            for i in deferred:
+                self._step_or_defer(i, gate[i:i + 1], False)
+        return gate
+
     def finish(self):
         """buckets backward never completed (their part of the model did not run this step, e.g. the audio tower on a text-only batch):
         single process -> the optimizer skips what received no gradient (torch: grad is None); data parallel -> they are reduced in the
@@ -366,21 +522,15 @@ class BackwardOverlap:
                     buf = self.arena.bucket_grads(i)
                     if buf.numel():
                         eng.issued.append(i)
-                        eng.allreduce_sum_(buf)
-                deferred.append(i)
-            with torch.cuda.stream(self.side):
-                if eng.staged:
-                    gate = torch.tensor(touched, dtype=torch.int32)
-                    dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
-                    gate = gate.to(self.arena.device)
-                else:
-                    gate = _flags_on_device(touched, self.arena.device)
-                    if eng.native is not None:
-                        eng.native.allreduce_(gate, op_max=True)
-                    else:
-                        dist.all_reduce(gate, op=dist.ReduceOp.MAX, group=eng.pg)
-                for i in deferred:
-                    self._step_or_defer(i, gate[i:i + 1], False)
+                        eng.reduce_bucket_(i)
+                    if eng.sharded:   # the bucket's own flag exchange, its gated update and its parameter all-gather follow at once (see _ready)
+                        self._step_or_defer(i, eng.exchange_bucket_flag_(i, bool(touched[i])), False)
+                if not eng.sharded:
+                    deferred.append(i)
+            if eng.sharded:
+                gate = eng._gate_vec if eng._gate_vec is not None else _flags_on_device(touched, self.arena.device)
+            else:
+                gate = self._exchange_flags_and_step(touched, deferred)
             gate.record_stream(torch.cuda.current_stream())
             eng.bucket_gate = gate
         else:

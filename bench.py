@@ -566,15 +566,18 @@ def main():
     model.check_placeholders = False  # the count assertion is a host sync; shapes are static in this benchmark
     if ckpt:
         model.gradient_checkpointing_enable()
-    opt = FusedAdamW(model.arena, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    if args.clip > 0:
-        opt.clip_norm = args.clip  # norm in one pass over the gradient arena, coefficient applied inside the AdamW launches
     engine = None
     if use_dp:
         engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
         engine.force_collectives = engine.force_collectives or args.force_dp
         engine.broadcast_parameters(0)
-        opt.sync_master()
+    # AFK_DP_FORM=rs_adamw_ag: the optimizer sharded over the ranks (arena.ShardedAdamW: reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather
+    # of the bf16 parameters); otherwise the replicated FusedAdamW
+    opt_kw = dict(lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    opt = engine.make_optimizer(**opt_kw) if engine is not None else FusedAdamW(model.arena, **opt_kw)
+    if args.clip > 0:
+        opt.clip_norm = args.clip  # norm in one pass over the gradient arena, coefficient applied inside the AdamW launches
+    opt.sync_master()
     from audio_flamingo_amd import functional as F_
     model.arena.lazy_T_shadows = F_.BWD_FORM == "direct"
     model.arena.refresh_shadows(force=True)
@@ -858,7 +861,11 @@ def main():
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
             "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb, "label_rows_static": bool(model.label_rows_static),
-            "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind, "form": engine.form if engine.native is not None else "allreduce",
+            "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind,
+                                               "form": engine.form if (engine.native is not None or engine.sharded) else "allreduce",
+                                               "optimizer": ("sharded over the ranks (reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather of the bf16 parameters)"
+                                                             if engine.sharded else "replicated"),
+                                               "optimizer_state_gib": round(12 * getattr(opt, "state_numel", model.arena.total) / 2 ** 30, 2),
                                                "collectives_forced_at_world_1": bool(engine.force_collectives and world == 1),
                                                "buckets": len(model.arena.bucket_names), "bucket_bytes_max": 2 * max(e - s_ for s_, e in model.arena._bucket_ranges),
                                                "bucket_bytes_total": 2 * model.arena.total, "overlapped_with_backward": overlap is not None or engine.overlap,

@@ -361,6 +361,18 @@ int afk_comm_init(int rank, int world, const char* host_uid128, void** host_comm
 int afk_comm_destroy(void* comm);
 int afk_allreduce_bucket(void* comm, void* buf, int64_t n, int dtype, int op_max, void* stream);
 int afk_reduce_scatter_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream);
+/* The two halves of the call above, for an optimizer that is SHARDED across the data-parallel ranks between them (round 5; the hook point the oracle
+ * exposes is the DDP communication hook, TORCH/distributed/algorithms/ddp_comm_hooks/default_hooks.py:18-35; its DDP itself replicates the optimizer):
+ *   afk_comm_share(n, world, dtype)   elements per rank: (n / world) rounded down to a multiple of 128 bytes.  Rank r OWNS buf[r * share, (r + 1) * share);
+ *                                     the tail buf[share * world, n) is replicated (every rank reduces and updates it).
+ *   afk_reduce_scatter_bucket         in place: afterwards rank r's own share and the tail hold the SUM over the ranks; the other shares hold what
+ *                                     they held before (this rank's local values) and must not be read as reduced gradients.
+ *   afk_allgather_bucket              in place: every rank's own share is distributed to all ranks; the tail is left alone (it is already equal
+ *                                     everywhere).  Called on the bf16 PARAMETER bucket after each rank's AdamW update of its share: same bytes on
+ *                                     the wire as gathering the gradients, 1 / world of the optimizer traffic and fp32 state per GPU. */
+int64_t afk_comm_share(int64_t n, int world, int dtype);
+int afk_reduce_scatter_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream);
+int afk_allgather_bucket(void* comm, void* buf, int64_t n, int dtype, void* stream);
 int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, void* stream);
 /* CU-contention probe (pre-flight of the multi-GPU run; models the CUs RCCL's persistent channel kernels take from the GEMM rounds - reference
  * behaviour being prepared for: TORCH/nn/parallel/distributed.py:1012,1442): parks `nblocks` workgroups of 64 threads + lds_bytes of LDS on `stream`

