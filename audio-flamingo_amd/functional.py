@@ -451,6 +451,12 @@ class LMHeadLossFn:
     CHUNK = 4096  # 16x14 = 224 tiles of 256x256 for the dgrad GEMM: enough to fill the chip with the fast kernel
 
     @staticmethod
+    def key_state(arena, wkey):
+        """part of the stage key (stage_ops.py): whether the unscaled dW is parked in the gradient arena itself (fresh block) or in a private buffer
+        decides what forward keeps for backward"""
+        return f"fresh{int(arena[wkey].fresh)}"
+
+    @staticmethod
     def forward(ctx, x, anchor, arena, wkey, shift_labels, denom, rows=None):
         # rows (int64, ascending, on the device; None = every row): the positions whose shifted label is not -100.  Only they
         # contribute to the loss and to any gradient (the CE gradient of an ignored row is exactly zero), so the lm_head GEMM, the CE

@@ -394,20 +394,21 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     # Activation checkpointing (oracle: GradientCheckpointingLayer.__call__, transformers/modeling_layers.py:79-114, switched on by
     # gradient_checkpointing_enable, modeling_utils.py:3187: EVERY transformer layer re-runs its forward in backward - the answer for 80 GB
-    # parts).  Here the switch keeps its meaning ("trade recompute for memory") but recomputes only what a memory budget requires: 288 GB of
-    # HBM3E hold the activations of a 5-minute clip outright (185 GiB), and a recomputed layer costs a third of its forward+backward time
-    # again.  Policy (gradient_checkpointing_kwargs / attributes):
-    #     memory_budget_gib = None   -> CKPT_BUDGET_FRACTION of the device's memory (0.85 x 268 GiB = 228 GiB on MI355X); env AFK_CKPT_BUDGET_GIB
-    #     policy = "budget" (default) | "full" (the reference's every-layer recompute; env AFK_CKPT_POLICY)
-    # The plan - how many of the FIRST layers of each tower are recomputed (their recompute runs last in backward, when the later layers'
-    # activations are already gone) - is made per forward from the batch geometry and what is allocated at that moment; gradients are
-    # bit-identical whatever the plan (tests/test_model_gpu.py::test_gradient_checkpointing_matches).
+    # parts).  gradient_checkpointing_enable() with no arguments means exactly that here too (policy "full", round 5 / ADVICE r04: a caller that
+    # switches checkpointing on to FIT must get the reference's memory behaviour).  Opt-in (gradient_checkpointing_kwargs / env):
+    #     policy = "budget" (env AFK_CKPT_POLICY)  recompute only what a memory budget requires: 288 GB of HBM3E hold the activations of a 5-minute clip
+    #                                              outright (185 GiB), and a recomputed layer costs a third of its forward + backward time again
+    #     memory_budget_gib = None                 -> CKPT_BUDGET_FRACTION of the device's memory (0.85 x 288 GiB = 245 GiB on MI355X); env AFK_CKPT_BUDGET_GIB
+    # The budget plan - how many of the FIRST layers of each tower are recomputed (their recompute runs last in backward, when the later layers'
+    # activations are already gone) - is made per forward from the batch geometry, what this process has allocated, what the DEVICE still has free
+    # (hipMemGetInfo: other processes count) plus this process's own cached blocks, and the W^T shadows that will still be allocated lazily; gradients
+    # are bit-identical whatever the plan (tests/test_model_gpu.py::test_gradient_checkpointing_matches).  Every new plan is logged.
     CKPT_BUDGET_FRACTION = 0.85
 
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
         kw = dict(gradient_checkpointing_kwargs or {})
         self.gradient_checkpointing = True
-        self.ckpt_policy = kw.get("policy", os.environ.get("AFK_CKPT_POLICY", "budget"))
+        self.ckpt_policy = kw.get("policy", os.environ.get("AFK_CKPT_POLICY", "full"))
         b = kw.get("memory_budget_gib", os.environ.get("AFK_CKPT_BUDGET_GIB"))
         self.ckpt_budget_bytes = None if b is None else int(float(b) * 2 ** 30)
         if self.ckpt_policy not in ("budget", "full"):
@@ -416,7 +417,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     def gradient_checkpointing_disable(self):
         self.gradient_checkpointing = False
 
-    ckpt_policy, ckpt_budget_bytes, ckpt_plan = "budget", None, None
+    ckpt_policy, ckpt_budget_bytes, ckpt_plan, _ckpt_logged = "full", None, None, None
 
     def activation_bytes_per_layer(self, windows: int, dec_rows: int):
         """bytes one encoder layer / one decoder layer keeps for backward (functional.EncoderLayerFn / DecoderLayerFn.save_for_backward):
@@ -429,8 +430,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         dec = dec_rows * (2 * (5 * H + (self.Hq + 2 * self.Hkv) * self.D + 3 * I) + 4 * (2 + self.Hq))
         return enc, dec
 
-    def plan_checkpointing(self, windows: int, dec_rows: int, allocated_bytes: int, total_bytes: int):
-        """-> {"enc": n, "dec": n, ...}: how many of the first layers of each tower are recomputed.  Pure host arithmetic (tested on the CPU)."""
+    def plan_checkpointing(self, windows: int, dec_rows: int, allocated_bytes: int, total_bytes: int, usable_bytes: Optional[int] = None,
+                           pending_bytes: int = 0):
+        """-> {"enc": n, "dec": n, ...}: how many of the first layers of each tower are recomputed.  Pure host arithmetic (tested on the CPU).
+        usable_bytes: what this process can still obtain (device-free memory + its own cached-but-unallocated blocks; None = unknown, trust the budget);
+        pending_bytes: allocations that will happen later in the step outside the activations (W^T shadows created lazily by the first backward)."""
         enc_b, dec_b = self.activation_bytes_per_layer(windows, dec_rows)
         if self.ckpt_policy == "full":
             return {"enc": self.enc_layers if windows else 0, "dec": self.dec_layers, "policy": "full"}
@@ -439,7 +443,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         # in flight (three streams), the lm_head logits chunk and its fp32 split-K partials, allocator slack
         V = self.config.text_config.vocab_size
         headroom = 2 * dec_b + 2 * enc_b + 3 * F_.LMHeadLossFn.CHUNK * V * 2 + (6 << 30)
-        avail = budget - allocated_bytes - headroom
+        avail = budget - allocated_bytes
+        if usable_bytes is not None:
+            avail = min(avail, int(usable_bytes))
+        avail -= headroom + int(pending_bytes)
         need = self.enc_layers * enc_b + self.dec_layers * dec_b
         n_dec = n_enc = 0
         if need > avail:
@@ -448,14 +455,27 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             if need > avail and enc_b:
                 n_enc = min(self.enc_layers, -(-(need - avail) // enc_b))
         return {"enc": int(n_enc), "dec": int(n_dec), "policy": "budget", "budget_gib": round(budget / 2 ** 30, 1),
-                "allocated_gib": round(allocated_bytes / 2 ** 30, 1), "enc_layer_gib": round(enc_b / 2 ** 30, 3), "dec_layer_gib": round(dec_b / 2 ** 30, 3)}
+                "allocated_gib": round(allocated_bytes / 2 ** 30, 1), "usable_gib": None if usable_bytes is None else round(usable_bytes / 2 ** 30, 1),
+                "pending_gib": round(pending_bytes / 2 ** 30, 2), "enc_layer_gib": round(enc_b / 2 ** 30, 3), "dec_layer_gib": round(dec_b / 2 ** 30, 3)}
+
+    def _pending_shadow_bytes(self) -> int:
+        """W^T / conv shadows that do not exist yet and will be allocated by the first backward that needs them"""
+        return sum(2 * b.numel * (2 if b.shadow_kind == "conv" else 1) for b in self.arena.order if b.shadow_kind is not None and b.shadow is None)
 
     def _make_ckpt_plan(self, windows, dec_rows):
         if not (self.gradient_checkpointing and torch.is_grad_enabled()):
             self.ckpt_plan = None
             return
-        total = torch.cuda.get_device_properties(self.device_).total_memory
-        self.ckpt_plan = self.plan_checkpointing(windows, dec_rows, torch.cuda.memory_allocated(self.device_), total)
+        free, total = torch.cuda.mem_get_info(self.device_)
+        alloc, reserved = torch.cuda.memory_allocated(self.device_), torch.cuda.memory_reserved(self.device_)
+        self.ckpt_plan = self.plan_checkpointing(windows, dec_rows, alloc, total, usable_bytes=free + max(reserved - alloc, 0),
+                                                 pending_bytes=self._pending_shadow_bytes())
+        key = (windows, dec_rows, self.ckpt_plan["enc"], self.ckpt_plan["dec"], self.ckpt_plan["policy"])
+        if key != self._ckpt_logged:
+            self._ckpt_logged = key
+            import logging
+
+            logging.getLogger("audio_flamingo_amd").info("activation checkpointing plan for %d windows / %d decoder rows: %s", windows, dec_rows, self.ckpt_plan)
 
     def _layer(self, fn, *args, ckpt=True):
         if ckpt and self.gradient_checkpointing and torch.is_grad_enabled():
@@ -565,7 +585,9 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             return sh.contiguous(), c[2]
         rows = (sh != -100).nonzero().reshape(-1)  # host sync: the count sizes the GEMMs
         rows = rows if 0 < rows.numel() < sh.numel() else None
-        self._rows_cache = (weakref.ref(labels), labels._version, rows, int(rows.numel()) if rows is not None else (int((sh != -100).sum()) if self.label_rows_static else -1))
+        # the REAL labelled count is always remembered (rows is None both for "no row" and "every row"; label_rows_static may be switched on after this call,
+        # and a remembered -1 would poison the next in-place label update - ADVICE r04)
+        self._rows_cache = (weakref.ref(labels), labels._version, rows, int(rows.numel()) if rows is not None else int((sh != -100).sum()))
         return sh.contiguous(), rows
 
     def forward(self, input_ids=None, input_features=None, input_features_mask=None, attention_mask=None, position_ids=None,
@@ -1124,6 +1146,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             do_sample, temperature, top_k, top_p = pick(do_sample, False, "do_sample"), pick(temperature, 1.0, "temperature"), pick(top_k, 50, "top_k"), pick(top_p, 1.0, "top_p")
             num_beams, length_penalty, early_stopping = pick(num_beams, 1, "num_beams"), pick(length_penalty, 1.0, "length_penalty"), pick(early_stopping, False, "early_stopping")
             eos_token_id, pad_token_id = pick(eos_token_id, None, "eos_token_id"), pick(pad_token_id, None, "pad_token_id")
+        if int(max_new_tokens) <= 0:   # GenerationMixin refuses it as well (generation/configuration_utils.py validate())
+            raise ValueError(f"`max_new_tokens` must be greater than 0, but is {max_new_tokens}.")
         if num_beams > 1 and (do_sample or not use_cache):
             raise AfkError("generate(num_beams > 1): beam search is deterministic and runs on the KV cache (no do_sample, no use_cache=False)")
         if hooks and (num_beams > 1 or not use_cache):

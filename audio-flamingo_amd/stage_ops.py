@@ -28,8 +28,20 @@ from torch import Tensor
 
 _LIB = torch.library.Library("afk", "FRAGMENT")
 _ARENAS: "weakref.WeakValueDictionary[int, object]" = weakref.WeakValueDictionary()
-_STATIC = {}   # key -> (arena id, static args in forward order)
-_CACHE = {}    # key -> {"fwd_meta", "src", "out_spec", "bwd_spec"}
+from collections import OrderedDict
+
+# Both tables are bounded LRU maps: a key contains every tensor shape of its stage, so a data loader with varying batch geometry mints new
+# keys for every layer; a key is touched by its forward AND its backward, so the least recently used ones belong to steps long finished.
+_TABLE_CAP = 16384
+_STATIC = OrderedDict()   # key -> (arena id, static args in forward order)
+_CACHE = OrderedDict()    # key -> {"fwd_meta", "src", "out_spec", "bwd_spec"}
+
+
+def _touch(table, key):
+    table.move_to_end(key)
+    while len(table) > _TABLE_CAP:
+        table.popitem(last=False)
+
 _STAGES = {}   # stage name -> _Stage
 _UID = [0]
 _ARENA = object()   # stands for "the arena" inside remembered metadata (the side tables must not keep arenas - 16 GB of HBM each - alive)
@@ -63,11 +75,21 @@ class _Ctx:
         self.saved_tensors = tensors
 
 
+def _same_meta(a, b) -> bool:
+    if isinstance(a, tuple) and isinstance(b, tuple):
+        return len(a) == len(b) and all((x is y) or (not isinstance(x, Tensor) and not isinstance(y, Tensor) and x == y) for x, y in zip(a, b))
+    return a is b or (not isinstance(a, Tensor) and a == b)
+
+
 def _placeholder(like: Tensor) -> Tensor:
     return like.new_empty(0)
 
 
 def _arena_of(key: str):
+    if key not in _STATIC:
+        raise RuntimeError(f"afk stage {key[:80]!r}...: its metadata was evicted (more than {_TABLE_CAP} distinct stage geometries between this stage's forward "
+                           f"and its backward)")
+    _touch(_STATIC, key)
     aid, static = _STATIC[key]
     arena = _ARENAS.get(aid)
     if arena is None:
@@ -111,9 +133,14 @@ class _Stage:
         # does this call record a backward?  (the operator's implementation runs below the autograd key with grad mode off and cannot see it;
         # lm_head + loss produces its gradients during the forward sweep only when somebody will ask for them)
         need = int(torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tens))
-        key = f"{self.name}|{uid}|{static!r}|{shapes!r}|g{need}"
+        # run-time state that decides WHAT a stage keeps for backward belongs to the key (equal keys must mean equal saved-tensor layout,
+        # whatever the interleaving of forwards and backwards): a stage declares it with a static `key_state(arena, *static_args) -> str`
+        ks = getattr(self.fn, "key_state", None)
+        state = f"|{ks(arena, *static)}" if ks is not None else ""
+        key = f"{self.name}|{uid}|{static!r}|{shapes!r}{state}|g{need}"
         if key not in _STATIC:
             _STATIC[key] = (uid, static)
+        _touch(_STATIC, key)
         return self.op(*tens, arena.params, arena.grads, key)[0]
 
     def _full_args(self, tens, arena, static):
@@ -148,8 +175,15 @@ class _Stage:
                 src.append(("out", len(outs)))
                 outs.append(t)
         c = _CACHE.setdefault(key, {})
+        _touch(_CACHE, key)
         meta = ctx.meta
-        c["fwd_meta"] = tuple(_ARENA if m is arena else m for m in meta) if isinstance(meta, tuple) else meta
+        fwd_meta = tuple(_ARENA if m is arena else m for m in meta) if isinstance(meta, tuple) else meta
+        if "src" in c and (c["src"] != src or not _same_meta(c["fwd_meta"], fwd_meta)):
+            # the layout is remembered per key and read by whichever backward of that key runs next: a second layout under one key would hand a
+            # backward the wrong saved tensors.  A stage whose layout depends on run-time state must expose that state through key_state()
+            raise RuntimeError(f"afk::{self.name}: two forwards with the same stage key kept different things for backward ({c['src']} vs {src}); "
+                               f"give the stage a key_state()")
+        c["fwd_meta"] = fwd_meta
         c["src"] = src
         c["out_spec"] = [(tuple(t.shape), t.dtype) for t in outs]
         return outs
@@ -196,6 +230,7 @@ class _Stage:
     def _bwd_impl(self, g, saved, params, grads, key):
         arena, static = _arena_of(key)
         c = _CACHE[key]
+        _touch(_CACHE, key)
         ctx = _Ctx()
         ctx.saved_tensors = tuple(None if kind == "none" else t for (kind, _), t in zip(c["src"], saved))
         meta = c["fwd_meta"]

@@ -796,11 +796,11 @@ def test_gradient_checkpointing_matches(dev):
     la.backward()
     torch.cuda.synchronize()
     plans = {}
-    for name, ck in (("full", dict(policy="full")), ("budget", None), ("partial", "partial")):
+    for name, ck in (("default", None), ("full", dict(policy="full")), ("budget", dict(policy="budget")), ("partial", "partial")):
         mb = _model(dev)
         if ck == "partial":
             # a budget that leaves room for about half of the activations: headroom + allocated + 1.5 encoder layers + 1 decoder layer
-            mb.gradient_checkpointing_enable()
+            mb.gradient_checkpointing_enable(dict(policy="budget"))
             W, rows = int(kw["input_features"].shape[0]), int(kw["input_ids"].numel())
             enc_b, dec_b = mb.activation_bytes_per_layer(W, rows)
             full_need = mb.enc_layers * enc_b + mb.dec_layers * dec_b
@@ -817,6 +817,7 @@ def test_gradient_checkpointing_matches(dev):
         assert float(la) == float(lb), name
         assert torch.equal(ma.arena.grads, mb.arena.grads), name
     assert plans["full"]["enc"] == 2 and plans["full"]["dec"] == 2, plans
+    assert plans["default"] == plans["full"], plans    # no arguments = the reference's every-layer recompute (modeling_layers.py:79-114)
     assert plans["budget"]["enc"] == 0 and plans["budget"]["dec"] == 0, plans        # the tiny batch fits: nothing is recomputed
     assert 0 < plans["partial"]["enc"] + plans["partial"]["dec"] < 4, plans             # part of the layers only
     REPORT["gradient_checkpointing_plans"] = plans
