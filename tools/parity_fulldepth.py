@@ -79,6 +79,8 @@ def restore_rope_buffers(model):
             inv, _ = mod.compute_default_rope_parameters(mod.config, mod.inv_freq.device)
             mod.inv_freq = torch.nn.Buffer(inv.float(), persistent=False)
             mod.original_inv_freq = torch.nn.Buffer(inv.float().clone(), persistent=False)
+            if hasattr(mod, "position_angles") and hasattr(mod, "_compute_position_angles"):   # Music Flamingo's rotary TIME embedding: its angle table and
+                mod.position_angles = torch.nn.Buffer(mod._compute_position_angles(mod.inv_freq), persistent=False)   # every timestamp take inv_freq's dtype
     return model
 
 
