@@ -9,6 +9,7 @@
 // tiny kernel merges the chunks:  o = sum_s e^(m_s - M) o_s / sum_s e^(m_s - M) l_s.   HBM-bound: the cache is read exactly once.
 // The visible key interval [lo, hi) of every sample comes from DEVICE memory (krange), so a captured HIP graph of the decode step can be
 // replayed while the sequence grows.
+#include <atomic>
 #include "common.h"
 #include "../../include/afk.h"
 
@@ -218,6 +219,198 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     finish();
 }
 
+// Round 5 - batched decode (afk_attn_decode_fused at B x Hkv x nsplit >= GROUP_MIN_BLOCKS): ONE block per (sample, KV head, key chunk) serves ALL G = Hq / Hkv
+// query heads of the group.  The per-head form above launches G blocks that each fetch the same K / V chunk - at B = 8 that was 1 792 blocks and 26 us per
+// layer for 13 MB of cache (profiles/r04_decode_kernel_stats.md).  Here a key row is loaded once and scored against the G query rows the thread holds in
+// registers, the transposed value rows are loaded once and accumulated into G outputs.  The arithmetic of every head - dot-product order, shuffle reduction,
+// per-thread strided sums, fold order of the parts, the merge - is that of attn_decode_split_kernel element for element, so the results are BIT-IDENTICAL to
+// the per-head form (tests/test_ops_gpu.py::test_attn_decode_group_kernel_bit_equal).  Same workspace layout; the arrival counter of a group is the slot of
+// its first head.  Hand-over: write-through stores drained by every storing wave (s_waitcnt vmcnt(0)) before the barrier and the counter bump.
+constexpr int GCHUNK = 1024;         // keys per chunk the group form holds in LDS (G score rows)
+constexpr int GROUP_MIN_BLOCKS = 128;
+constexpr int GROUP_LDS_FLOATS = 8 * (GCHUNK + 24);
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
+                                                                int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
+                                                                int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
+                                                                float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
+    constexpr int LPK = D / 8, KPP = 256 / LPK, PARTS = 256 / D;
+    constexpr int SROW = GCHUNK + 8;
+    __shared__ __attribute__((aligned(16))) float sc[GROUP_LDS_FLOATS];   // [G][SROW] scores / probabilities; later the merge's staging area
+    __shared__ float red[2][G][4];
+    __shared__ float part[G][256];
+    __shared__ int last_flag;
+    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b = blockIdx.z, h0 = hk * G;
+    const int t = threadIdx.x;
+    const int lo = krange[2 * b], hi = krange[2 * b + 1];
+    const int a0 = lo & ~7, total = max(hi - a0, 0);
+    const int chunk = min((((total + nsplit - 1) / nsplit) + 7) & ~7, GCHUNK);
+    const int c0 = a0 + split * chunk, c1 = min(c0 + chunk, hi);
+    const int n = max(c1 - c0, 0);
+    auto slot = [&](int g) { return ws + ((int64_t)(b * Hq + h0 + g) * nsplit + split) * (D + 2); };
+    auto put = [&](float* dst, float v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [&](const float* src) -> float { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto finish = [&]() {
+        int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through partials have landed (see attn_decode_split_kernel)
+        __syncthreads();
+        if (t == 0) {
+            const int prev = __hip_atomic_fetch_add(&counters[b * Hq + h0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (prev == nsplit - 1);
+            if (last_flag) __hip_atomic_store(&counters[b * Hq + h0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        // the G heads' partials are contiguous in the workspace: [h0 .. h0 + G)[nsplit][D + 2]
+        const float* base = ws + (int64_t)(b * Hq + h0) * nsplit * (D + 2);
+        const int tot = G * nsplit * (D + 2);
+        // G x nsplit x (D + 2) words (7 280 at the AF3 geometry): SIXTEEN independent agent-scope loads per thread and round - these loads bypass the cache
+        // levels, a round costs a memory round trip (~2 us), and four per round (the per-head kernel's depth) made the merge 8 dependent trips
+        constexpr int NL = 16;
+        for (int i = t; i < tot; i += 256 * NL) {
+            float v[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+                if (i + 256 * u < tot) sc[i + 256 * u] = v[u];
+        }
+        __syncthreads();
+        for (int g = t / D; g < G; g += PARTS) {   // PARTS heads at a time, thread -> feature d
+            const int d = t % D;
+            const float* sg = sc + g * nsplit * (D + 2);
+            float M = NEG_INF;
+            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, sg[s * (D + 2)]);
+            float L = 0.f, o = 0.f;
+            if (M != NEG_INF) {
+                for (int s = 0; s < nsplit; ++s) {
+                    const float w = __builtin_amdgcn_exp2f(sg[s * (D + 2)] - M);
+                    L += w * sg[s * (D + 2) + 1];
+                    o += w * sg[s * (D + 2) + 2 + d];
+                }
+            }
+            O[b * o_bs + (h0 + g) * o_hs + d] = (bf16)(L > 0.f ? o / L : 0.f);
+        }
+    };
+    if (n <= 0 || c1 <= lo) {
+        for (int g = 0; g < G; ++g) {
+            if (t < D) put(slot(g) + 2 + t, 0.f);
+            if (t == 0) { put(slot(g), NEG_INF); put(slot(g) + 1, 0.f); }
+        }
+        finish();
+        return;
+    }
+    constexpr int UK = 128 / KPP, UV = 128 / (PARTS * 8);
+    const int sub = t % LPK, krow = t / LPK;
+    bf16x8 qv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) qv[g] = *(const bf16x8*)(Q + b * q_bs + (h0 + g) * q_hs + sub * 8);
+    const bf16* kbase = Kc + b * k_bs + hk * k_hs + sub * 8 + (int64_t)c0 * k_rs;
+    const int d = t % D, pt = t / D;
+    const bf16* vrow = Vt + b * vt_bs + ((int64_t)hk * D + d) * spad + c0;
+    bf16x8 kv[UK], vv[UV];
+    auto load_k = [&](int i0) {
+#pragma unroll
+        for (int u = 0; u < UK; ++u) kv[u] = *(const bf16x8*)(kbase + (int64_t)min(i0 + u * KPP + krow, n - 1) * k_rs);
+    };
+    auto load_v = [&](int g0) {
+#pragma unroll
+        for (int u = 0; u < UV; ++u) {
+            const int gi = g0 + (u * PARTS + pt) * 8;
+            vv[u] = *(const bf16x8*)(vrow + (gi < n ? gi : 0));
+        }
+    };
+    load_k(0);
+    load_v(0);
+    const float c2 = scale * LOG2E;
+    float mx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) mx[g] = NEG_INF;
+    for (int i0 = 0; i0 < n; i0 += 128) {
+        if (i0) load_k(i0);
+#pragma unroll
+        for (int u = 0; u < UK; ++u) {
+            const int i = i0 + u * KPP + krow;
+            const int key = c0 + i;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bf16x2 a = {qv[g][2 * e], qv[g][2 * e + 1]}, c = {kv[u][2 * e], kv[u][2 * e + 1]};
+                    s = __builtin_amdgcn_fdot2_f32_bf16(a, c, s, false);
+                }
+#pragma unroll
+                for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+                if (i < n && sub == 0) sc[g * SROW + i] = (key >= lo) ? s * c2 : NEG_INF;
+                if (i < n && key >= lo) mx[g] = fmaxf(mx[g], s * c2);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float w = wave_max(mx[g]);
+        if ((t & 63) == 0) red[0][g][t >> 6] = w;
+    }
+    __syncthreads();
+    float m[G], msafe[G], ls[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = fmaxf(fmaxf(red[0][g][0], red[0][g][1]), fmaxf(red[0][g][2], red[0][g][3]));
+        msafe[g] = (m[g] == NEG_INF) ? 0.f : m[g];
+        ls[g] = 0.f;
+    }
+    for (int i = t; i < n; i += 256) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float p = __builtin_amdgcn_exp2f(sc[g * SROW + i] - msafe[g]);
+            sc[g * SROW + i] = p;
+            ls[g] += p;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float w = wave_sum(ls[g]);
+        if ((t & 63) == 0) red[1][g][t >> 6] = w;
+    }
+    __syncthreads();
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+    for (int g0 = 0; g0 < n; g0 += 128) {
+        if (g0) load_v(g0);
+#pragma unroll
+        for (int u = 0; u < UV; ++u) {
+            const int gi = g0 + (u * PARTS + pt) * 8;   // wave-uniform
+            const int gg = gi < n ? gi : 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const f32x4 p0 = *(const f32x4*)&sc[g * SROW + gg], p1 = *(const f32x4*)&sc[g * SROW + gg + 4];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const bool in = gi + e < n;
+                    const float pe = in ? (e < 4 ? p0[e & 3] : p1[e & 3]) : 0.f;
+                    const float ve = in ? (float)vv[u][e] : 0.f;
+                    acc[g] = fmaf(pe, ve, acc[g]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) part[g][t] = acc[g];
+    __syncthreads();
+    for (int g = 0; g < G; ++g) {
+        if (t < D) {
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) o += part[g][t + q * D];
+            put(slot(g) + 2 + t, o);
+        }
+        if (t == 0) { put(slot(g), m[g]); put(slot(g) + 1, red[1][g][0] + red[1][g][1] + red[1][g][2] + red[1][g][3]); }
+    }
+    finish();
+}
+
 template <int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, int nsplit, bf16* __restrict__ O, int64_t o_bs,
                                                                int64_t o_hs, int Hq) {
@@ -240,6 +433,13 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
 
 extern "C" int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit) { return B * Hq * nsplit * (D + 2) + B * Hq; }   // + arrival counters (afk_attn_decode_fused)
 
+static std::atomic<int> g_group_mode{[] { const char* e = getenv("AFK_ATTN_DECODE_GROUP"); return e ? atoi(e) : 0; }()};
+extern "C" int afk_attn_decode_set_group(int mode) {
+    AFK_REQUIRE(mode >= 0 && mode <= 2, "afk_attn_decode_set_group: mode %d (0 per-head, 1 group form from 128 blocks on, 2 group form whenever it fits)", mode);
+    g_group_mode.store(mode, std::memory_order_relaxed);
+    return AFK_OK;
+}
+
 static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                             const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
                             int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream) {
@@ -251,6 +451,33 @@ static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_h
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)nsplit, (unsigned)Hq, (unsigned)B);
     static const int sync = [] { const char* e = getenv("AFK_ATTN_DECODE_SYNC"); return e ? atoi(e) : 1; }();
+    // group form (one block per (sample, KV head, chunk) for all Hq / Hkv query heads).  OFF by default (mode 0): built for the batched decode step on the
+    // argument that the G per-head blocks re-fetch the same K / V chunk, bit-identical to the per-head form - and MEASURED 1-2 % SLOWER on the B = 8 step
+    // (4.50 / 4.54 vs 4.45 / 4.46 ms, alternating runs on one box, profiles/r05_kernel_ab.md): with nsplit = 8 the blocks of one chunk index already share
+    // an XCD (linear block id mod 8 = chunk index), so the L2 serves the G - 1 re-reads, and 256 blocks of 4 waves hide less latency than 1 792.
+    // afk_attn_decode_set_group / AFK_ATTN_DECODE_GROUP: 1 = group form from 128 blocks on, 2 = whenever its limits hold
+    const int group_mode = g_group_mode.load(std::memory_order_relaxed);
+    const int G = Hq / Hkv;
+    const bool group_fits = fused && sync == 1 && G >= 2 && (int64_t)spad <= (int64_t)nsplit * GCHUNK && G * nsplit * (D + 2) <= GROUP_LDS_FLOATS &&
+                            (G == 2 || G == 4 || G == 7 || G == 8);
+    if (group_fits && group_mode && (group_mode == 2 || B * Hkv * nsplit >= GROUP_MIN_BLOCKS)) {
+        const dim3 ggrid((unsigned)nsplit, (unsigned)Hkv, (unsigned)B);
+#define AFK_ADG(DD, GG)                                                                                                                                   \
+    hipLaunchKernelGGL((attn_decode_group_kernel<DD, GG>), ggrid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs,        \
+                       (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs)
+#define AFK_ADG_D(DD)                                      \
+    do {                                                   \
+        if (G == 2) AFK_ADG(DD, 2);                        \
+        else if (G == 4) AFK_ADG(DD, 4);                   \
+        else if (G == 7) AFK_ADG(DD, 7);                   \
+        else AFK_ADG(DD, 8);                               \
+    } while (0)
+        if (D == 128) AFK_ADG_D(128); else AFK_ADG_D(64);
+#undef AFK_ADG_D
+#undef AFK_ADG
+        AFK_LAUNCH_CHECK("afk_attn_decode_fused (group form)");
+        return AFK_OK;
+    }
 #define AFK_AD_ARGS (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs
 #define AFK_AD(DD)                                                                                                                       \
     do {                                                                                                                                 \

@@ -263,6 +263,11 @@ int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, i
 int afk_attn_decode_fused(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                           const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
                           int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
+/* Form of afk_attn_decode_fused for GQA caches (round 5): 0 (default) one block per (sample, QUERY head, chunk); 1 = one block per (sample, KV head, chunk)
+ * serving all Hq / Hkv query heads of the group when the launch has >= 128 such blocks, 2 = whenever the form's limits hold (Hq / Hkv in {2, 4, 7, 8},
+ * spad <= nsplit * 1024, (Hq / Hkv) * nsplit * (D + 2) <= 8384).  Results are bit-identical between the forms; the group form measured 1-2 % slower on
+ * the B = 8 decode step of AF3-7B and is kept for A/B runs.  Env AFK_ATTN_DECODE_GROUP sets the initial mode. */
+int afk_attn_decode_set_group(int mode);
 
 /* Decode-step glue (csrc/decode_glue.hip): the weight-streaming first pass alone, and one kernel per Linear of a decoder layer that sums
  * its fp32 partials ws[splits][M][N] and applies everything up to the next Linear's input (one live row per call today: M <= AFK_GEMV_MAX_M; same arithmetic and bf16

@@ -911,6 +911,52 @@ def test_attn_decode_fused_last_block_merges(dev, D, Hq, Hkv):
             assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,B", [(128, 28, 4, 8), (64, 4, 2, 16), (128, 8, 2, 8)])
+def test_attn_decode_group_kernel_bit_equal(dev, D, Hq, Hkv, B):
+    """round 5: batched decode attention - ONE block per (sample, KV head, key chunk) serves all Hq / Hkv query heads (attn_decode_group_kernel, taken by
+    afk_attn_decode_fused when B x Hkv x nsplit >= 128) - must be BIT-IDENTICAL to the per-head split + combine launches (afk_attn_decode), with ragged and
+    left-padded key ranges, an empty chunk, repeated calls into the same workspace and counters left at zero"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    Smax = 1300
+    spad = ops.pad64(Smax)
+    nk, nq = Hkv * D, Hq * D
+    q = _rand((B, nq), dev, 1.0, 1).to(BF)
+    kc = _rand((B, Smax, nk), dev, 1.0, 2).to(BF)
+    vt = _rand((B, Hkv, D, spad), dev, 1.0, 3).to(BF)
+    kr = torch.tensor([[(13 * b) % 50, max(1300 - 150 * b, 60)] for b in range(B)], device=dev, dtype=torch.int32)
+    kr[-1] = torch.tensor([5, 9], device=dev, dtype=torch.int32)     # four visible keys: most chunks of this sample are empty
+    _lib.call("afk_attn_decode_set_group", 1)   # the group form is opt-in (measured 1-2 % slower on the B = 8 step): select it for this test
+    try:
+        _group_checks(_lib, ops, dev, q, kc, vt, kr, B, Hq, Hkv, D, Smax, spad, nk, nq)
+    finally:
+        _lib.call("afk_attn_decode_set_group", 0)
+
+
+def _group_checks(_lib, ops, dev, q, kc, vt, kr, B, Hq, Hkv, D, Smax, spad, nk, nq):
+    for ns in (8, 4) if B * Hkv * 4 >= 128 else (8,):
+        nws = _lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns)
+        args = lambda o, ws: (q.data_ptr(), nq, D, kc.data_ptr(), Smax * nk, nk, D, vt.data_ptr(), Hkv * D * spad, spad, o.data_ptr(), nq, D,
+                              kr.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, ws.data_ptr(), ops._stream())
+        o2 = torch.empty((B, nq), device=dev, dtype=BF)
+        _lib.call("afk_attn_decode", *args(o2, torch.empty(nws, device=dev, dtype=torch.float32)))
+        ws1 = torch.zeros(nws, device=dev, dtype=torch.float32)
+        for rep in range(3):
+            o1 = torch.full((B, nq), 7.0, device=dev, dtype=BF)
+            _lib.call("afk_attn_decode_fused", *args(o1, ws1))
+            torch.cuda.synchronize()
+            assert torch.equal(o1, o2), (ns, rep, float((o1.float() - o2.float()).abs().max()))
+            assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
+    # and against plain fp32 softmax attention on the visible interval
+    for b in (0, B - 1):
+        lo, hi = int(kr[b, 0]), int(kr[b, 1])
+        qq = q[b].float().view(Hq, D)
+        kk = kc[b, lo:hi].float().view(hi - lo, Hkv, D).repeat_interleave(Hq // Hkv, 1)
+        vv = vt[b, :, :, lo:hi].float().permute(2, 0, 1).repeat_interleave(Hq // Hkv, 1)
+        pr = torch.softmax(torch.einsum("hd,shd->hs", qq, kk) * D ** -0.5, -1)
+        _cmp(f"group decode attention b={b}", o2[b], torch.einsum("hs,shd->hd", pr, vv).reshape(-1), atol=2e-2, rtol=2e-2)
+
+
 def test_last_block_hand_over_under_memory_load(dev):
     """Stress of the lock-free "last block merges" hand-over (afk_colsum_bf16_fused, afk_attn_decode_fused): the partials are agent-scope write-through
     stores that every storing wave drains with an explicit s_waitcnt vmcnt(0) before the block barrier and the counter bump (the workgroup-scope
