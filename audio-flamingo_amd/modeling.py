@@ -596,6 +596,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         if (input_ids is None) == (inputs_embeds is None):
             raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
         self._require_hip()
+        from . import exact as _exact
+
+        if _exact.ENABLED and labels is None and inputs_embeds is None and past_key_values is None and not torch.is_grad_enabled():
+            # AFK_EXACT_FP32=1 (verification mode, exact.py): the inference forward in exact fp32 on the afk_x32_* kernels - fp32 logits, no KV cache
+            return AF3Output(logits=_exact.logits(self, input_ids, input_features, input_features_mask, attention_mask))
         if past_key_values is not None or use_cache:
             # inference with the reference's cache protocol (modeling_qwen2.py:213-214, 360-364): prefill returns a cache, later calls
             # append their tokens to it.  Same kernels and cache layout as generate(); no autograd graph.
@@ -1146,6 +1151,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             do_sample, temperature, top_k, top_p = pick(do_sample, False, "do_sample"), pick(temperature, 1.0, "temperature"), pick(top_k, 50, "top_k"), pick(top_p, 1.0, "top_p")
             num_beams, length_penalty, early_stopping = pick(num_beams, 1, "num_beams"), pick(length_penalty, 1.0, "length_penalty"), pick(early_stopping, False, "early_stopping")
             eos_token_id, pad_token_id = pick(eos_token_id, None, "eos_token_id"), pick(pad_token_id, None, "pad_token_id")
+        from . import exact as _exact
+
+        if _exact.ENABLED and not do_sample and num_beams == 1 and not hooks and type(self).__name__ == "AudioFlamingo3ForConditionalGeneration":
+            # AFK_EXACT_FP32=1: greedy decoding by exact-fp32 recomputation of the prefix (exact.py) - the reference's greedy ids with no "confident rows" filter
+            return _exact.greedy_generate(self, input_ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id)
         if int(max_new_tokens) <= 0:   # GenerationMixin refuses it as well (generation/configuration_utils.py validate())
             raise ValueError(f"`max_new_tokens` must be greater than 0, but is {max_new_tokens}.")
         if num_beams > 1 and (do_sample or not use_cache):

@@ -385,6 +385,30 @@ int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, vo
  * start tick, ticks alive, XCC id << 32 | HW_ID of every parked workgroup - proof that they sat where the GEMM workgroups wanted to be. */
 int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, int64_t* report, void* stream);
 
+/* ---- EXACT fp32 inference forward (round 5; SURVEY.md 8c "an fp32 mode of our kernels ... should give bit-exact tokens unconditionally on the tiny config").
+ * A VERIFICATION mode (AFK_EXACT_FP32=1, audio_flamingo_amd/exact.py), not a fast path: activations fp32, weights the bf16 values of the checkpoint widened in
+ * registers, every product and sum fp32 (v_mfma_f32_32x32x2_f32 for the Linears, fp32 VALU elsewhere) - no bf16 rounding point between the log-mel features
+ * and the logits.  Same oracle lines as the bf16 entry points they mirror.
+ *   afk_x32_linear      C[M,N] = epi((A[M,K] . W[N,K]^T + bias[n]) * alpha): optional exact-erf GELU, then + residual[m or m % res_mod][n].  K % 8 == 0.
+ *   afk_x32_norm        LayerNorm (rms = 0: weight + bias, eps as given) or Qwen2 RMSNorm (rms = 1, b may be NULL), one row = D floats.
+ *   afk_x32_attention   softmax(Q K^T * scale) V with fp32 softmax; row (b, s) of head h lies at X + (b * S + s) * ldx + h * D; GQA by Hq / Hkv; visible keys of
+ *                       query s of sample b: [kv_lo[b], min(kv_len[b], causal ? s + 1 : S)) (NULL = 0 / S); a row without a visible key yields zeros.
+ *   afk_x32_rope        rotate-half RoPE in place on the first `nheads` heads of every fused row (position = row % S), cos / sin tables [S, D] fp32.
+ *   afk_x32_silu_mul    out[r][c] = silu(gu[r][c]) * gu[r][I + c].
+ *   afk_x32_conv3_gelu  y = gelu(conv1d(x, w[E][C][3], pad 1, stride)) (+ pos[t][e]); x is [W][C][T] (x_cmajor) or [W][T][C]; y [W][T_out][E].
+ *   afk_x32_avgpool2    mean of row pairs;  afk_x32_embed_scatter  out[row] = audio[src[row]] if src[row] >= 0 else embed[ids[row]]. */
+int afk_x32_linear(const float* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int M, int N, int K, const void* bias,
+                   const float* residual, int64_t ldr, int res_mod, float alpha, int gelu, void* stream);
+int afk_x32_norm(const float* x, const void* w, const void* b, float* y, int64_t rows, int D, float eps, int rms, void* stream);
+int afk_x32_attention(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo, int B, int S, int Hq,
+                      int Hkv, int D, float scale, int causal, const int* kv_lo, const int* kv_len, void* stream);
+int afk_x32_rope(float* x, int64_t ld, const float* cos_tab, const float* sin_tab, int64_t rows, int S, int nheads, int D, void* stream);
+int afk_x32_silu_mul(const float* gate_up, float* out, int64_t rows, int I, void* stream);
+int afk_x32_conv3_gelu(const float* x, int x_cmajor, const void* w, const void* bias, const void* pos, float* y, int W, int C, int T, int E, int stride,
+                       void* stream);
+int afk_x32_avgpool2(const float* x, float* y, int64_t W, int T, int E, void* stream);
+int afk_x32_embed_scatter(const int64_t* ids, const int* src, const float* audio, const void* embed, float* out, int64_t rows, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
