@@ -105,6 +105,14 @@ class AfkTrainer(_trainer_base()):
             from .dp import DataParallelEngine
 
             self._afk_engine = DataParallelEngine(self.model.arena, overlap=True)
+            if self._afk_engine.sharded:
+                # AFK_DP_FORM=rs_adamw_ag reduce-SCATTERS the gradients: only arena.ShardedAdamW (engine.make_optimizer) may consume them.  The Trainer's
+                # optimizer is the replicated AfkAdamW (its state_dict is the full fp32 state the HF checkpoint format expects) - refuse instead of
+                # training on gradient shares that were never reduced
+                from ._lib import AfkError
+
+                raise AfkError("AfkTrainer drives the replicated optimizer (AfkAdamW); AFK_DP_FORM=rs_adamw_ag (optimizer sharded over the ranks) is "
+                               "available through DataParallelEngine.make_optimizer() / bench.py, not through the Trainer - unset it")
             self._afk_engine.broadcast_parameters(0)
             opt = unwrap_optimizer(self.optimizer)
             if opt is not None:
