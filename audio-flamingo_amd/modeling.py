@@ -10,8 +10,15 @@ fused arena blocks (q|k|v and gate|up are stored contiguously so that each is on
 
 Deviations from the oracle surface (documented, not silent):
   * training forward with ``labels`` fuses lm_head + loss; ``output.logits`` is still there, as in the reference, but LAZY: the [B, S, V]
-    tensor is built on first access (``return_logits=True`` builds it eagerly, inside the autograd graph of the step); lm_head and the
-    loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
+    tensor is built on first access from the DETACHED final hidden states under ``no_grad`` - it carries NO gradient (the reference's is in
+    the graph: an auxiliary loss built on ``outputs.logits`` must use ``forward(return_logits=True)``, which builds the logits eagerly inside
+    the step's autograd graph) and reading it after an optimizer step raises (the weights are no longer the ones of ``output.loss``); lm_head
+    and the loss run only on the rows whose shifted label is not -100 (identical loss and gradients);
+  * ``gradient_checkpointing_enable()`` = every layer recomputed, as in the reference; ``gradient_checkpointing_kwargs={"policy": "budget"}``
+    opts into recomputing only what a memory budget requires;
+  * greedy token selection on the device (``afk_decode_select_greedy``) ignores NaN logits (picks the largest finite one) where ``torch.argmax``
+    returns the NaN's index: a model that produces NaNs decodes differently - by design, it keeps the graph-replayed step free of host checks;
+  * ``AFK_EXACT_FP32=1`` routes the inference forward / greedy ``generate`` through the exact fp32 verification kernels (exact.py);
   * ``forward(use_cache=True)`` / ``forward(past_key_values=cache)``: the reference's cache protocol for inference (prefill returns an
     ``AfkKVCache``, later calls append one or several tokens); same kernels and cache layout as ``generate``;
   * ``generate``: prefill fills a KV cache, each new token is one HIP-graph replay; greedy by default, ``do_sample=True`` with
