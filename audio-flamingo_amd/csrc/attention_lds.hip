@@ -425,6 +425,224 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ forward, PERSISTENT form (round 5, opt-in: AFK_ATTN_PERSIST=1)
+// At S = 1024 a forward block lives for 2-16 key tiles and pays ~6.8 us of fixed cost per block against 2.3 us per tile at long S: Q rows and
+// the first K / V tile arrive cold, the block is dispatched, the store tail drains.  Here min(items, slots) blocks stay resident and pull work items -
+// (sample, head, 128-query block), heavy first, the order the grid of attn_fwd_lds_kernel dispatches - from an atomic queue.  The hand-over between two
+// items hides the cold loads: the next item's first K / V tile is DMA'd into buffer 0 at the START of the current item's last tile (that tile lives in
+// buffer 1: the tile count is even), its Q rows are requested right after the last tile (qf is dead there), BEFORE the O / LSE stores - so the stores of item
+// i drain under tile 0 of item i + 1 (the compiler's counted vmcnt for qf skips the younger stores; nothing waits for vmcnt(0) until the barrier after tile 0).
+// Restrictions (the launcher falls back to attn_fwd_lds_kernel otherwise): no kv_len / kv_lo, S % 128 == 0 (every tile full, an even tile count per item).
+// Same arithmetic per item, bit for bit (same tile function, same order).  queue[0] = next item, queue[1] = blocks that have left; the last block resets both.
+template <int D, bool LM>
+__global__ __launch_bounds__(256, 2) void attn_fwd_persist_kernel(AttnArgs2 p, int* __restrict__ queue, int total_items) {
+    using T = Tile<D>;
+    constexpr int KS = T::KS, DT = T::DT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_next;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const typename T::Offs offs = T::make_offs(lane);
+    const int nz = p.S >> 7, HB = p.Hq * p.B, group = p.Hq / p.Hkv;
+    const float c2 = p.scale * LOG2E;
+    const uint32_t lds0 = afk_lds_addr(smem);
+    uint32_t vtr[DT][2];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) vtr[dt][pc] = lds0 + T::BYTES + offs.tr[dt][pc];
+    constexpr int NP = T::UNITS / 4;
+    uint32_t koff[NP], voff[NP];
+#pragma unroll
+    for (int u0 = 0; u0 < NP; ++u0) {
+        const int u = wave + 4 * u0, r = u * T::RPU + lane / T::CPR, chunk = (lane % T::CPR) ^ swz<D>(r);
+        koff[u0] = (uint32_t)(r * (int)p.k_rs + chunk * 8) * 2u;
+        voff[u0] = (uint32_t)(r * (int)p.v_rs + chunk * 8) * 2u;
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.f;
+
+    struct Item { int b, h, qb0; const bf16 *Kb, *Vb; };
+    auto decode = [&](int it) -> Item {   // wave-uniform
+        const int zr = it / HB, rem = it - zr * HB;
+        Item x;
+        x.h = rem % p.Hq;
+        x.b = rem / p.Hq;
+        x.qb0 = (p.causal ? nz - 1 - zr : zr) * 128;
+        x.Kb = p.K + x.b * p.k_bs + (x.h / group) * p.k_hs;
+        x.Vb = p.V + x.b * p.v_bs + (x.h / group) * p.v_hs;
+        return x;
+    };
+    auto stage_tile = [&](const Item& x, int j, int par) {
+        const uint32_t buf = lds0 + par * 2 * T::BYTES + wave * 1024;
+        const bf16* k0 = x.Kb + (int64_t)j * 64 * p.k_rs;
+        const bf16* v0 = x.Vb + (int64_t)j * 64 * p.v_rs;
+#pragma unroll
+        for (int u0 = 0; u0 < NP; ++u0) {
+            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
+        }
+    };
+    bf16x8 qf[KS];
+    auto load_q = [&](const Item& x) {
+        const bf16* Qp = p.Q + x.b * p.q_bs + x.h * p.q_hs + (int64_t)(x.qb0 + wave * 32 + l31) * p.q_rs + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+    };
+
+    Item cur = decode(blockIdx.x);
+    load_q(cur);
+    stage_tile(cur, 0, 0);
+    AFK_ATTN_BARRIER();
+    while (true) {
+        if (threadIdx.x == 0) s_next = (int)gridDim.x + __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read >= 2 barriers later
+        const int q = cur.qb0 + wave * 32 + l31;
+        const int ntiles = p.causal ? (cur.qb0 + 128) >> 6 : p.S >> 6;
+        const int n_int = p.causal ? cur.qb0 >> 6 : ntiles;
+        const int kv_end = p.causal ? cur.qb0 + wave * 32 + 32 : p.S;   // this wave's horizon
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[dt] = zero16();
+        float m = NEG_INF, l = 0.f;
+        f32x16 lacc = zero16();
+
+        auto tile = [&](int j, auto masked_, auto par_) {
+            constexpr bool MASKED = decltype(masked_)::value;
+            constexpr int POFF = par_static_off<decltype(par_)>(2 * T::BYTES);
+            const uint32_t boff = par_dyn_off(par_, 2 * T::BYTES);
+            const char* kimg = smem + POFF + boff;
+            f32x16 st[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
+                st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+            }
+            bf16x8 fa[4], fb[4];
+            auto issue = [&](auto g_, bf16x8(&dst)[4]) {
+                constexpr int dt = decltype(g_)::value;
+                const uint32_t a0 = vtr[dt][0] + boff, a1 = vtr[dt][1] + boff;
+                afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<POFF + s4 * 16 * T::RS>(a0, a1); });
+            };
+            issue(std::integral_constant<int, 0>{}, fa);
+            if (MASKED) {
+#pragma unroll
+                for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);
+                        st[kt2][r] = (p.causal && key > q) ? NEG_INF : st[kt2][r];
+                    }
+            }
+            float mx = fmaxf(st[0][0], st[1][0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);
+            mx = fmaxf(mx, other_half(mx)) * c2;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx > m + RESCALE_THR) != 0, 0)) {
+                asm volatile("" ::);
+                const float m_new = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - ((m_new == NEG_INF) ? 0.f : m_new));
+                if (LM) lacc[0] *= alpha;
+                else l *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                m = m_new;
+            }
+            const float nm = (m == NEG_INF) ? 0.f : -m;
+            const f32x2 c2v = {c2, c2}, nmv = {nm, nm};
+            bf16x8 pb[4];
+            f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 s2 = {st[kt2][r], st[kt2][r + 1]};
+                    const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, nmv);
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
+                    if (!LM) rs2 += p2;
+                    pb[2 * kt2 + (r >> 3)][r & 7] = (bf16)p2[0];
+                    pb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
+                }
+            if (!LM) l += rs2[0] + rs2[1];
+            if (LM) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) lacc = MFMA(ones, pb[s4], lacc);
+            }
+            afk_frag_ring<DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
+                constexpr int dt = decltype(g_)::value;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) oacc[dt] = MFMA(f[s4], pb[s4], oacc[dt]);
+            }, fa, fb);
+        };
+
+        // tiles in pairs (tile j in buffer j & 1; ntiles and n_int are even): every tile prefetches its successor, the LAST tile of the item (odd index:
+        // buffer 1) prefetches tile 0 of the NEXT item into buffer 0 instead - that buffer is free once the barrier behind tile ntiles - 2 has passed
+        int next = 0;
+        bool has_next = false;
+        Item nx = cur;
+        auto second_prefetch = [&](int j) {   // issued in front of tile j + 1
+            if (j + 2 < ntiles) {
+                stage_tile(cur, j + 2, 0);
+            } else {
+                next = s_next;
+                has_next = next < total_items;
+                if (has_next) {
+                    nx = decode(next);
+                    stage_tile(nx, 0, 0);
+                }
+            }
+        };
+        int j = 0;
+        for (; j < n_int; j += 2) {          // every key visible to every row
+            stage_tile(cur, j + 1, 1);
+            tile(j, std::false_type{}, StaticPar<0>{});
+            AFK_ATTN_BARRIER();
+            second_prefetch(j);
+            tile(j + 1, std::false_type{}, StaticPar<1>{});
+            AFK_ATTN_BARRIER();
+        }
+        if (j < ntiles) {                     // causal: the diagonal pair (the last one)
+            stage_tile(cur, j + 1, 1);
+            if (j * 64 < kv_end) tile(j, std::true_type{}, StaticPar<0>{});
+            AFK_ATTN_BARRIER();
+            second_prefetch(j);
+            if ((j + 1) * 64 < kv_end) tile(j + 1, std::true_type{}, StaticPar<1>{});
+            AFK_ATTN_BARRIER();
+        }
+        // epilogue of `cur`; the next item's Q rows are requested first
+        const int qcur = q, bcur = cur.b, hcur = cur.h;
+        if (has_next) {
+            cur = nx;
+            load_q(cur);
+        }
+        {
+            if (LM) l = lacc[0];
+            else l += other_half(l);
+            const float inv = (l > 0.f) ? 1.f / l : 0.f;
+            bf16* Op = p.O + bcur * p.o_bs + hcur * p.o_hs + (int64_t)qcur * p.o_rs;
+            if (p.wide) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) store_block32<true>(Op + dt * 32, oacc[dt], inv, hi);
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) store_block32<false>(Op + dt * 32, oacc[dt], inv, hi);
+            }
+            if (hi == 0 && p.LSE) p.LSE[((int64_t)bcur * p.Hq + hcur) * p.Spad + qcur] = (l > 0.f) ? -(m + __log2f(l)) / c2 : INFINITY;
+        }
+        if (!has_next) break;
+    }
+    if (threadIdx.x == 0) {
+        const int gone = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == (int)gridDim.x - 1) {   // every block has taken its last ticket: leave the queue ready for the next launch (stream order does the rest)
+            __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(queue + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dQ
 // Same geometry and loop structure as the forward (interior / boundary key tiles, opaque tr-reads issued ahead of the VALU block,
 // K/V prefetch in flight for the whole tile).  Per 64-key tile and wave: S^T = K.Q^T and dP^T = V.dO^T (4 x KS MFMAs on four
@@ -1037,6 +1255,50 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     }
 #undef AFK_FWD
     AFK_LAUNCH_CHECK("afk_attn2_fwd");
+    return AFK_OK;
+}
+
+// persistent form of afk_attn2_fwd (attn_fwd_persist_kernel): `queue` = two device ints, zero before the first call, left at zero by every call.
+// Falls back to the plain launch when the form's restrictions do not hold (kv_len / kv_lo given, S % 128 != 0).
+extern "C" int afk_attn2_fwd_persistent(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                                        int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
+                                        int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
+                                        int D, float scale, int causal, int* queue, void* stream) {
+    if (kv_len || kv_lo || S % 128 != 0 || !queue)
+        return afk_attn2_fwd(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, O, o_bs, o_hs, o_rs, LSE, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, stream);
+    AFK_REQUIRE(Q && K && V && O && LSE, "afk_attn2_fwd_persistent: null pointer");
+    AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && Spad >= S && Spad % 64 == 0 && (D == 64 || D == 128), "afk_attn2_fwd_persistent: bad shape");
+    AFK_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && q_hs % 8 == 0 && k_hs % 8 == 0 && v_hs % 8 == 0 && o_rs % 4 == 0,
+                "afk_attn2_fwd_persistent: strides must keep 16-byte alignment");
+    AttnArgs2 p = {};
+    p.Q = (const bf16*)Q; p.q_bs = q_bs; p.q_hs = q_hs; p.q_rs = q_rs;
+    p.K = (const bf16*)K; p.k_bs = k_bs; p.k_hs = k_hs; p.k_rs = k_rs;
+    p.V = (const bf16*)V; p.v_bs = v_bs; p.v_hs = v_hs; p.v_rs = v_rs;
+    p.O = (bf16*)O; p.o_bs = o_bs; p.o_hs = o_hs; p.o_rs = o_rs;
+    p.LSE = LSE;
+    p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    p.wide = attn_wide_stores() && (uintptr_t)O % 16 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 && o_rs % 8 == 0;
+    const int total = Hq * B * (S / 128);
+    hipStream_t st = (hipStream_t)stream;
+    afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
+    static const int lsum_env = [] { const char* e = getenv("AFK_ATTN_LSUM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool lm = lsum_env < 0 ? D == 128 : lsum_env == 1;
+    static const int slots_env = [] { const char* e = getenv("AFK_ATTN_PERSIST_BLOCKS"); return e ? atoi(e) : 0; }();
+#define AFK_FWDP(DD, LM_)                                                                                                \
+    do {                                                                                                                 \
+        constexpr int L = 4 * Tile<DD>::BYTES;                                                                           \
+        static int once = set_lds(attn_fwd_persist_kernel<DD, LM_>, L);                                                  \
+        (void)once;                                                                                                      \
+        const int slots = slots_env > 0 ? slots_env : 512;   /* two resident blocks per CU (237 / 175-189 VGPRs: two waves per SIMD) */          \
+        hipLaunchKernelGGL((attn_fwd_persist_kernel<DD, LM_>), dim3((unsigned)std::min(total, slots)), dim3(256), L, st, p, queue, total); \
+    } while (0)
+    if (D == 128) {
+        if (lm) AFK_FWDP(128, true); else AFK_FWDP(128, false);
+    } else {
+        if (lm) AFK_FWDP(64, true); else AFK_FWDP(64, false);
+    }
+#undef AFK_FWDP
+    AFK_LAUNCH_CHECK("afk_attn2_fwd_persistent");
     return AFK_OK;
 }
 

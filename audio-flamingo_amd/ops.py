@@ -483,6 +483,19 @@ def _row_stat_buffer(B, H, S, spad, device, kernel_writes_tail=True):
     return t
 
 
+ATTN_PERSIST = os.environ.get("AFK_ATTN_PERSIST", "0") == "1"   # forward on resident blocks + work queue (afk_attn2_fwd_persistent); restrictions in include/afk.h
+_ATTN_QUEUES = {}
+
+
+def _attn_queue(dev):
+    """work-queue words of afk_attn2_fwd_persistent: zero before the first launch, left at zero by every launch; one pair per (device, stream)"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _ATTN_QUEUES.get(key)
+    if t is None:
+        t = _ATTN_QUEUES[key] = torch.zeros(2, device=dev, dtype=torch.int32)
+    return t
+
+
 ATTN_FUSE_DELTA = os.environ.get("AFK_ATTN_FUSE_DELTA", "1") == "1"   # afk_attn2_bwd_fused (delta inside the dQ kernel) vs delta pass + afk_attn2_bwd
 ATTN_IMPL = "lds"  # "lds" = attention_lds.hip (head_dim 64/128), "direct" = attention.hip (also head_dim 32; A/B reference)
 
@@ -505,6 +518,11 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
     o = torch.empty((B * S, Hq * D), device=qkv.device, dtype=BF16)
     if _use_lds(D):
         lse = _row_stat_buffer(B, Hq, S, spad, qkv.device)
+        if ATTN_PERSIST and kv_len is None and kv_lo is None and S % 128 == 0:
+            _lib.call("afk_attn2_fwd_persistent", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+                      o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), None, None, B, Hq, Hkv, S, spad, D, float(scale),
+                      int(causal), _attn_queue(qkv.device).data_ptr(), _stream())
+            return o, lse
         _lib.call("afk_attn2_fwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   o.data_ptr(), S * Hq * D, D, Hq * D, lse.data_ptr(), _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D, float(scale),
                   int(causal), _stream())

@@ -219,6 +219,14 @@ int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
                   int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
                   int D, float scale, int causal, void* stream);
+/* afk_attn2_fwd with RESIDENT blocks that pull (sample, head, 128-query block) items from an atomic queue, heavy first, and overlap the next item's cold
+ * loads (first K / V tile, Q rows) with the current item's last tile and store tail (round 5, opt-in: AFK_ATTN_PERSIST=1).  Same results bit for bit.
+ * queue: two device ints, zero before the first call, left at zero by every call (one queue per stream that launches concurrently).  Restrictions: no
+ * kv_len / kv_lo, S % 128 == 0 - otherwise the call forwards to afk_attn2_fwd. */
+int afk_attn2_fwd_persistent(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                             int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
+                             int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
+                             int D, float scale, int causal, int* queue, void* stream);
 int afk_attn2_delta(const void* O, int64_t o_bs, int64_t o_hs, int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs,
                     int64_t do_rs, float* delta, int B, int H, int S, int Spad, int D, void* stream);
 int afk_attn2_bwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,

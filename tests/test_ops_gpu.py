@@ -911,6 +911,27 @@ def test_attn_decode_fused_last_block_merges(dev, D, Hq, Hkv):
             assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,causal", [(8, 1024, 28, 4, 128, True), (2, 1536, 20, 20, 64, False), (1, 128, 4, 2, 128, True), (3, 384, 4, 4, 64, True)])
+def test_attention_forward_persistent_form_bit_equal(dev, B, S, Hq, Hkv, D, causal):
+    """round 5, opt-in (AFK_ATTN_PERSIST=1): the forward on resident blocks that pull (sample, head, query block) items from an atomic queue and overlap the next
+    item's cold loads with the current item's last tile and store tail (attn_fwd_persist_kernel) - O and LSE bit-identical to the grid form, the queue words
+    left at zero, repeated launches; with fewer items than resident blocks (every block takes exactly one) and with more"""
+    ops = _ops()
+    qkv = _rand((B * S, (Hq + 2 * Hkv) * D), dev, 0.5, 5).to(BF)
+    old = ops.ATTN_PERSIST
+    try:
+        ops.ATTN_PERSIST = False
+        o0, l0 = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal)
+        ops.ATTN_PERSIST = True
+        for _ in range(3):
+            o1, l1 = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal)
+            torch.cuda.synchronize()
+            assert torch.equal(o0, o1) and torch.equal(l0[..., :S], l1[..., :S])
+            assert ops._attn_queue(dev).tolist() == [0, 0]
+    finally:
+        ops.ATTN_PERSIST = old
+
+
 @pytest.mark.parametrize("D,Hq,Hkv,B", [(128, 28, 4, 8), (64, 4, 2, 16), (128, 8, 2, 8)])
 def test_attn_decode_group_kernel_bit_equal(dev, D, Hq, Hkv, B):
     """round 5: batched decode attention - ONE block per (sample, KV head, key chunk) serves all Hq / Hkv query heads (attn_decode_group_kernel, taken by
