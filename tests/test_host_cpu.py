@@ -595,3 +595,89 @@ def test_comm_share_matches_the_library():
         for world in (1, 2, 3, 8):
             assert int(lib.afk_comm_share(n, world, 0)) == comm_share(n, world, 2), (n, world)
             assert int(lib.afk_comm_share(n, world, 1)) == comm_share(n, world, 4), (n, world)
+
+
+def test_reference_rotary_buffers_survive_the_harness_dtype_changes():
+    """round 5 finding: `module.to(torch.bfloat16)` rounds the reference's non-persistent rotary `inv_freq` buffer (modeling_qwen2.py:67-68) and a later
+    `.float()` only widens the rounded values, while a checkpoint loaded with `from_pretrained(dtype=bf16)` keeps the fp32 buffer (`:87`: explicit fp32 arange) - the
+    behaviour this repo implements.  At theta = 1e6 the rounded frequencies put position 1 000 off by radians; the parity harness therefore restores the fp32 values
+    after every dtype change of the reference (tools/parity_fulldepth.restore_rope_buffers).  Pinned here on the CPU: the hazard exists and the restore removes it."""
+    from transformers import AudioFlamingo3Config, AudioFlamingo3ForConditionalGeneration
+
+    from tools.parity_fulldepth import restore_rope_buffers
+
+    cfg = dict(TINY)
+    cfg["text_config"] = dict(TINY["text_config"], rope_parameters=dict(rope_theta=1000000.0, rope_type="default"))
+    ref = AudioFlamingo3ForConditionalGeneration(AudioFlamingo3Config(**cfg))
+    rot = next(m for m in ref.modules() if hasattr(m, "inv_freq") and hasattr(m, "compute_default_rope_parameters"))
+    exact = rot.inv_freq.clone()
+    assert exact.dtype == torch.float32
+    ref.to(torch.bfloat16).float()
+    rounded = rot.inv_freq.float()
+    assert not torch.equal(rounded, exact), "this transformers build no longer rounds the buffer: the restore below is then a no-op"
+    angle_err = ((rounded - exact).abs() * 1000.0).max()          # radians at position 1 000
+    assert float(angle_err) > 0.5, float(angle_err)
+    restore_rope_buffers(ref)
+    assert rot.inv_freq.dtype == torch.float32 and torch.equal(rot.inv_freq, exact) and torch.equal(rot.original_inv_freq, exact)
+    restore_rope_buffers(ref.to(torch.bfloat16))                   # and in a bf16 model the buffer stays fp32 (what from_pretrained(dtype=bf16) leaves)
+    assert rot.inv_freq.dtype == torch.float32 and torch.equal(rot.inv_freq, exact)
+
+
+def test_sharded_optimizer_ownership_map_and_budget_plan_accounting():
+    """host arithmetic of round 5: (i) ShardedAdamW's ownership map - own share + replicated tail per bucket, compact state offsets, `_pieces` of arbitrary
+    arena ranges - for worlds 2 / 3 / 8 on the tiny arena (no device, no launches); (ii) the memory-budgeted checkpoint plan takes the smaller of
+    "budget - allocated" and what the device can still give, and subtracts allocations that are still to come (lazy W^T shadows)"""
+    import bench
+
+    from audio_flamingo_amd.arena import ShardedAdamW, comm_share
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    m = Mine(_cfg(), device="cpu")
+    a = m.arena
+
+    class Eng:   # rank / world are all the constructor reads of the engine
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+
+    for world in (2, 3, 8):
+        owned_all = []
+        for rank in range(world):
+            o = ShardedAdamW.__new__(ShardedAdamW)
+            o.arena, o.engine, o.rank, o.world = a, Eng(rank, world), rank, world
+            o.owned, off = [], 0
+            for i in range(len(a.bucket_names)):
+                s, e = a.bucket_range(i)
+                share = comm_share(e - s, world)
+                for a0, a1 in ((s + rank * share, s + (rank + 1) * share), (s + share * world, e)):
+                    if a1 > a0:
+                        o.owned.append((a0, a1, off))
+                        off += a1 - a0
+            assert o.owned == sorted(o.owned) and all(x[1] <= y[0] for x, y in zip(o.owned, o.owned[1:]))      # ascending, disjoint
+            assert [p[2] for p in o.owned] == [sum(q[1] - q[0] for q in o.owned[:k]) for k in range(len(o.owned))]   # compact state
+            s0, e0 = a.bucket_range(3)
+            pieces = o._pieces(s0 + 5, e0 - 3)
+            assert all(s0 + 5 <= lo < hi <= e0 - 3 for lo, hi, _ in pieces)
+            assert sum(hi - lo for lo, hi, _ in o._pieces(0, a.total)) == off
+            owned_all.append(o.owned)
+        cover = torch.zeros(a.total, dtype=torch.int32)
+        for rank, owned in enumerate(owned_all):
+            for a0, a1, _ in owned:
+                cover[a0:a1] += 1
+        tails = torch.zeros(a.total, dtype=torch.bool)
+        for i in range(len(a.bucket_names)):
+            s, e = a.bucket_range(i)
+            tails[s + comm_share(e - s, world) * world: e] = True
+        assert bool((cover[~tails] == 1).all()) and bool((cover[tails] == world).all())   # every element owned once, tails by every rank
+
+    g = Mine.__new__(Mine)   # geometry only (as test_checkpoint_planner_...)
+    cfg = bench.af3_7b_config()
+    ac, tc = cfg.audio_config, cfg.text_config
+    g.config, g.enc_layers, g.dec_layers, g.max_pos, g.enc_heads = cfg, ac.num_hidden_layers, tc.num_hidden_layers, ac.max_source_positions, ac.num_attention_heads
+    g.Hq, g.Hkv, g.D = tc.num_attention_heads, tc.num_key_value_heads, tc.hidden_size // tc.num_attention_heads
+    g.ckpt_policy, g.ckpt_budget_bytes = "budget", None
+    total, resident = 288 * 2 ** 30, int(139.5 * 2 ** 30)
+    roomy = g.plan_checkpointing(20, 15274, resident, total, usable_bytes=140 * 2 ** 30)
+    tight = g.plan_checkpointing(20, 15274, resident, total, usable_bytes=100 * 2 ** 30)       # another process holds 40 GiB of the device
+    pending = g.plan_checkpointing(20, 15274, resident, total, usable_bytes=140 * 2 ** 30, pending_bytes=20 * 2 ** 30)
+    assert roomy["dec"] < tight["dec"] and roomy["dec"] < pending["dec"], (roomy, tight, pending)
+    assert g.plan_checkpointing(20, 15274, resident, total)["dec"] <= roomy["dec"]                # unknown device state: the budget alone
