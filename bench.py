@@ -380,6 +380,107 @@ def decode_leg(model, frontend, waves, ids, dev):
     return out
 
 
+LINE_LIMIT = 4096   # bytes: the driver parses the LAST stdout line; round 5's 30 KB line came back unparsed
+
+
+def _r(x, n=4):
+    return round(x, n) if isinstance(x, float) else x
+
+
+def _pick(d, keys, n=4):
+    return None if not isinstance(d, dict) else {k: _r(d[k], n) for k in keys if k in d}
+
+
+def parity_brief(s):
+    """<= 600 bytes of the full-depth parity summary (tools/parity_fulldepth.summary): verdict + the headline distances"""
+    if not isinstance(s, dict):
+        return None
+    if "error" in s:
+        return {"green": None, "error": str(s["error"])[:160]}
+    lg, g = s.get("logits", {}), s.get("gradients", {})
+    out = {"green": s.get("green"), "loss_abs_err": _r(s.get("loss_abs_err"), 5), "logits_rel_l2": _r(lg.get("rel_l2"), 4),
+           "logits_rel_l2_floor": _r(s.get("logits_floor_ref_bf16", {}).get("rel_l2"), 4),
+           "argmax_mismatches_on_confident_rows": lg.get("argmax_mismatches_on_confident_rows"), "confident_rows": lg.get("confident_rows"),
+           "rows": lg.get("rows"), "grad_tensors": g.get("tensors"),
+           "grad_ratio_median": _r(g.get("ours_over_floor", {}).get("median"), 3), "grad_ratio_max": _r(g.get("ours_over_floor", {}).get("max"), 3),
+           "bucket_norm_rel_err_max": _r(g.get("bucket_norm_rel_err_max"), 5),
+           "failed_checks": [k for k, v in (s.get("checks") or {}).items() if not v]}
+    for k in ("peaked", "long5min_train"):      # the round-6 legs: each already a short dict
+        if k in s:
+            out[k] = s[k]
+    return out
+
+
+def compact_line(res, detail_path=None):
+    """The ONE JSON line the driver parses: the contract's fields + roofline + roofline_hbm + cpu_baseline + parity verdict, <= LINE_LIMIT bytes.
+    Everything else of `res` (long-audio / decode / ICL / eager legs, DP prose, per-tensor tables) lives in gpurun_out/bench_detail.json."""
+    c = res.get("config") or {}
+    rf, rh, cb = res.get("roofline"), res.get("roofline_hbm"), res.get("cpu_baseline")
+    out = {k: _r(res.get(k), 3) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                          "dtype", "data")}
+    out["config"] = {k: c[k] for k in ("workload", "micro_batch_per_gpu", "global_batch", "seq_len", "parallelism", "activation_checkpointing") if k in c}
+    for k in ("decoder_tokens_per_s", "answer_tokens_per_s", "model_tflops_per_gpu", "executed_tflops_per_gpu", "hardware_tflops_per_gpu",
+              "model_frac_of_mfma_peak", "executed_frac_of_mfma_peak", "speedup_vs_eager_rocm", "peak_mem_gib"):
+        if res.get(k) is not None:
+            out[k] = _r(res[k], 4)
+    out["loss"], out["loss_first_step"], out["step_enqueue"] = _r(res.get("loss"), 4), _r(res.get("loss_first_step"), 4), res.get("step_enqueue")
+    if rf:
+        out["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "gemm_ms_per_step",
+                                     "frac_of_power_ceiling", "power_ceiling_tflops"))
+        out["roofline"]["kernel"] = str(out["roofline"].get("kernel"))[:120]
+    if rh:
+        out["roofline_hbm"] = _pick(rh, ("bound", "kernel", "achieved", "peak", "unit", "frac", "ms"))
+        out["roofline_hbm"]["kernel"] = str(out["roofline_hbm"].get("kernel"))[:60]
+    if cb:
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "dtype", "decoder_tokens_per_s", "s_per_sample_extrapolated", "host_cpus"), 5)
+        out["cpu_baseline"]["sample"] = str(cb.get("sample"))[:420]
+    eb = res.get("eager_rocm_baseline")
+    if isinstance(eb, dict) and eb.get("value"):
+        out["eager_rocm_baseline"] = _pick(eb, ("value", "unit", "ms_per_step", "micro_batch"), 2)
+    if res.get("parity_fulldepth") is not None:
+        out["parity_fulldepth"] = parity_brief(res["parity_fulldepth"])
+    la = res.get("long_audio_configs4")
+    if isinstance(la, dict):
+        out["long_audio_configs4"] = _pick(la, ("ms_per_step", "value", "unit", "decoder_tokens_per_s"), 2)
+    dec = res.get("decode")
+    if isinstance(dec, dict) and "B1" in dec:
+        out["decode_ms_per_token_steady"] = {b: _r(dec[b]["decode_ms_per_token_steady"], 3) for b in ("B1", "B8") if b in dec}
+    dp = res.get("dp")
+    if isinstance(dp, dict):
+        out["dp"] = {k: _r(dp[k], 2) for k in ("backend", "comm", "form", "chosen", "probe_ms", "preflight", "exposed_comm_ms", "buckets", "fallback",
+                                               "launched_by") if k in dp}
+        out["replicas_identical_after_steps"] = res.get("replicas_identical_after_steps")
+    for k in ("param_checksum", "rank_losses", "rccl_ranks"):    # tests/test_dp_gpu.py compares schedules on these
+        if res.get(k) is not None:
+            out[k] = res[k]
+    if res.get("dry_run"):
+        for k in ("dry_run", "replicas_identical_after_steps", "collective_backend", "buckets", "collectives_per_step", "launched_by"):
+            if k in res:
+                out[k] = res[k]
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out)
+    if len(line) >= LINE_LIMIT:   # never emit an unparseable record: shed the optional parts, largest first
+        for k in ("parity_fulldepth", "eager_rocm_baseline", "long_audio_configs4", "decode_ms_per_token_steady", "dp"):
+            if k in out and len(line) >= LINE_LIMIT:
+                out[k] = {"moved_to": detail_path} if k != "parity_fulldepth" else {"green": out[k].get("green"), "moved_to": detail_path}
+                line = json.dumps(out)
+    assert len(line) < LINE_LIMIT and json.loads(line)["metric"] == res.get("metric"), f"bench line is {len(line)} bytes"
+    return line
+
+
+def write_detail(res, name="bench_detail.json"):
+    """the full record beside the line: gpurun_out/ (merged back by gpurun); best effort - returns the repo-relative path or None"""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(res, f, indent=1)
+        return "gpurun_out/" + name
+    except OSError:
+        return None
+
+
 def dry_run_cpu(args):
     """CONTROL-FLOW TEST ONLY - no GPU, no kernel, no throughput (value = null).  Runs the N > 1 sequence of main() over gloo on the host:
     process group -> replica = the real model class on the CPU (layout / arena / buckets only) -> DataParallelEngine + parameter broadcast ->
@@ -428,11 +529,29 @@ def dry_run_cpu(args):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train", "dry_run": True, "value": None, "unit": "audio-s/s", "n_gpus": world,
+        print(compact_line({"metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train", "dry_run": True, "value": None, "unit": "audio-s/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "config": {"workload": "CONTROL-FLOW DRY RUN on the host (gloo): no kernels ran, nothing was measured"},
                           "replicas_identical_after_steps": identical, "collective_backend": "gloo", "buckets": len(arena.bucket_names),
-                          "collectives_per_step": len(engine.issued) + 1}), flush=True)
+                          "collectives_per_step": len(engine.issued) + 1, "launched_by": os.environ.get("AFK_BENCH_LAUNCHED_BY", "external")}), flush=True)
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): re-exec this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` - one rank per GPU - and hand its
+    exit status back.  The launcher form stays the primary one (it sets WORLD_SIZE, so this is never entered twice)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, AFK_BENCH_LAUNCHED_BY="self_spawn", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print(f"[bench] --gpus {n} without a launcher: re-executing under torch.distributed.run (port {port})", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def settle_hbm(dev, quiet_s=8.0, timeout_s=60.0):
@@ -505,9 +624,13 @@ def main():
                     "for each, park that many persistent workgroups on a side stream (afk_cu_hog: what RCCL's channel kernels do to the GEMM rounds) and time "
                     "5 steps beside them; reported as cu_contention {n: ms_per_step}")
     ap.add_argument("--no-settle", action="store_true", help="do not wait for the driver to release a previous process's VRAM (tests)")
+    ap.add_argument("--detail-name", default="bench_detail.json", help="file under gpurun_out/ that receives the FULL record (every leg, every note); the "
+                    "stdout line is the <= 4 KB summary of it")
     ap.add_argument("--dry-run-cpu", action="store_true", help="CONTROL-FLOW TEST ONLY (tests/test_host_cpu.py): no GPU, no kernels - the N > 1 sequence of this script "
                     "(process group, parameter broadcast, per-bucket exchange in backward order, replica checksum, one JSON line on rank 0) with a stub in place of the step")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_spawn(args.gpus)
     if args.dry_run_cpu:
         return dry_run_cpu(args)
     wl = WORKLOADS[args.workload]
@@ -550,7 +673,7 @@ def main():
         assert world == 1, "icl4 is a single-GPU measurement"
         res = run_icl4(args, dev)
         res["waited_for_free_hbm_s"] = waited
-        print(json.dumps(res), flush=True)
+        print(compact_line(res, write_detail(res, "bench_detail_icl4.json")), flush=True)
         return
     use_dp = world > 1 or args.force_dp
     if use_dp:
@@ -975,7 +1098,10 @@ def main():
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the measured line down
                 res["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": os.cpu_count(), "kind": "reference", "sample": f"failed: {e!r}"}
-        line = json.dumps(res)
+        # hardware = executed (what the kernels really did, recompute included, unlabelled lm_head rows excluded); the algorithmic figure stays `model_*`
+        res["hardware_tflops_per_gpu"] = res["executed_tflops_per_gpu"]
+        res["executed_frac_of_mfma_peak"] = (res["executed_tflops_per_gpu"] / 2500.0) if res["executed_tflops_per_gpu"] else None
+        line = compact_line(res, write_detail(res, args.detail_name))
     else:
         line = None
     def drain():

@@ -337,6 +337,52 @@ def test_bench_multi_rank_control_flow_gloo():
     assert d["buckets"] == 8 and d["collectives_per_step"] == 9    # stem, enc0, enc1, enc_out, embed, dec0, dec1, head + the touched-flag MAX
 
 
+def test_bench_self_spawns_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` with WORLD_SIZE unset (the command form the driver uses at N = 1) must not die on the
+    world-size assert: it re-executes itself under torch.distributed.run with one rank per GPU and still ends on ONE parseable JSON line"""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu"],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    assert len(lines[-1]) < 4096 and d["dry_run"] is True and d["n_gpus"] == 2 and d["launched_by"] == "self_spawn" and d["replicas_identical_after_steps"] is True
+
+
+def test_bench_line_stays_parseable_and_small():
+    """BENCH_r05.json came back `parsed: null` because the line had grown to 30 KB.  The line is now a <= 4 KB summary built by
+    bench.compact_line from the full record (which goes to gpurun_out/bench_detail.json); checked here on the largest record the repo holds - round 5's
+    full default run with every leg, DP prose and the per-tensor parity table in it - and on a record whose optional parts are all oversized"""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    with open(os.path.join(root, "profiles", "r05_bench_n1.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    d = json.loads(line)
+    assert len(line) < bench.LINE_LIMIT <= 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "roofline_hbm", "cpu_baseline", "parity_fulldepth"):
+        assert k in d, k
+    assert d["value"] == round(full["value"], 3) and d["ms_per_step"] == round(full["ms_per_step"], 3)
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "mfma"
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert d["parity_fulldepth"]["green"] is True and len(json.dumps(d["parity_fulldepth"])) <= 600
+    assert "model" not in d["config"] and d["config"]["workload"]
+    # pathological growth of the optional parts must shed them, never break the line
+    fat = dict(full)
+    fat["parity_fulldepth"] = dict(full["parity_fulldepth"], peaked={"note": "x" * 5000})
+    line2 = bench.compact_line(fat, "gpurun_out/bench_detail.json")
+    assert len(line2) < 4096 and json.loads(line2)["parity_fulldepth"]["green"] is True
+
+
 def test_af3_output_is_lazy_about_logits():
     """forward(labels=...) hands back the reference's output surface with logits built on FIRST ACCESS: reading the loss (attribute, key or
     index 0 - what Trainer.compute_loss does) must not build them; outputs[1:] (what Trainer.prediction_step reads) must"""
