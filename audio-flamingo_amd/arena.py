@@ -158,7 +158,9 @@ class Arena:
         self._bucket_pending = list(self._bucket_sizes)
 
     def enable_wgrad_stream(self, on: bool = True):
-        self.wgrad_stream = torch.cuda.Stream(device=self.device) if on and self.device.type == "cuda" else None
+        from .streams import make_stream   # lowest queue priority: the wgrad GEMMs fill what the critical path leaves (streams.py)
+
+        self.wgrad_stream = make_stream(self.device, "wgrad") if on and self.device.type == "cuda" else None
 
     def join_streams(self):
         """make the current stream wait for everything enqueued on the wgrad stream (call before reading .grad)"""

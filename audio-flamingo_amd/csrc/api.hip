@@ -44,3 +44,30 @@ extern "C" int afk_has_probes(void) {
     return 0;
 #endif
 }
+
+// ---- streams with an explicit priority (include/afk.h): the side streams of the training step below the default, its critical path above
+extern "C" int afk_stream_priority_range(int* host_least, int* host_greatest) {
+    AFK_REQUIRE(host_least && host_greatest, "afk_stream_priority_range: null output");
+    hipError_t e = hipDeviceGetStreamPriorityRange(host_least, host_greatest);
+    AFK_REQUIRE(e == hipSuccess, "hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e));
+    return AFK_OK;
+}
+extern "C" int afk_stream_create(int priority, void** host_stream_out) {
+    AFK_REQUIRE(host_stream_out, "afk_stream_create: null output");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    AFK_REQUIRE(e == hipSuccess, "hipDeviceGetStreamPriorityRange: %s", hipGetErrorString(e));
+    if (priority > least) priority = least;        // numerically greater = lower priority
+    if (priority < greatest) priority = greatest;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    AFK_REQUIRE(e == hipSuccess, "hipStreamCreateWithPriority(%d): %s", priority, hipGetErrorString(e));
+    *host_stream_out = (void*)s;
+    return AFK_OK;
+}
+extern "C" int afk_stream_destroy(void* stream) {
+    AFK_REQUIRE(stream, "afk_stream_destroy: null stream");
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    AFK_REQUIRE(e == hipSuccess, "hipStreamDestroy: %s", hipGetErrorString(e));
+    return AFK_OK;
+}

@@ -429,7 +429,9 @@ class BackwardOverlap:
 
     def __init__(self, arena: Arena, optimizer, engine: Optional["DataParallelEngine"] = None):
         self.arena, self.opt, self.engine = arena, optimizer, engine
-        self.side = torch.cuda.Stream(device=arena.device)
+        from .streams import make_stream
+
+        self.side = make_stream(arena.device, "side")
         self._done: List[bool] = []
         self.grad_scale = engine.grad_scale if engine is not None else 1.0
         self.thin_blocks = 256  # optimizer launches of one block per CU so that they co-reside with the GEMM workgroups

@@ -25,11 +25,12 @@ from ._lib import AfkError
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, overlap, step_body: Callable[[], torch.Tensor], warmup: int = 2):
+    def __init__(self, model, optimizer, overlap, step_body: Callable[[], torch.Tensor], warmup: int = 2, stream: Optional[torch.cuda.Stream] = None):
         """step_body(): one EAGER training step on static input tensors, built from
                model.arena.zero_grad(); overlap.begin_step(); loss = model(...).loss; loss.backward(); overlap.finish(); return loss
         It runs `warmup` times eagerly (real optimizer steps: lazy one-time initialisation inside the library and the allocator's
-        steady state happen outside the capture), then once more under capture."""
+        steady state happen outside the capture), then once more under capture.  `stream`: the stream the capture (and the eager warm-up) runs on -
+        pass streams.make_stream(device, "compute") so that the captured critical path keeps its queue priority over the wgrad / optimizer branches."""
         if model.device_.type != "cuda":
             raise AfkError("GraphedTrainStep needs a HIP device")
         if getattr(model, "check_placeholders", False):
@@ -38,7 +39,7 @@ class GraphedTrainStep:
             raise AfkError("GraphedTrainStep: activation checkpointing (torch.utils.checkpoint) is not captured; use the eager step")
         self.model, self.opt, self.overlap = model, optimizer, overlap
         cur = torch.cuda.current_stream()
-        s = torch.cuda.Stream(device=model.device_)
+        s = stream if stream is not None else torch.cuda.Stream(device=model.device_)
         s.wait_stream(cur)
         with torch.cuda.stream(s):
             for _ in range(max(warmup, 1)):
@@ -53,7 +54,7 @@ class GraphedTrainStep:
             # while this one captures invalidates the capture and the watchdog's exception aborts the process (seen 2 / 8 runs of the 1-rank RCCL graph test)
             import torch.distributed as dist
             mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode, **({"stream": stream} if stream is not None else {})):
                 self.loss = step_body()
         finally:
             optimizer._in_capture = False

@@ -1,0 +1,50 @@
+"""HIP streams of the training step, with queue priorities.
+
+The step runs on three streams: the critical path (forward, dgrad, attention, norms: "compute"), the weight-gradient GEMMs
+("wgrad") and the optimizer / gradient exchange ("side").  The compute stream IS the step (392 of 406 ms busy, profiles/r05_bench_timeline_default_schedule.md),
+and beside the one-per-CU 256 x 256 wgrad workgroups its kernels ran 2.5-7 x slower than alone.  With priorities the workgroup
+dispatcher hands a CU that frees up to the compute queue first; the wgrad GEMMs take what is left.  torch.cuda.Stream only reaches "normal" and
+"high", so the handles come from libafk (afk_stream_create: the device's whole range) and are wrapped with torch.cuda.ExternalStream.
+
+AFK_STREAM_PRIORITIES=0 turns it off (every role at the default priority: the round-5 schedule).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+_ROLE_PRIORITY = {"compute": "greatest", "wgrad": "least", "side": "least"}
+_keep = []   # ExternalStream does not own its handle: the handles live as long as the process
+
+
+def enabled() -> bool:
+    return os.environ.get("AFK_STREAM_PRIORITIES", "1") != "0"
+
+
+def priority_range():
+    """(least, greatest) of the current device: numerically greater = lower priority; (0, 0) = the device has one level"""
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.call("afk_stream_priority_range", ctypes.byref(least), ctypes.byref(greatest))
+    return least.value, greatest.value
+
+
+def make_stream(device, role: str) -> torch.cuda.Stream:
+    """a stream for `role` ("compute" | "wgrad" | "side") on `device`; plain torch.cuda.Stream when priorities are off"""
+    device = torch.device(device)
+    if role not in _ROLE_PRIORITY:
+        raise _lib.AfkError(f"make_stream: unknown role {role!r}")
+    if not enabled():
+        return torch.cuda.Stream(device=device)
+    with torch.cuda.device(device):
+        least, greatest = priority_range()
+        prio = least if _ROLE_PRIORITY[role] == "least" else greatest
+        h = ctypes.c_void_p(0)
+        _lib.call("afk_stream_create", prio, ctypes.byref(h))
+    s = torch.cuda.ExternalStream(h.value, device=device)
+    s.afk_role, s.afk_priority = role, prio
+    _keep.append(h.value)
+    return s

@@ -450,7 +450,7 @@ def compact_line(res, detail_path=None):
         out["dp"] = {k: _r(dp[k], 2) for k in ("backend", "comm", "form", "chosen", "probe_ms", "preflight", "exposed_comm_ms", "buckets", "fallback",
                                                "launched_by") if k in dp}
         out["replicas_identical_after_steps"] = res.get("replicas_identical_after_steps")
-    for k in ("param_checksum", "rank_losses", "rccl_ranks"):    # tests/test_dp_gpu.py compares schedules on these
+    for k in ("param_checksum", "rank_losses", "rccl_ranks", "stream_priorities"):    # tests/test_dp_gpu.py compares schedules on these
         if res.get(k) is not None:
             out[k] = res[k]
     if res.get("dry_run"):
@@ -707,6 +707,15 @@ def main():
     model.arena.enable_wgrad_stream(not args.no_wgrad_stream)
     model.arena.thin_blocks = int(os.environ.get("AFK_THIN_TRANSPOSE", "0"))
     frontend = LogMelFrontend(dev)
+    # the critical path on a stream ABOVE the default queue priority, the wgrad / optimizer streams below it (audio_flamingo_amd/streams.py);
+    # AFK_STREAM_PRIORITIES=0 = every stream at the default priority (the round-5 schedule)
+    from audio_flamingo_amd import streams as _streams
+
+    compute_stream = None
+    if _streams.enabled():
+        compute_stream = _streams.make_stream(dev, "compute")
+        compute_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(compute_stream)
     # `--batches` distinct synthetic batches live in HBM; every step trains on the next one (copied into the static input tensors the step -
     # and its HIP graph - reads).  Training the SAME batch every step (round 2) drives the loss to ~0 within the timed region: saturated
     # softmax, vanishing gradients - and on a power-limited chip operand statistics move the clock.
@@ -770,7 +779,7 @@ def main():
     if use_graph:
         from audio_flamingo_amd.graphs import GraphedTrainStep
 
-        run = GraphedTrainStep(model, opt, overlap, step, warmup=1)
+        run = GraphedTrainStep(model, opt, overlap, step, warmup=1, stream=compute_stream)
     loss = None
     for i in range(args.warmup):
         load_next()
@@ -991,6 +1000,9 @@ def main():
                        "windows_per_sample": windows, "activation_checkpointing": ckpt, "checkpoint_plan": plan, "max_grad_norm": args.clip if args.clip > 0 else None,
                        "parallelism": f"dp{world}", "params": model.trainable_numel()},
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
+            "stream_priorities": None if compute_stream is None else {"range_least_greatest": list(_streams.priority_range()), "compute": compute_stream.afk_priority,
+                                                                      "wgrad": getattr(model.arena.wgrad_stream, "afk_priority", None),
+                                                                      "side": getattr(getattr(overlap, "side", None), "afk_priority", None)},
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
             "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb, "label_rows_static": bool(model.label_rows_static),
             "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind,

@@ -393,6 +393,24 @@ int afk_comm_broadcast(void* comm, void* buf, int64_t n, int dtype, int root, vo
  * start tick, ticks alive, XCC id << 32 | HW_ID of every parked workgroup - proof that they sat where the GEMM workgroups wanted to be. */
 int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_ticks, int64_t* report, void* stream);
 
+/* ---- measured ceiling of the matrix pipe under the socket power cap (round 6; measurement utility like afk_cu_hog, no reference counterpart: the
+ * reference's GEMMs are the vendor BLAS behind TORCH F.linear, modeling_qwen2.py:46-48).  Launches `nblocks` workgroups of 8 waves that run `iters`
+ * segments of 16 v_mfma_f32_32x32x16_bf16 (2 x 2 tiles x 4 k-steps, the MFMA segment of gemm_nt_bf16_k256) on operands taken from `operands`
+ * (device, bf16, >= 65536 elements, e.g. N(0,1)).  mode 0: operands resident in registers, no memory access inside the loop.  mode 1: the GEMM's
+ * LDS fragment traffic added (12 ds_read_b128 per segment from a 64 KiB LDS image of `operands`).  *host_flops (nullable) receives the flops
+ * of the launch; time it with HIP events on `stream`.  sink: device float, never written in practice. */
+int afk_mfma_ceiling(int mode, int nblocks, int iters, const void* operands, float* sink, double* host_flops, void* stream);
+
+/* ---- HIP streams with an explicit queue priority (round 6).  The training step runs on three streams: the critical path (forward, dgrad, attention,
+ * norms), the weight-gradient GEMMs and the optimizer / gradient exchange (reference counterpart: DDP's separate reduction stream,
+ * TORCH/nn/parallel/distributed.py:1442; autograd itself is single-stream there).  torch.cuda.Stream can only ask for "normal" or "high"; these entry points
+ * expose the device's whole range so that the side streams can sit BELOW the default and the compute stream above it (torch wraps the handle with
+ * torch.cuda.ExternalStream).  host_least / host_greatest receive hipDeviceGetStreamPriorityRange (numerically greater = lower priority);
+ * afk_stream_create clamps `priority` into that range, creates a non-blocking stream on the current device and stores the hipStream_t in *host_stream_out. */
+int afk_stream_priority_range(int* host_least, int* host_greatest);
+int afk_stream_create(int priority, void** host_stream_out);
+int afk_stream_destroy(void* stream);
+
 /* ---- EXACT fp32 inference forward (round 5; SURVEY.md 8c "an fp32 mode of our kernels ... should give bit-exact tokens unconditionally on the tiny config").
  * A VERIFICATION mode (AFK_EXACT_FP32=1, audio_flamingo_amd/exact.py), not a fast path: activations fp32, weights the bf16 values of the checkpoint widened in
  * registers, every product and sum fp32 (v_mfma_f32_32x32x2_f32 for the Linears, fp32 VALU elsewhere) - no bf16 rounding point between the log-mel features
