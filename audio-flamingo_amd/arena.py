@@ -23,6 +23,7 @@ import os
 import torch
 
 from . import ops
+from ._lib import AfkError
 
 ALIGN = 64  # elements (128 B): keeps every block 16-byte aligned for the LDS-DMA GEMM
 
@@ -456,6 +457,10 @@ class ShardedAdamW(FusedAdamW):
     replicated rs_ag form; at world 2 any summation order gives the same bits).  The tail of a bucket that does not divide (afk_comm_share: shares are
     multiples of 128 bytes) is all-reduced and updated by every rank - replicated state of < world * 64 elements per bucket.
 
+    GRADIENT VALIDITY: after a sharded reduce only this rank's share and the replicated tail of `arena.grads` hold reduced values - the shares of the other
+    ranks still hold this rank's LOCAL, unreduced gradients.  Nothing but this optimizer may read arena.grads in this form (a logging hook that wants a
+    gradient norm reads `grad_norm`, which set_clip_coef() assembles from every rank's share).  engine.poison_unowned (tests) makes a wrong reader visible.
+
     State lives in ONE compact fp32 array per moment: for every bucket, this rank's share followed by the bucket's tail.  `engine` (dp.DataParallelEngine)
     supplies rank / world and the collectives; after this rank's launches of a bucket it all-gathers the bucket's parameters on the same stream.
     Global-norm clipping: every rank sums the squares of its own shares (the tail on rank 0 only), one extra SUM all-reduce of the per-bucket partial
@@ -524,15 +529,23 @@ class ShardedAdamW(FusedAdamW):
 
     def add_sumsq(self, i: int, gate=None, written_only: bool = True):
         """this rank's part of sum(g^2) of bucket i: its own share, and the replicated tail on rank 0 only (counted once in the all-rank sum).
-        Data parallel: every slice of a reduced bucket holds a reduced gradient (zeros where nobody contributed), so `written_only` does not apply."""
+        Data parallel: every slice of a reduced bucket holds a reduced gradient (zeros where nobody contributed).  Without collectives (one process,
+        force_collectives off) nothing has cleared the blocks backward did not write: `written_only` then restricts the sum to the blocks written
+        since zero_grad(), exactly the set step_bucket() updates (the norm and the update must see the same gradients)."""
         a = self.arena
         s, e = a.bucket_range(i)
         share = comm_share(e - s, self.world)
         tail0 = s + share * self.world
-        for lo, hi, _ in self._pieces(s, e):
-            if lo >= tail0 and self.rank != 0:
-                continue
-            ops.sumsq_(a.grads[lo:hi], self._sumsq[i:i + 1], gate=gate, ws=self._sumsq_ws)
+        multi = self.world > 1 or bool(getattr(self.engine, "force_collectives", False))
+        if written_only and not multi:
+            spans = [(rs, re_) for rs, re_, _ in self._runs([b for b in a.bucket_blocks(i) if not b.fresh])]
+        else:
+            spans = [(s, e)]
+        for rs, re_ in spans:
+            for lo, hi, _ in self._pieces(rs, re_):
+                if lo >= tail0 and self.rank != 0:
+                    continue
+                ops.sumsq_(a.grads[lo:hi], self._sumsq[i:i + 1], gate=gate, ws=self._sumsq_ws)
 
     def set_clip_coef(self, grad_scale: float = 1.0):
         self.engine.allreduce_small_sum_(self._sumsq)   # per-bucket partial sums of squares over the ranks' shares -> the full gradient's
@@ -562,3 +575,67 @@ class ShardedAdamW(FusedAdamW):
         self._mark_synced()
         if refresh_shadows:
             a.refresh_shadows(force=True)
+
+    # ------------------------------------------------------------------ checkpoint / resume (the sharded state must be saveable)
+    def _consolidate(self, compact: torch.Tensor, to_cpu: bool) -> torch.Tensor:
+        """one compact per-rank state array -> the FULL flat fp32 array in the arena's layout (what FusedAdamW holds and trainer.AfkAdamW saves), on every
+        rank: each rank writes the pieces it owns into zeros (a bucket's replicated tail from rank 0 only) and a SUM over the ranks assembles them -
+        x + 0 + ... + 0 is exact, so the result is bit-identical to the owners' values.  Chunked (256 Mi elements) so that a host-staged backend works."""
+        a = self.arena
+        full = torch.zeros(a.total, device=a.device, dtype=torch.float32)
+        for i in range(len(a.bucket_names)):
+            s, e = a.bucket_range(i)
+            tail0 = s + comm_share(e - s, self.world) * self.world
+            for lo, hi, off in self._pieces(s, e):
+                if lo >= tail0 and self.rank != 0:
+                    continue
+                full[lo:hi].copy_(compact[off: off + hi - lo])
+        if self.world > 1:
+            import torch.distributed as dist
+
+            eng = self.engine
+            for c0 in range(0, a.total, 1 << 28):
+                piece = full[c0: c0 + (1 << 28)]
+                if eng.native is not None:
+                    eng.native.allreduce_(piece, form="allreduce")
+                elif getattr(eng, "staged", False):
+                    h = piece.cpu()
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=eng.pg)
+                    piece.copy_(h.to(piece.device))
+                else:
+                    dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=eng.pg)
+        return full.cpu() if to_cpu else full
+
+    def state_dict(self, to_cpu: bool = True):
+        """COLLECTIVE (every rank calls it): the consolidated optimizer state in the replicated layout - {"state": {"master", "m", "v": fp32 [arena.total],
+        "t"}, "hyper": {...}} - the same "state" trainer.AfkAdamW.state_dict() saves, so a run may be checkpointed sharded and resumed replicated (or at another
+        world size) and vice versa.  One moment at a time (33 GB fp32 for AF3-7B), moved to the host before the next when to_cpu (the default)."""
+        self.arena.join_streams()
+        return {"state": {"master": self._consolidate(self.master, to_cpu), "m": self._consolidate(self.m, to_cpu), "v": self._consolidate(self.v, to_cpu),
+                          "t": self.t},
+                "hyper": {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay},
+                "layout": {"format": "flat-arena-fp32", "numel": self.arena.total, "saved_from_world": self.world}}
+
+    def load_state_dict(self, sd):
+        """restore from the consolidated layout (state_dict() above or trainer.AfkAdamW.state_dict()): every rank slices out the pieces it owns; the bf16
+        working copy of EVERY parameter follows the restored fp32 master, as AfkAdamW.load_state_dict does."""
+        st = sd["state"]
+        a = self.arena
+        for name in ("master", "m", "v"):
+            if st[name].numel() != a.total:
+                raise AfkError(f"ShardedAdamW.load_state_dict: {name} has {st[name].numel()} elements, the arena {a.total}")
+        for a0, a1, off in self.owned:
+            n = a1 - a0
+            self.master[off: off + n].copy_(st["master"][a0:a1])
+            self.m[off: off + n].copy_(st["m"][a0:a1])
+            self.v[off: off + n].copy_(st["v"][a0:a1])
+        self.t = int(st["t"])
+        for k, v in (sd.get("hyper") or {}).items():
+            setattr(self, k, tuple(v) if k == "betas" else v)
+        for c0 in range(0, a.total, 1 << 28):
+            a.params.data[c0: c0 + (1 << 28)].copy_(st["master"][c0: c0 + (1 << 28)])
+        a.step_counter += 1
+        self._mark_synced()
+        if a.device.type == "cuda":
+            a.refresh_shadows(force=True)
+

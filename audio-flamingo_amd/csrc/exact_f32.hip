@@ -79,12 +79,15 @@ __global__ __launch_bounds__(256) void x32_norm_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void x32_attention_kernel(const float* __restrict__ Q, int64_t ldq, const float* __restrict__ Kp, int64_t ldk,
                                                             const float* __restrict__ Vp, int64_t ldv, float* __restrict__ O, int64_t ldo, int S, int Hq, int Hkv,
                                                             int D, float scale, int causal, const int* __restrict__ kv_lo, const int* __restrict__ kv_len) {
-    extern __shared__ float x32_smem[];
+    extern __shared__ __attribute__((aligned(16))) float x32_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
     if (s >= S) return;   // whole wave: no block-level barrier below
-    float* sc = x32_smem + (int64_t)wave * (S + D);
-    float* qs = sc + S;
+    // the score row is padded to a multiple of 4 floats: the query row behind it is read with 16-byte LDS loads, and greedy decoding grows S by one
+    // per token (3 of 4 steps would otherwise read it misaligned: ADVICE r05).  D % 4 == 0 (checked by the launcher) keeps every wave's base aligned too.
+    const int Sp = (S + 3) & ~3;
+    float* sc = x32_smem + (int64_t)wave * (Sp + D);
+    float* qs = sc + Sp;
     const int hk = h / (Hq / Hkv);
     const int lo = kv_lo ? max(kv_lo[b], 0) : 0;
     int hiK = kv_len ? min(kv_len[b], S) : S;
@@ -233,7 +236,8 @@ extern "C" int afk_x32_attention(const float* Q, int64_t ldq, const float* K, in
                                  int Hkv, int D, float scale, int causal, const int* kv_lo, const int* kv_len, void* stream) {
     AFK_REQUIRE(Q && K && V && O && B > 0 && S > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && D > 0 && D % 4 == 0, "afk_x32_attention: bad arguments");
     AFK_REQUIRE(ldk % 4 == 0 && ((uintptr_t)K & 15) == 0, "afk_x32_attention: key rows must be 16-byte aligned");
-    const size_t lds = (size_t)4 * (S + D) * sizeof(float);
+    AFK_REQUIRE(D % 4 == 0, "afk_x32_attention: head_dim %d is not a multiple of 4", D);
+    const size_t lds = (size_t)4 * (((S + 3) & ~3) + D) * sizeof(float);
     AFK_REQUIRE(lds <= 160 * 1024, "afk_x32_attention: S + D = %d exceeds the LDS score rows of this verification kernel (160 KiB / 16 bytes)", S + D);
     static int once = hipFuncSetAttribute((const void*)x32_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : 1;
     (void)once;

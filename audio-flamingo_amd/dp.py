@@ -132,7 +132,9 @@ class NativeComm:
 
 
 class DataParallelEngine:
-    def __init__(self, arena: Arena, process_group=None, overlap: bool = True, comm: Optional[str] = None):
+    _native_cache: dict = {}   # one RCCL communicator of the C ABI per (process group) for the life of the process: engines come and go (bench.py's form probe)
+
+    def __init__(self, arena: Arena, process_group=None, overlap: bool = True, comm: Optional[str] = None, form: Optional[str] = None):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.arena = arena
@@ -149,14 +151,19 @@ class DataParallelEngine:
         import os as _os
 
         self.comm_kind = comm or _os.environ.get("AFK_DP_COMM", "torch")
-        self.form = _os.environ.get("AFK_DP_FORM", "rs_ag")
+        self.form = form or _os.environ.get("AFK_DP_FORM", "rs_ag")
         # AFK_DP_FORM=rs_adamw_ag (opt-in, round 5): the optimizer is SHARDED over the ranks - per bucket reduce-scatter(grads) -> AdamW on this rank's
         # share (arena.ShardedAdamW) -> all-gather(bf16 params); with either communicator library.  After reduce_bucket_() only this rank's share and
         # the replicated tail of a gradient bucket hold reduced values.
         self.sharded = self.form == "rs_adamw_ag"
         self._gate_vec: Optional[torch.Tensor] = None
         self.poison_unowned = False   # tests: where the exchange is emulated by an all-reduce (gloo), put the LOCAL values back into the shares this rank does not own
-        self.native = NativeComm.from_process_group(process_group) if (self.comm_kind == "native" and self.cuda and not self.staged) else None
+        self.native = None
+        if self.comm_kind == "native" and self.cuda and not self.staged:
+            ck = id(process_group) if process_group is not None else 0
+            if ck not in DataParallelEngine._native_cache:
+                DataParallelEngine._native_cache[ck] = NativeComm.from_process_group(process_group)
+            self.native = DataParallelEngine._native_cache[ck]
         self.overlap = overlap and self.cuda
         self.comm_stream = torch.cuda.Stream(device=arena.device) if self.cuda else None
         self._works: List = []
@@ -206,6 +213,11 @@ class DataParallelEngine:
             self.native.allreduce_(buf, form=self.form)
             return
         if not self.staged:
+            if not self.cuda and not self._native_bf16:   # host arenas over a gloo build without bf16 reductions: through fp32
+                f = buf.float()
+                dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.pg)
+                buf.copy_(f)
+                return
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
             return
         for ev in self.arena.ready_events():
@@ -271,7 +283,10 @@ class DataParallelEngine:
         # `.data`: same storage, its OWN version counter - the parameter views are saved tensors of backward nodes that have not run yet (this call
         # sits inside backward), and an in-place torch op on the arena itself would invalidate them for autograd; the AdamW kernels write through
         # raw pointers for the same reason
-        p = self.arena.params.data[s:e]
+        self._allgather_shares_(self.arena.params.data[s:e], share)
+
+    def _allgather_shares_(self, p: torch.Tensor, share: int):
+        """in place on the CURRENT stream: rank r's [r * share, (r + 1) * share) of `p` to every rank"""
         r, w = self.rank, self.world
         if self.native is not None:
             self.native.allgather_(p)
@@ -396,6 +411,91 @@ class DataParallelEngine:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
         return t
 
+    # ------------------------------------------------------------------ pre-flight (bench.py, N > 1)
+    def preflight(self) -> dict:
+        """One round of every collective the step uses, on a real gradient bucket, with KNOWN answers - run once before the first step so that a broken
+        communicator shows up as a named failure in seconds instead of as a hang or a diverged replica mid-run:
+            all-reduce(SUM) of a whole layer bucket (the replicated forms) -> every element = world (world + 1) / 2;
+            reduce-scatter of it (the sharded form) -> this rank's share and the tail hold that sum; all-gather of per-rank markers -> share q = q + 1;
+            the touched-flag MAX; replica checksum (parameters identical on every rank after broadcast_parameters).
+        -> {"ok", "failed": [...], "<leg>_ms", "allreduce_busbw_gbs", ...}.  Clobbers the gradient arena (re-zeroed at the end), never the parameters."""
+        import time
+
+        a, w, r = self.arena, self.world, self.rank
+        sizes = [a.bucket_range(i)[1] - a.bucket_range(i)[0] for i in range(len(a.bucket_names))]
+        i = max((k for k in range(len(sizes)) if 2 * sizes[k] <= (1 << 30)), key=lambda k: sizes[k], default=max(range(len(sizes)), key=lambda k: sizes[k]))
+        buf, n = a.bucket_grads(i), sizes[i]
+        share = comm_share(n, w)
+        want = w * (w + 1) / 2.0
+        out = {"bucket": a.bucket_names[i], "bytes": 2 * n, "world": w, "comm": self.comm_kind if self.native is not None else ("gloo-staged" if self.staged else "torch"),
+               "failed": []}
+
+        def sync():
+            if self.cuda:
+                torch.cuda.synchronize()
+
+        def timed(name, fn):
+            sync()
+            t0 = time.perf_counter()
+            fn()
+            sync()
+            out[name + "_ms"] = round(1e3 * (time.perf_counter() - t0), 2)
+
+        def all_equal(t, v):
+            return t.numel() == 0 or (float(t.float().min()) == v and float(t.float().max()) == v)
+
+        buf.fill_(r + 1)
+        timed("allreduce_first", lambda: self.allreduce_sum_(buf))     # carries the lazy communicator / channel setup
+        if not all_equal(buf, want):
+            out["failed"].append("allreduce")
+        buf.fill_(r + 1)
+        timed("allreduce", lambda: self.allreduce_sum_(buf))
+        out["allreduce_busbw_gbs"] = round(2.0 * (w - 1) / max(w, 1) * 2 * n / max(out["allreduce_ms"] * 1e-3, 1e-9) / 1e9, 1)
+        was = self.sharded
+        try:
+            self.sharded = True
+            buf.fill_(r + 1)
+            timed("reduce_scatter", lambda: self.reduce_bucket_(i))
+            mine = torch.cat([buf[r * share:(r + 1) * share], buf[share * w:]])
+            if not all_equal(mine, want):
+                out["failed"].append("reduce_scatter")
+            if share and (w > 1 or self.force_collectives):
+                buf[: share * w].zero_()
+                buf[r * share:(r + 1) * share].fill_(r + 1)
+                timed("all_gather", lambda: self._allgather_shares_(buf, share))
+                if not all(all_equal(buf[q * share:(q + 1) * share], float(q + 1)) for q in range(w)):
+                    out["failed"].append("all_gather")
+        finally:
+            self.sharded = was
+        flags = [1 if (k % w) == r else 0 for k in range(len(sizes))]
+        if self.cuda and not self.staged:
+            g = _flags_on_device(flags, a.device)
+            if self.native is not None:
+                self.native.allreduce_(g, op_max=True)
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.MAX, group=self.pg)
+        else:
+            g = torch.tensor(flags, dtype=torch.int32)
+            dist.all_reduce(g, op=dist.ReduceOp.MAX, group=self.pg)
+        sync()
+        if int(g.min()) != 1 and len(sizes) >= w:
+            out["failed"].append("flag_max")
+        p32 = a.params.float()
+        cdev = a.device if (self.cuda and not self.staged) else torch.device("cpu")
+        chk = torch.stack([p32.sum().double(), p32.abs().sum().double()]).to(cdev)
+        allc = [torch.zeros_like(chk) for _ in range(w)]
+        dist.all_gather(allc, chk, group=self.pg)
+        if not all(bool(torch.equal(c, allc[0])) for c in allc):
+            out["failed"].append("replica_checksum")
+        del p32
+        a.grads.zero_()
+        sync()
+        # every rank must reach the same verdict: a leg that failed anywhere failed
+        bad = torch.tensor([len(out["failed"])], dtype=torch.int32, device=a.device if (self.cuda and not self.staged) else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.pg)
+        out["ok"] = int(bad.item()) == 0
+        return out
+
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
@@ -435,6 +535,10 @@ class BackwardOverlap:
         self._done: List[bool] = []
         self.grad_scale = engine.grad_scale if engine is not None else 1.0
         self.thin_blocks = 256  # optimizer launches of one block per CU so that they co-reside with the GEMM workgroups
+        # measure_tail (eager steps only - captured events carry no timestamps): HIP-event pairs around the wait for the side stream at the end of every
+        # step = how long the compute stream sat idle behind the last backward kernel waiting for [exchange ->] AdamW -> shadow refresh of the last buckets
+        self.measure_tail = False
+        self.tail_events: List[tuple] = []
 
     def begin_step(self):
         self.opt.begin_step()
@@ -466,6 +570,11 @@ class BackwardOverlap:
                 if self.engine.sharded:            # RS_i, flag_i, [AdamW on this rank's share], AG_i: the same sequence on every rank (exchange_bucket_flag_)
                     gate, written_only = self.engine.exchange_bucket_flag_(i, True), False
             self._step_or_defer(i, gate, written_only)
+
+    def exposed_tail_ms(self, last: int = 0):
+        """mean over the recorded steps (the last `last` of them; 0 = all) of the exposed tail; the events must have completed (synchronize first)"""
+        ev = self.tail_events[-last:] if last else self.tail_events
+        return None if not ev else sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
     def _step_or_defer(self, i, gate, written_only):
         """on the side stream, behind bucket i's reduction: AdamW + shadow refresh - or, with clipping, its share of the gradient norm"""
@@ -543,6 +652,13 @@ class BackwardOverlap:
                     self._done[i] = True
         self._flush_clipped()
         self.arena.join_streams()
-        torch.cuda.current_stream().wait_stream(self.side)
+        if self.measure_tail:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda.current_stream().wait_stream(self.side)
+            e1.record()
+            self.tail_events.append((e0, e1))
+        else:
+            torch.cuda.current_stream().wait_stream(self.side)
         self.opt.end_step()
         self.arena.on_bucket_ready = self.engine._on_bucket_ready if self.engine is not None else None

@@ -149,21 +149,26 @@ def logits(model, input_ids, input_features=None, input_features_mask=None, atte
 
 
 @torch.no_grad()
-def greedy_generate(model, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20, eos_token_id=None):
-    """greedy search without a cache (GenerationMixin with use_cache=False): re-run the prefix in exact fp32, append the argmax of the last position"""
+def greedy_generate(model, input_ids, input_features=None, input_features_mask=None, attention_mask=None, max_new_tokens=20, eos_token_id=None,
+                    pad_token_id=None):
+    """greedy search without a cache (GenerationMixin with use_cache=False): re-run the prefix in exact fp32, append the argmax of the last position.
+    GenerationMixin semantics for finished rows (generation/utils.py:2730-2830): eos_token_id may be an int or a list; a row is finished once it has
+    emitted ANY of them and emits pad_token_id from then on (the first EOS when no pad id is configured, as modeling.generate does)."""
     dev = model.device_
     ids = input_ids.to(dev)
     att = None if attention_mask is None else attention_mask.to(dev)
+    eos = None if eos_token_id is None else torch.as_tensor(eos_token_id, device=dev, dtype=ids.dtype).reshape(-1)
+    pad = int(pad_token_id) if pad_token_id is not None else (int(eos[0]) if eos is not None else None)
     done = torch.zeros(ids.shape[0], dtype=torch.bool, device=dev)
     for _ in range(int(max_new_tokens)):
         lg = logits(model, ids, input_features, input_features_mask, att)
         nxt = lg[:, -1].argmax(-1)
-        if eos_token_id is not None:
-            nxt = torch.where(done, torch.full_like(nxt, int(eos_token_id)), nxt)
-            done |= nxt == int(eos_token_id)
+        if eos is not None:
+            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+            done |= torch.isin(nxt, eos) & ~done
         ids = torch.cat([ids, nxt[:, None]], 1)
         if att is not None:
             att = torch.cat([att, torch.ones_like(att[:, :1])], 1)
-        if eos_token_id is not None and bool(done.all()):
+        if eos is not None and bool(done.all()):
             break
     return ids

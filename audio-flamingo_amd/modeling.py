@@ -606,7 +606,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         from . import exact as _exact
 
         if _exact.ENABLED and labels is None and inputs_embeds is None and past_key_values is None and not torch.is_grad_enabled():
-            # AFK_EXACT_FP32=1 (verification mode, exact.py): the inference forward in exact fp32 on the afk_x32_* kernels - fp32 logits, no KV cache
+            # AFK_EXACT_FP32=1 (verification mode, exact.py): the inference forward in exact fp32 on the afk_x32_* kernels - fp32 logits, no KV cache.
+            # What the mode does not implement is refused, never silently dropped
+            if position_ids is not None or use_cache or logits_to_keep not in (0, None):
+                raise AfkError("AFK_EXACT_FP32=1: the exact-fp32 verification forward takes no position_ids / use_cache / logits_to_keep "
+                               "(positions are cumsum(attention_mask) - 1, every row's logits are returned, there is no KV cache); unset AFK_EXACT_FP32 for those")
             return AF3Output(logits=_exact.logits(self, input_ids, input_features, input_features_mask, attention_mask))
         if past_key_values is not None or use_cache:
             # inference with the reference's cache protocol (modeling_qwen2.py:213-214, 360-364): prefill returns a cache, later calls
@@ -1160,11 +1164,11 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             eos_token_id, pad_token_id = pick(eos_token_id, None, "eos_token_id"), pick(pad_token_id, None, "pad_token_id")
         from . import exact as _exact
 
-        if _exact.ENABLED and not do_sample and num_beams == 1 and not hooks and type(self).__name__ == "AudioFlamingo3ForConditionalGeneration":
-            # AFK_EXACT_FP32=1: greedy decoding by exact-fp32 recomputation of the prefix (exact.py) - the reference's greedy ids with no "confident rows" filter
-            return _exact.greedy_generate(self, input_ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id)
         if int(max_new_tokens) <= 0:   # GenerationMixin refuses it as well (generation/configuration_utils.py validate())
             raise ValueError(f"`max_new_tokens` must be greater than 0, but is {max_new_tokens}.")
+        if _exact.ENABLED and not do_sample and num_beams == 1 and not hooks and type(self).__name__ == "AudioFlamingo3ForConditionalGeneration":
+            # AFK_EXACT_FP32=1: greedy decoding by exact-fp32 recomputation of the prefix (exact.py) - the reference's greedy ids with no "confident rows" filter
+            return _exact.greedy_generate(self, input_ids, input_features, input_features_mask, attention_mask, max_new_tokens, eos_token_id, pad_token_id)
         if num_beams > 1 and (do_sample or not use_cache):
             raise AfkError("generate(num_beams > 1): beam search is deterministic and runs on the KV cache (no do_sample, no use_cache=False)")
         if hooks and (num_beams > 1 or not use_cache):

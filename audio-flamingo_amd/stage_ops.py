@@ -37,10 +37,26 @@ _STATIC = OrderedDict()   # key -> (arena id, static args in forward order)
 _CACHE = OrderedDict()    # key -> {"fwd_meta", "src", "out_spec", "bwd_spec"}
 
 
+_PINNED = set()           # keys a tracer has seen (_fwd_fake / _bwd_fake): a compiled or captured step bakes the key string in as a constant and calls the
+                          # operator implementations directly, never through _Stage.apply() - nothing would re-insert the key after an eviction
+
+
 def _touch(table, key):
     table.move_to_end(key)
-    while len(table) > _TABLE_CAP:
-        table.popitem(last=False)
+    if len(table) > _TABLE_CAP:
+        for k in list(table):
+            if len(table) <= _TABLE_CAP:
+                break
+            if k not in _PINNED:
+                del table[k]
+
+
+def _cache_of(key: str):
+    c = _CACHE.get(key)
+    if c is None:
+        raise RuntimeError(f"afk stage {key[:80]!r}...: what its forward kept for backward was evicted (more than {_TABLE_CAP} distinct stage geometries "
+                           f"between this stage's forward and its backward) or the forward never ran in this process")
+    return c
 
 _STAGES = {}   # stage name -> _Stage
 _UID = [0]
@@ -62,6 +78,7 @@ def _purge(uid: int):
     for table in (_STATIC, _CACHE):
         for k in [k for k in table if tag in k[: k.index("|", k.index("|") + 1) + 1]]:
             table.pop(k, None)
+            _PINNED.discard(k)
 
 
 class _Ctx:
@@ -193,6 +210,7 @@ class _Stage:
         c = _CACHE.get(key)
         if c is None:
             raise RuntimeError(f"afk::{self.name}: run the step eagerly once before tracing it (output shapes are recorded per stage geometry)")
+        _PINNED.add(key)   # traced: the compiled step will call _fwd_impl / _bwd_impl with this very string for as long as it lives
         return [params.new_empty(shape, dtype=dtype) for shape, dtype in c["out_spec"]]
 
     # ------------------------------------------------------------------ autograd registration
@@ -219,7 +237,7 @@ class _Stage:
         tens = [next(it) if p else None for p in ctx.in_present]
         outs = [None] + list(it)                       # outs[i] for i >= 1: the activations the forward operator returned
         saved = []
-        for kind, i in _CACHE[key]["src"]:
+        for kind, i in _cache_of(key)["src"]:
             t = tens[i] if kind == "in" else outs[i] if kind == "out" else None
             saved.append(_placeholder(g) if t is None else t)
         res = self.op_bwd(g.contiguous(), saved, params, grads, key)
@@ -229,7 +247,7 @@ class _Stage:
     # ------------------------------------------------------------------ backward operator
     def _bwd_impl(self, g, saved, params, grads, key):
         arena, static = _arena_of(key)
-        c = _CACHE[key]
+        c = _cache_of(key)
         _touch(_CACHE, key)
         ctx = _Ctx()
         ctx.saved_tensors = tuple(None if kind == "none" else t for (kind, _), t in zip(c["src"], saved))
@@ -251,6 +269,7 @@ class _Stage:
         c = _CACHE.get(key, {})
         if "bwd_spec" not in c:
             raise RuntimeError(f"afk::{self.name}_bwd: run one eager forward + backward before tracing the step")
+        _PINNED.add(key)
         return tuple(g.new_empty(shape, dtype=dtype) for shape, dtype in c["bwd_spec"])
 
 

@@ -447,8 +447,12 @@ def compact_line(res, detail_path=None):
         out["decode_ms_per_token_steady"] = {b: _r(dec[b]["decode_ms_per_token_steady"], 3) for b in ("B1", "B8") if b in dec}
     dp = res.get("dp")
     if isinstance(dp, dict):
-        out["dp"] = {k: _r(dp[k], 2) for k in ("backend", "comm", "form", "chosen", "probe_ms", "preflight", "exposed_comm_ms", "buckets", "fallback",
-                                               "launched_by") if k in dp}
+        out["dp"] = {k: _r(dp[k], 2) for k in ("backend", "comm", "form", "chosen", "probe_ms", "exposed_comm_ms", "buckets", "launched_by") if k in dp}
+        if isinstance(dp.get("preflight"), dict):
+            out["dp"]["preflight"] = {k: _pick(v, ("ok", "failed", "allreduce_ms", "allreduce_busbw_gbs", "reduce_scatter_ms", "all_gather_ms", "skipped"), 2)
+                                      for k, v in dp["preflight"].items()}
+        if dp.get("fallback"):
+            out["dp"]["fallback"] = [str(x)[:120] for x in dp["fallback"]][:3]
         out["replicas_identical_after_steps"] = res.get("replicas_identical_after_steps")
     for k in ("param_checksum", "rank_losses", "rccl_ranks", "stream_priorities"):    # tests/test_dp_gpu.py compares schedules on these
         if res.get(k) is not None:
@@ -506,6 +510,8 @@ def dry_run_cpu(args):
     arena = model.arena
     engine = DataParallelEngine(arena, overlap=True)
     engine.broadcast_parameters(0)
+    pf = engine.preflight()     # the known-answer round of every collective, as the real N > 1 run does before its first step
+    assert pf["ok"], pf
     t0 = time.perf_counter()
     for k in range(args.warmup + args.steps):
         arena.zero_grad()
@@ -533,7 +539,8 @@ def dry_run_cpu(args):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": "bf16", "data": "synthetic", "config": {"workload": "CONTROL-FLOW DRY RUN on the host (gloo): no kernels ran, nothing was measured"},
                           "replicas_identical_after_steps": identical, "collective_backend": "gloo", "buckets": len(arena.bucket_names),
-                          "collectives_per_step": len(engine.issued) + 1, "launched_by": os.environ.get("AFK_BENCH_LAUNCHED_BY", "external")}), flush=True)
+                          "collectives_per_step": len(engine.issued) + 1, "launched_by": os.environ.get("AFK_BENCH_LAUNCHED_BY", "external"),
+                          "dp": {"backend": "gloo", "preflight": {"torch": pf}}}), flush=True)
 
 
 def self_spawn(n):
@@ -623,6 +630,9 @@ def main():
     ap.add_argument("--cu-contention", default="", help="pre-flight of the multi-GPU run (VERDICT r03 item 5a): comma-separated CU counts, e.g. 0,8,16,32,64 - "
                     "for each, park that many persistent workgroups on a side stream (afk_cu_hog: what RCCL's channel kernels do to the GEMM rounds) and time "
                     "5 steps beside them; reported as cu_contention {n: ms_per_step}")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the communicator pre-flight (known-answer all-reduce / reduce-scatter / all-gather on a layer bucket)")
+    ap.add_argument("--no-dp-probe", action="store_true", help="N > 1: skip the startup probe that times the exchange forms (c10d all-reduce, native reduce-scatter + "
+                    "all-gather, sharded optimizer) and run the first usable one; AFK_DP_COMM / AFK_DP_FORM set explicitly have the same effect")
     ap.add_argument("--no-settle", action="store_true", help="do not wait for the driver to release a previous process's VRAM (tests)")
     ap.add_argument("--detail-name", default="bench_detail.json", help="file under gpurun_out/ that receives the FULL record (every leg, every note); the "
                     "stdout line is the <= 4 KB summary of it")
@@ -689,18 +699,76 @@ def main():
     model.check_placeholders = False  # the count assertion is a host sync; shapes are static in this benchmark
     if ckpt:   # --workload long5min: AFK_CKPT_POLICY picks the plan (default "full" = the reference's every-layer recompute; "budget" = memory-budgeted)
         model.gradient_checkpointing_enable()
-    engine = None
-    if use_dp:
-        engine = DataParallelEngine(model.arena, overlap=not args.no_overlap)
-        engine.force_collectives = engine.force_collectives or args.force_dp
-        engine.broadcast_parameters(0)
-    # AFK_DP_FORM=rs_adamw_ag: the optimizer sharded over the ranks (arena.ShardedAdamW: reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather
-    # of the bf16 parameters); otherwise the replicated FusedAdamW
+    engine = opt = overlap = None
     opt_kw = dict(lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
-    opt = engine.make_optimizer(**opt_kw) if engine is not None else FusedAdamW(model.arena, **opt_kw)
-    if args.clip > 0:
-        opt.clip_norm = args.clip  # norm in one pass over the gradient arena, coefficient applied inside the AdamW launches
-    opt.sync_master()
+    dp_info = {"launched_by": os.environ.get("AFK_BENCH_LAUNCHED_BY", "external")}
+
+    def configure_dp(kind, form):
+        """(re)build the exchange engine + the optimizer that matches its form + the in-backward overlap driver.  kind: "torch" (c10d -> RCCL) | "native"
+        (libafk.so's own communicator); form: "allreduce" | "rs_ag" (replicated AdamW) | "rs_adamw_ag" (optimizer sharded over the ranks)."""
+        nonlocal engine, opt, overlap
+        engine = opt = overlap = None
+        import gc as _gc
+
+        _gc.collect()
+        torch.cuda.empty_cache()
+        engine = DataParallelEngine(model.arena, overlap=not args.no_overlap, comm=kind, form=form)
+        engine.force_collectives = engine.force_collectives or args.force_dp
+        opt = engine.make_optimizer(**opt_kw)
+        if args.clip > 0:
+            opt.clip_norm = args.clip
+        opt.sync_master()
+        overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
+        if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
+            overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
+
+    if use_dp:
+        # N > 1 (VERDICT r05 item 2): an explicit AFK_DP_COMM / AFK_DP_FORM is honoured as given; otherwise pre-flight the communicators (native first, the
+        # c10d one as the fallback) and let a short startup probe pick the exchange form (below, once the step exists)
+        env_kind, env_form = os.environ.get("AFK_DP_COMM"), os.environ.get("AFK_DP_FORM")
+        staged = args.backend != "nccl"
+        kinds = [env_kind] if env_kind else (["torch"] if staged else ["native", "torch"])
+        dp_info["preflight"], dp_info["fallback"] = {}, []
+        usable = []
+        for kind in kinds:
+            try:
+                configure_dp(kind, env_form or ("rs_ag" if kind == "native" else "allreduce"))
+                if not usable:
+                    engine.broadcast_parameters(0)
+                    opt.sync_master()
+                pf = engine.preflight() if not args.no_preflight else {"ok": True, "skipped": True}
+                dp_info["preflight"][kind] = pf
+                if pf["ok"]:
+                    usable.append(kind)
+                else:
+                    dp_info["fallback"].append(f"{kind}: pre-flight failed {pf['failed']}")
+            except Exception as e:   # a communicator that cannot even be created / used: named, and the next one is tried
+                dp_info["fallback"].append(f"{kind}: {type(e).__name__}: {str(e)[:160]}")
+        if not usable:
+            raise RuntimeError(f"no usable data-parallel communicator: {dp_info['fallback']}")
+        dp_info["usable_comms"] = usable
+        if rank == 0:
+            print(f"[bench] dp pre-flight: {json.dumps(dp_info['preflight'])} fallback={dp_info['fallback']}", file=sys.stderr, flush=True)
+        # candidates of the startup probe: (kind, form); the first one is the fallback of last resort (c10d all-reduce: the most travelled RCCL path)
+        if env_form or env_kind or args.no_dp_probe:
+            k0 = env_kind or usable[-1]
+            cands = [(k0, env_form or ("rs_ag" if k0 == "native" else "allreduce"))]
+        else:
+            cands = [("torch", "allreduce")] if "torch" in usable else []
+            if "native" in usable:
+                cands += [("native", "rs_ag"), ("native", "rs_adamw_ag")]
+            elif "torch" in usable:
+                cands += [("torch", "rs_adamw_ag")]
+        configure_dp(*cands[0])
+    else:
+        cands = []
+        opt = FusedAdamW(model.arena, **opt_kw)
+        if args.clip > 0:
+            opt.clip_norm = args.clip  # norm in one pass over the gradient arena, coefficient applied inside the AdamW launches
+        opt.sync_master()
+        overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, None)
+        if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
+            overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
     from audio_flamingo_amd import functional as F_
     model.arena.lazy_T_shadows = F_.BWD_FORM == "direct"
     model.arena.refresh_shadows(force=True)
@@ -723,10 +791,6 @@ def main():
     pool = [synthetic_batch(args.batch, (rank + k * world) * args.batch, dev, windows) for k in range(nb)]
     waves, ids, labels = (t.clone() for t in pool[0])
     model.label_rows_static = True   # the labelled POSITIONS are the same in every synthetic batch; only the token values change
-
-    overlap = None if args.no_opt_overlap else BackwardOverlap(model.arena, opt, engine)
-    if overlap is not None and os.environ.get("AFK_THIN_BLOCKS"):
-        overlap.thin_blocks = int(os.environ["AFK_THIN_BLOCKS"])
 
     data = {"waves": waves, "ids": ids, "labels": labels}
     hbm_probe = {}   # {"events": (start, end)} while the serial profiling step runs: HIP events around its one full-width AdamW launch set
@@ -775,6 +839,44 @@ def main():
     use_graph = (not args.no_graph) and (not use_dp or args.dp_graph) and overlap is not None and not ckpt
     load_next()
     first_loss = float(step().detach())  # ~ ln(152064) = 11.9 for random-init weights: the line checks itself (the last loss is lower)
+    if use_dp and len(cands) > 1:
+        # startup probe: 1 warm-up + 2 timed eager steps per candidate, max over the ranks; the fastest form runs the benchmark.
+        # Every rank sees the same (all-reduced) times, so every rank picks the same candidate.  A candidate that raises is dropped - on every rank
+        # (the verdict is exchanged) - and the probe goes on; the real steps it costs train the replicas like any other step.
+        probe = {}
+        for kind, form in cands:
+            name = f"{kind}:{form}"
+            ok_here = 1
+            try:
+                if (kind, form) != cands[0] or engine is None:
+                    configure_dp(kind, form)
+                load_next()
+                step()
+                fence()
+                t_p = time.perf_counter()
+                for _ in range(2):
+                    load_next()
+                    step()
+                fence()
+                ms_p = 1e3 * (time.perf_counter() - t_p) / 2
+            except Exception as e:
+                ok_here, ms_p = 0, 1e9
+                dp_info["fallback"].append(f"probe {name}: {type(e).__name__}: {str(e)[:160]}")
+            tt = torch.tensor([ms_p, float(1 - ok_here)], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            if float(tt[1]) == 0.0:
+                probe[name] = round(float(tt[0]), 2)
+        assert probe, f"every exchange form failed its probe: {dp_info['fallback']}"
+        best = min(probe, key=probe.get)
+        dp_info["probe_ms"], dp_info["chosen"] = probe, best
+        if rank == 0:
+            print(f"[bench] dp form probe (ms/step, max over ranks): {probe} -> {best}", file=sys.stderr, flush=True)
+        bk, bf = best.split(":")
+        configure_dp(bk, bf)   # fresh optimizer state for the chosen form (the probe's steps trained the replicas like any other step)
+    elif use_dp:
+        dp_info["chosen"] = f"{cands[0][0]}:{cands[0][1]}"
+    if overlap is not None and not use_graph and use_dp:
+        overlap.measure_tail = True
     run = step
     if use_graph:
         from audio_flamingo_amd.graphs import GraphedTrainStep
@@ -794,6 +896,14 @@ def main():
     host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (no sync inside; includes queue back-pressure once the GPU lags)
     fence()
     dt = time.perf_counter() - t0
+    if overlap is not None and overlap.measure_tail:
+        tail = overlap.exposed_tail_ms(last=args.steps)   # compute stream idle behind the last backward kernel: [exchange ->] AdamW -> shadows of the last buckets
+        if use_dp:
+            tt = torch.tensor([tail or 0.0], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tail = float(tt.item())
+        dp_info["exposed_comm_ms"] = None if tail is None else round(tail, 2)
+        overlap.measure_tail = False
     # the same WITHOUT back-pressure: one more (untimed) step enqueued onto an idle GPU - what the host really needs per step
     t1 = time.perf_counter()
     load_next()
@@ -1005,7 +1115,7 @@ def main():
                                                                       "side": getattr(getattr(overlap, "side", None), "afk_priority", None)},
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
             "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb, "label_rows_static": bool(model.label_rows_static),
-            "dp": None if engine is None else {"backend": args.backend, "comm": engine.comm_kind,
+            "dp": None if engine is None else {**dp_info, "backend": args.backend, "comm": engine.comm_kind if engine.native is not None else "torch",
                                                "form": engine.form if (engine.native is not None or engine.sharded) else "allreduce",
                                                "optimizer": ("sharded over the ranks (reduce-scatter -> AdamW on 1 / world of every bucket -> all-gather of the bf16 parameters)"
                                                              if engine.sharded else "replicated"),
@@ -1015,11 +1125,7 @@ def main():
                                                "bucket_bytes_total": 2 * model.arena.total, "overlapped_with_backward": overlap is not None or engine.overlap,
                                                "collectives_per_step": len(model.arena.bucket_names) + 1,
                                                "rccl_channel_env": {k: os.environ.get(k) for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS", "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None},
-                                               "why_these_defaults": "one c10d all_reduce per layer bucket (466 MB): RCCL itself spreads a large all-reduce over the rings of "
-                                                   "all seven xGMI links - the native reduce-scatter + all-gather form (AFK_DP_COMM=native) moves the same bytes in two launches and "
-                                                   "stays opt-in until a multi-GPU box has timed both; eager enqueue (RCCL inside the captured HIP graph is validated at world 1 only: "
-                                                   "--dp-graph); no RCCL channel cap: parking 32 / 64 persistent workgroups on as many CUs beside this step costs 0 ms "
-                                                   "(profiles/r04_cu_contention.json: the step is power-limited, not CU-limited). No scaling curve has been measured."},
+                                               },
             "long_audio_configs4": long_audio, "long_audio_10min": long_10min, "decode": decode, "cu_contention_ms_per_step": cu_contention,
             "peak_mem_gib": round(peak_mem, 1), "host_enqueue_ms_per_step": round(1000.0 * host_enqueue / args.steps, 1),
             "host_enqueue_ms_idle_gpu": round(1000.0 * host_enqueue_idle, 1),

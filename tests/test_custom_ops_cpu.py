@@ -147,3 +147,27 @@ def test_stage_operator_plumbing_with_a_toy_stage():
     out = compiled(x3, b3)
     out.backward()
     assert torch.allclose(out, eager) and torch.allclose(x3.grad, g_eager, atol=1e-6) and torch.allclose(a3.gw, gw_eager, atol=1e-6)
+    # a traced step bakes its stage keys in as constants and never goes through _Stage.apply() again - traced keys are pinned, so the LRU cap of
+    # the side tables evicts only untraced geometries, and the compiled step still runs after more than _TABLE_CAP other geometries have passed through
+    traced = [k for k in stage_ops._PINNED if k.startswith(name + "|")]
+    assert traced and all(k in stage_ops._CACHE and k in stage_ops._STATIC for k in traced)
+    cap = stage_ops._TABLE_CAP
+    try:
+        stage_ops._TABLE_CAP = len(stage_ops._STATIC) + 2
+        for n in range(6, 14):   # eight more geometries: more than the cap leaves room for
+            with torch.no_grad():
+                ToyFn.apply(torch.randn(n, 3), anchor, a3, 2.0, None)
+        assert len(stage_ops._STATIC) <= stage_ops._TABLE_CAP + len(stage_ops._PINNED)
+        assert all(k in stage_ops._CACHE and k in stage_ops._STATIC for k in traced)
+        x3.grad = None
+        a3.grads.zero_()
+        out2 = compiled(x3, b3)
+        out2.backward()
+        assert torch.allclose(out2, eager) and torch.allclose(x3.grad, g_eager, atol=1e-6)
+    finally:
+        stage_ops._TABLE_CAP = cap
+    # and an evicted (never traced) key fails with the explicit message, not a bare KeyError
+    import pytest as _pt
+
+    with _pt.raises(RuntimeError, match="evicted"):
+        stage_ops._cache_of("no_such_stage|0|()|()|g0")
