@@ -6,7 +6,8 @@ and beside the one-per-CU 256 x 256 wgrad workgroups its kernels ran 2.5-7 x slo
 dispatcher hands a CU that frees up to the compute queue first; the wgrad GEMMs take what is left.  torch.cuda.Stream only reaches "normal" and
 "high", so the handles come from libafk (afk_stream_create: the device's whole range) and are wrapped with torch.cuda.ExternalStream.
 
-AFK_STREAM_PRIORITIES=0 turns it off (every role at the default priority: the round-5 schedule).
+AFK_STREAM_PRIORITIES:  "hl" (default) compute at the highest, wgrad / side at the lowest priority;  "h0" compute highest, the others at the default;
+"0l" compute at the default, the others lowest;  "0" off (every role a plain torch stream at the default priority: the round-5 schedule).
 """
 from __future__ import annotations
 
@@ -17,12 +18,21 @@ import torch
 
 from . import _lib
 
-_ROLE_PRIORITY = {"compute": "greatest", "wgrad": "least", "side": "least"}
+_MODES = {"hl": {"compute": "greatest", "wgrad": "least", "side": "least"}, "h0": {"compute": "greatest", "wgrad": "default", "side": "default"},
+          "0l": {"compute": "default", "wgrad": "least", "side": "least"}}
 _keep = []   # ExternalStream does not own its handle: the handles live as long as the process
 
 
+def mode() -> str:
+    m = os.environ.get("AFK_STREAM_PRIORITIES", "hl")
+    m = "hl" if m == "1" else m
+    if m != "0" and m not in _MODES:
+        raise _lib.AfkError(f"AFK_STREAM_PRIORITIES={m!r}: one of 0, 1, {', '.join(_MODES)}")
+    return m
+
+
 def enabled() -> bool:
-    return os.environ.get("AFK_STREAM_PRIORITIES", "1") != "0"
+    return mode() != "0"
 
 
 def priority_range():
@@ -35,13 +45,14 @@ def priority_range():
 def make_stream(device, role: str) -> torch.cuda.Stream:
     """a stream for `role` ("compute" | "wgrad" | "side") on `device`; plain torch.cuda.Stream when priorities are off"""
     device = torch.device(device)
-    if role not in _ROLE_PRIORITY:
+    if role not in _MODES["hl"]:
         raise _lib.AfkError(f"make_stream: unknown role {role!r}")
     if not enabled():
         return torch.cuda.Stream(device=device)
     with torch.cuda.device(device):
         least, greatest = priority_range()
-        prio = least if _ROLE_PRIORITY[role] == "least" else greatest
+        want = _MODES[mode()][role]
+        prio = least if want == "least" else greatest if want == "greatest" else 0
         h = ctypes.c_void_p(0)
         _lib.call("afk_stream_create", prio, ctypes.byref(h))
     s = torch.cuda.ExternalStream(h.value, device=device)
