@@ -485,6 +485,40 @@ def write_detail(res, name="bench_detail.json"):
         return None
 
 
+def mfma_power_ceiling(dev, seconds=1.2):
+    """what the matrix pipe sustains on THIS chip under its power cap when nothing but MFMAs run (csrc/ceiling.hip mode 0: v_mfma_f32_32x32x16_bf16 on
+    N(0,1) operands resident in registers, 256 workgroups x 8 waves, no LDS / global access in the loop): 0.3 s ramp + `seconds` timed with HIP events.
+    The datasheet 2.5 PFLOP/s assumes 2.4 GHz; at the 1.4 kW cap this loop runs at ~1.83 GHz (profiles/r06_mfma_power_ceiling.json)."""
+    import ctypes
+
+    from audio_flamingo_amd import _lib
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    src = torch.randn(1 << 20, device=dev, generator=g).to(torch.bfloat16)
+    sink = torch.zeros(4, device=dev)
+    fl = ctypes.c_double(0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        _lib.call("afk_mfma_ceiling", 0, 256, 20000, src.data_ptr(), sink.data_ptr(), ctypes.byref(fl), st)
+
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.3:
+        go()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n, t0 = 0, time.perf_counter()
+    e0.record()
+    while time.perf_counter() - t0 < seconds:
+        go()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.current_stream().synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    return fl.value * n / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
 def dry_run_cpu(args):
     """CONTROL-FLOW TEST ONLY - no GPU, no kernel, no throughput (value = null).  Runs the N > 1 sequence of main() over gloo on the host:
     process group -> replica = the real model class on the CPU (layout / arena / buckets only) -> DataParallelEngine + parameter broadcast ->
@@ -1156,6 +1190,14 @@ def main():
                                   "disabled (launches back to back)" if had_side else "HIP events around every GEMM launch, timed region")
                                  + "; the gate|up launches carry the fused SwiGLU forward: its elementwise work counts as GEMM time, not as flops"},
         }
+        if world == 1 and full_model and not args.no_extra_legs:
+            # the measured ceiling the GEMM is held against: pure-MFMA rate of this chip under its power cap, live, beside `frac`
+            try:
+                ceil_tf = mfma_power_ceiling(dev)
+                res["roofline"]["power_ceiling_tflops"] = ceil_tf
+                res["roofline"]["frac_of_power_ceiling"] = achieved_tf / ceil_tf
+            except Exception as e:
+                res["roofline"]["power_ceiling_error"] = repr(e)[:200]
         want_eager = not args.no_eager_baseline and world == 1 and args.workload == "clip30"
         want_icl = not args.no_extra_legs and world == 1 and args.workload == "clip30" and full_model
         want_parity = not args.no_parity and world == 1 and args.workload == "clip30" and full_model and args.batch == 8

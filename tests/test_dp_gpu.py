@@ -302,7 +302,7 @@ def _bench(extra, nproc=1, timeout=900, env_extra=None):
     cmd = [sys.executable]
     if nproc > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + _BENCH_TINY + extra
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--detail-name", "bench_detail_from_tests.json"] + _BENCH_TINY + extra   # never the driver run's record
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=str(_free_port()), TORCH_SHOW_CPP_STACKTRACES="1")
     env.pop("AFK_DP_FORM", None)
     env.update(env_extra or {})
