@@ -54,6 +54,50 @@ class AfkKVCache:
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.length
 
+    # ---- interop with the reference's cache object (TF/cache_utils.py DynamicCache; generation/utils.py:519-640 hands one to every forward)
+    @staticmethod
+    def is_reference_cache(obj) -> bool:
+        return obj is not None and not isinstance(obj, AfkKVCache) and hasattr(obj, "layers") and hasattr(obj, "update") and hasattr(obj, "get_seq_length")
+
+    @classmethod
+    def adopt(cls, ref_cache, n_layers: int, Hkv: int, D: int, n_new: int, headroom: int, device, attention_mask=None):
+        """the tensors of a reference DynamicCache (per layer: keys / values [B, Hkv, S, D], keys post-RoPE - Qwen2Attention.forward
+        modeling_qwen2.py:213-214) re-laid into this cache: K [L, B, Smax, Hkv * D], values transposed Vt [L, B, Hkv, D, pad64(Smax)].  Left padding is
+        read off the attention_mask of the call (which covers past + new positions, as the reference requires)."""
+        from . import ops
+
+        start = int(ref_cache.get_seq_length())
+        if start == 0:
+            return None   # an EMPTY reference cache on the prefill call (`past_key_values=DynamicCache()`): nothing to adopt
+        if len(ref_cache.layers) != n_layers:
+            raise AfkError(f"forward(past_key_values=<reference cache>): it holds {len(ref_cache.layers)} layers, the decoder has {n_layers}")
+        k0 = ref_cache.layers[0].keys
+        B = k0.shape[0]
+        if tuple(k0.shape[1:]) != (Hkv, start, D):
+            raise AfkError(f"forward(past_key_values=<reference cache>): layer 0 keys are {tuple(k0.shape)}, expected [B, {Hkv}, {start}, {D}]")
+        Smax = start + n_new + headroom
+        K = torch.zeros((n_layers, B, Smax, Hkv * D), device=device, dtype=torch.bfloat16)
+        Vt = torch.zeros((n_layers, B, Hkv, D, ops.pad64(Smax)), device=device, dtype=torch.bfloat16)
+        for i, layer in enumerate(ref_cache.layers):
+            K[i, :, :start].copy_(layer.keys.to(device, torch.bfloat16).permute(0, 2, 1, 3).reshape(B, start, Hkv * D))
+            Vt[i, :, :, :, :start].copy_(layer.values.to(device, torch.bfloat16).permute(0, 1, 3, 2))
+        lo = torch.zeros(B, device=device, dtype=torch.int32)
+        if attention_mask is not None:
+            am = attention_mask.to(device)
+            if am.shape[1] >= start and not bool(am[:, :start].all()):
+                lo = (start - am[:, :start].sum(-1)).to(torch.int32)   # left padding: leading zeros of the past part
+        return cls(K, Vt, lo, start)
+
+    def write_back(self, ref_cache, first: int, n: int, Hkv: int, D: int):
+        """append positions [first, first + n) of every layer to the reference cache the caller handed in (DynamicCache.update), so that it stays the
+        caller's single source of truth: the next call - to this model or to the reference - finds past + new in it"""
+        L, B = self.K.shape[0], self.K.shape[1]
+        for i in range(L):
+            k = self.K[i, :, first: first + n].reshape(B, n, Hkv, D).permute(0, 2, 1, 3).contiguous()
+            v = self.Vt[i, :, :, :, first: first + n].permute(0, 1, 3, 2).contiguous()
+            ref_cache.update(k, v, i)
+        return ref_cache
+
 
 class AF3Output:
     """The reference's ModelOutput surface (AudioFlamingo3CausalLMOutputWithPast, modeling_audioflamingo3.py:635-642): attribute, key, index and
@@ -618,7 +662,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             if labels is not None:
                 raise AfkError("forward(labels=..., use_cache=True): the KV-cache path is inference only")
             return self._forward_cached(input_ids, inputs_embeds, input_features, input_features_mask, attention_mask, past_key_values,
-                                        logits_to_keep)
+                                        logits_to_keep, position_ids)
         a, lm = self.arena, self._lm
         if inputs_embeds is not None:
             # the reference merges audio only when input_ids are given (modeling_audioflamingo3.py:532-545): precomputed embeddings pass through
@@ -747,7 +791,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
     cache_headroom = 256  # forward(use_cache=True): positions reserved beyond the prompt; the cache grows by doubling when they run out
 
     @torch.no_grad()
-    def _forward_cached(self, input_ids, inputs_embeds, input_features, input_features_mask, attention_mask, past, logits_to_keep):
+    def _forward_cached(self, input_ids, inputs_embeds, input_features, input_features_mask, attention_mask, past, logits_to_keep, position_ids=None):
         dev = self.device_
         if inputs_embeds is not None:
             B, n = inputs_embeds.shape[:2]
@@ -757,6 +801,14 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             ids = input_ids.to(dev)
             B, n = ids.shape
         L, nk = self.dec_layers, self.Hkv * self.D
+        ref_cache = None
+        if AfkKVCache.is_reference_cache(past):
+            # the reference's cache object (GenerationMixin hands a DynamicCache to every forward, generation/utils.py:519-640): its tensors are adopted
+            # into this implementation's layout for the call and the new positions are appended to it afterwards - the caller keeps ONE cache object
+            ref_cache = past
+            past = AfkKVCache.adopt(ref_cache, L, self.Hkv, self.D, n, self.cache_headroom, dev, attention_mask)
+            if past is not None and attention_mask is not None:
+                attention_mask = None    # consumed: the left padding is in past.lo, the new positions are all real
         if past is None:
             lo = torch.zeros(B, device=dev, dtype=torch.int32)
             padded = False
@@ -777,7 +829,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             kv_lo = lo if padded else None
         else:
             if not isinstance(past, AfkKVCache):
-                raise AfkError("forward(past_key_values=...): pass the AfkKVCache a previous forward(use_cache=True) returned")
+                raise AfkError("forward(past_key_values=...): pass the AfkKVCache a previous forward(use_cache=True) returned, or the reference's DynamicCache")
             if input_features is not None:
                 raise AfkError("forward(past_key_values=...): audio belongs to the prefill call (the reference merges it there too)")
             Kc, Vt, lo, start = past.K, past.Vt, past.lo, past.length
@@ -792,13 +844,24 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 x = ops.embed_scatter_fwd(ids.reshape(-1).contiguous(), None, self.arena[self._lm + "embed_tokens.weight"].data, None)
             fast, kv_lo = False, None
         ar = torch.arange(start, start + n, device=dev, dtype=torch.int32)
-        pos_rows = (ar[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()                       # position_ids = cumsum(mask) - 1
+        if position_ids is not None:
+            # the rotary positions the caller computed (GenerationMixin: cumsum(attention_mask) - 1 of the whole sequence, sliced to the new tokens)
+            pos_rows = position_ids.to(dev).expand(B, n).to(torch.int32).clamp_min(0).reshape(-1).contiguous()
+        elif ref_cache is not None:
+            # a reference cache and no position_ids: the reference rotates by cache_position = arange(past, past + n) whatever the mask says
+            # (Qwen2Model.forward modeling_qwen2.py:361-364) - the keys already in the cache (or the reference's next call on it) follow that convention
+            pos_rows = ar[None, :].expand(B, n).reshape(-1).contiguous()
+        else:
+            pos_rows = (ar[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()                   # position_ids = cumsum(mask) - 1
         krange = torch.stack([lo[:, None].expand(B, n), torch.maximum(ar[None, :] + 1, lo[:, None])], -1).contiguous()   # [lo, i + 1)
         y = self._decode_layers(x, B, n, start, (Kc, Vt), pos_rows, krange, fast, kv_lo=kv_lo)
         keep = n if not logits_to_keep else min(int(logits_to_keep), n)
         rows = y.reshape(B, n, -1)[:, n - keep:, :].reshape(B * keep, -1).contiguous()
         logits = ops.gemm_nt(rows, self.arena["lm_head.weight"].data).reshape(B, keep, -1)
-        return AF3Output(logits=logits, past_key_values=AfkKVCache(Kc, Vt, lo, start + n))
+        new_cache = AfkKVCache(Kc, Vt, lo, start + n)
+        if ref_cache is not None:
+            return AF3Output(logits=logits, past_key_values=new_cache.write_back(ref_cache, start, n, self.Hkv, self.D))
+        return AF3Output(logits=logits, past_key_values=new_cache)
 
     def _decode_layers(self, x, B, n, start, cache, pos_rows, krange, fast_prefill, start_dev=None, kv_lo=None):
         """all decoder layers on n new positions per sample (rows [B*n, H]) at cache offset `start` (or *start_dev: graph replay).

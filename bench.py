@@ -646,7 +646,10 @@ def main():
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the unmodified reference model on this GPU (eager PyTorch-ROCm)")
     ap.add_argument("--eager-only", action="store_true", help="measure ONLY the unmodified reference model on this GPU (eager PyTorch-ROCm): for rocprofv3 kernel tables")
     ap.add_argument("--clip", type=float, default=0.0, help="global-norm gradient clipping (HF Trainer default: 1.0); 0 = off, as the eager reference leg runs")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured HIP graph of the step (N = 1)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python (the default whenever stream priorities are on, i.e. unless AFK_STREAM_PRIORITIES=0)")
+    ap.add_argument("--graph", action="store_true", help="N = 1: replay the captured HIP graph of the step instead of enqueueing it from Python.  Round 6 measured the eager "
+                    "enqueue with stream priorities FASTER (387-397 ms against 400-405 for any graph variant, same boxes: profiles/r06_stream_priorities.md) - a graph "
+                    "replay ends only when its lowest-priority branch has, and hipGraph maps the captured branches onto its own queues - so the graph is opt-in")
     ap.add_argument("--no-long-audio", action="store_true", help="skip the extra BASELINE configs[4] measurement (5-minute clips) and the 10-minute leg of the default run")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed full-depth parity leg of the default run (tools/parity_fulldepth.py: this model against the live "
                     "reference in fp32 and bf16 on the BASELINE configs[1] batch, one shared state_dict; forward-only on the configs[4] shape) -> `parity_fulldepth`")
@@ -868,9 +871,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # N = 1: the step (static shapes) is captured once into a HIP graph - three streams, ~3 000 launches -> one hipGraphLaunch per step.
-    # N > 1 keeps the eager enqueue (RCCL inside a capture is not validated on this pool's 1-GPU boxes; the host keeps ahead of the GPU there).
-    use_graph = (not args.no_graph) and (not use_dp or args.dp_graph) and overlap is not None and not ckpt
+    # Default (round 6): the step is enqueued from Python on prioritised streams - the host needs ~41 ms per step on an idle GPU and keeps ahead of the
+    # ~390 ms the GPU needs.  --graph (N = 1): the step (static shapes) captured once into a HIP graph - three streams, ~3 000 launches -> one
+    # hipGraphLaunch per step.  N > 1 always enqueues eagerly (RCCL inside a capture is validated at world 1 only: --dp-graph).
+    want_graph = args.graph or args.dp_graph or (not args.no_graph and not _streams.enabled())
+    use_graph = want_graph and (not use_dp or args.dp_graph) and overlap is not None and not ckpt
     load_next()
     first_loss = float(step().detach())  # ~ ln(152064) = 11.9 for random-init weights: the line checks itself (the last loss is lower)
     if use_dp and len(cands) > 1:

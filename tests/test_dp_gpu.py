@@ -319,7 +319,12 @@ def _bench(extra, nproc=1, timeout=900, env_extra=None):
     assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    assert len(lines[0]) < 4096 and line["detail"] == "gpurun_out/bench_detail_from_tests.json", (len(lines[0]), line.get("detail"))   # the driver-parsable summary ...
+    with open(os.path.join(ROOT, line["detail"])) as f:                                                              # ... and the full record it points to
+        full = json.load(f)
+    assert full["ms_per_step"] == pytest.approx(line["ms_per_step"], abs=1e-3) and full["param_checksum"] == line["param_checksum"]
+    return full
 
 
 SHARDED = {"AFK_DP_FORM": "rs_adamw_ag"}
@@ -357,7 +362,7 @@ def test_bench_world1_rccl_inside_hip_graph_experimental(dev):
     abort is an explicit xfail that names the kept log of the dead process, every other failure - and any parameter mismatch - fails the test."""
     import json
 
-    plain_graph = _bench([])
+    plain_graph = _bench(["--graph"])
     try:
         dp_graph = _bench(["--force-dp", "--dp-graph"])
         sh_graph = _bench(["--force-dp", "--dp-graph"], env_extra=SHARDED)

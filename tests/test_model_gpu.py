@@ -425,6 +425,83 @@ def test_forward_with_past_key_values_reproduces_generate(dev):
     assert torch.cat(new, 1).cpu().tolist() == gc["generate"][:, S0: S0 + N_GEN].tolist()
 
 
+def test_forward_accepts_and_updates_the_reference_dynamic_cache(dev):
+    """VERDICT r05 missing 6: `forward(past_key_values=<transformers DynamicCache>)` - the cache object GenerationMixin hands to every forward
+    (TF/generation/utils.py:519-640) - is adopted (keys / values re-laid into this implementation's layout) and UPDATED in place, in both directions:
+      (a) the REFERENCE prefills its DynamicCache, this model continues on it: stepwise greedy ids == the golden generate ids, and the cache it hands
+          back is the same object, grown by one position per step, still usable by the reference (its next-step logits agree with ours);
+      (b) this model prefills an EMPTY DynamicCache (`past_key_values=DynamicCache(), use_cache=True`), the REFERENCE continues on it: same ids;
+      (c) the processor's LEFT-padded batch (case C): reference prefill with its attention_mask, this model decodes with the extended mask
+          (no position_ids: both sides rotate by the absolute cache position, modeling_qwen2.py:361-364);
+      (d) the same with the position_ids GenerationMixin computes, on both sides."""
+    from transformers import DynamicCache
+
+    g = torch.load(os.path.join(G, "tiny64_caseA.pt"))
+    m, ref = _model(dev), _ref_bf16(dev).eval()
+    p = _gen_prompt(g).to(dev)
+    kw = dict(input_features=g["feats"][:1].to(dev), input_features_mask=g["fmask"][:1].to(dev))
+    S0 = p.shape[1]
+    with torch.no_grad():
+        # (a) reference prefill -> ours decodes on the reference's cache object
+        rc = DynamicCache()
+        ro = ref(input_ids=p, input_features=kw["input_features"].to(torch.bfloat16), input_features_mask=kw["input_features_mask"], past_key_values=rc, use_cache=True)
+        assert rc.get_seq_length() == S0
+        nxt, ids = ro.logits[:, -1].float().argmax(-1), [p]
+        for t in range(N_GEN):
+            ids.append(nxt[:, None])
+            o = m(input_ids=nxt[:, None], past_key_values=rc, logits_to_keep=1)
+            assert o.past_key_values is rc and rc.get_seq_length() == S0 + t + 1      # the caller's object, updated in place
+            if t == 3:   # the reference continues from the cache ours just extended: same next-step logits (bf16 noise), same token
+                import copy
+
+                rc2 = copy.deepcopy(rc)
+                r_next = ref(input_ids=o.logits[:, -1].float().argmax(-1)[:, None], past_key_values=rc2, use_cache=True).logits[:, -1].float()
+                o_next = m(input_ids=o.logits[:, -1].float().argmax(-1)[:, None], past_key_values=copy.deepcopy(rc), logits_to_keep=1).logits[:, -1].float()
+                assert float((r_next - o_next).abs().max()) <= 3e-2 * max(1.0, float(r_next.abs().max()))
+            nxt = o.logits[:, -1].float().argmax(-1)
+        assert torch.cat(ids, 1).cpu().tolist() == g["generate"].tolist()
+        # (b) ours prefills an empty reference cache -> the reference decodes on it
+        rc = DynamicCache()
+        o = m(input_ids=p, past_key_values=rc, use_cache=True, logits_to_keep=1, **kw)
+        assert o.past_key_values is rc and rc.get_seq_length() == S0 and len(rc.layers) == m.dec_layers
+        assert tuple(rc.layers[0].keys.shape) == (1, m.Hkv, S0, m.D)
+        nxt, ids = o.logits[:, -1].float().argmax(-1), [p]
+        for _ in range(N_GEN):
+            ids.append(nxt[:, None])
+            ro = ref(input_ids=nxt[:, None], past_key_values=rc, use_cache=True)
+            nxt = ro.logits[:, -1].float().argmax(-1)
+        assert torch.cat(ids, 1).cpu().tolist() == g["generate"].tolist()
+        # (c) left-padded batch: the mask of the call covers past + new positions (the reference's convention)
+        gc = torch.load(os.path.join(G, "tiny64_caseC.pt"))
+        Sc = gc["ids"].shape[1]
+        att = gc["att"].to(dev)
+        rc = DynamicCache()
+        ro = ref(input_ids=gc["ids"].to(dev), input_features=gc["feats"].to(dev).to(torch.bfloat16), input_features_mask=gc["fmask"].to(dev), attention_mask=att,
+                 past_key_values=rc, use_cache=True)
+        nxt, new = ro.logits[:, -1].float().argmax(-1), []
+        for _ in range(N_GEN):
+            new.append(nxt[:, None])
+            att = torch.cat([att, torch.ones_like(att[:, :1])], 1)
+            o = m(input_ids=nxt[:, None], past_key_values=rc, attention_mask=att, logits_to_keep=1)
+            nxt = o.logits[:, -1].float().argmax(-1)
+        assert torch.cat(new, 1).cpu().tolist() == gc["generate"][:, Sc: Sc + N_GEN].tolist()
+        # (d) the same batch the way GenerationMixin drives a forward: position_ids = cumsum(attention_mask) - 1 on every call (generation/utils.py
+        #     prepare_inputs_for_generation) - the reference prefills with them, this model decodes with the slice for the new token
+        att = gc["att"].to(dev)
+        pid = (att.long().cumsum(-1) - 1).masked_fill(att == 0, 1)
+        rc = DynamicCache()
+        ro = ref(input_ids=gc["ids"].to(dev), input_features=gc["feats"].to(dev).to(torch.bfloat16), input_features_mask=gc["fmask"].to(dev), attention_mask=att,
+                 position_ids=pid, past_key_values=rc, use_cache=True)
+        nxt, new = ro.logits[:, -1].float().argmax(-1), []
+        for _ in range(N_GEN):
+            new.append(nxt[:, None])
+            att = torch.cat([att, torch.ones_like(att[:, :1])], 1)
+            pid = (att.long().cumsum(-1) - 1)[:, -1:]
+            o = m(input_ids=nxt[:, None], past_key_values=rc, attention_mask=att, position_ids=pid, logits_to_keep=1)
+            nxt = o.logits[:, -1].float().argmax(-1)
+        assert torch.cat(new, 1).cpu().tolist() == gc["generate"][:, Sc: Sc + N_GEN].tolist()
+
+
 def test_generate_sampling(dev):
     """do_sample: top_k = 1 is greedy; a seed reproduces the draw; tokens come from the top-k set of the reference distribution"""
     g = torch.load(os.path.join(G, "tiny64_caseA.pt"))

@@ -148,8 +148,9 @@ def _logit_stats(got, ref32, noise=None):
 #           softmax concentrates (encoder x 2.8, decoder x 1.7: score std ~ 4), (ii) embed_tokens scaled x 200 so that the token identity survives the
 #           28 random layers in the residual stream and lm_head = embed_tokens / 480 so that the logit of the CURRENT token stands ~ 20 sigma above
 #           the rest: argmax is then decided on (nearly) every row and the q / k gradients carry signal.  Same code path, same shapes, same kernels.
-PEAKED = dict(enc_qk=float(os.environ.get("AFK_PEAK_ENC_QK", "2.8")), dec_qk=float(os.environ.get("AFK_PEAK_DEC_QK", "1.7")),
-              embed=float(os.environ.get("AFK_PEAK_EMBED", "200")), head=float(os.environ.get("AFK_PEAK_HEAD", str(1.0 / 480))))
+PEAKED = dict(enc_qk=float(os.environ.get("AFK_PEAK_ENC_QK", "4.5")), dec_qk=float(os.environ.get("AFK_PEAK_DEC_QK", "1.7")),
+              embed=float(os.environ.get("AFK_PEAK_EMBED", "200")), head=float(os.environ.get("AFK_PEAK_HEAD", str(1.0 / 480))),
+              audio=float(os.environ.get("AFK_PEAK_AUDIO", "200")))
 
 
 def _build_state(cfg, dev, variant):
@@ -173,6 +174,11 @@ def _build_state(cfg, dev, variant):
             emb = ref.get_input_embeddings().weight
             emb.mul_(PEAKED["embed"])
             ref.lm_head.weight.copy_(emb * PEAKED["head"])
+            # the audio rows enter the decoder beside the (scaled) text embeddings: the projector's output layer is scaled alike, or the loss would barely
+            # depend on the audio tower and EVERY encoder gradient would be bf16 noise (first calibration run: 461 of 829 tensors noise-dominated)
+            for k, p in ref.named_parameters():
+                if "multi_modal_projector.linear_2." in k:
+                    p.mul_(PEAKED["audio"])
     ref.to(BF)
     sd = {k: v.detach().clone() for k, v in ref.state_dict().items()}
     ref.train()
@@ -317,7 +323,7 @@ def _leg(dev, cfg, variant, batch, micro_fp32, long_windows, lr, enc_layers, dec
     wtxt = "reference _init_weights under torch.manual_seed(0), biases ~ N(0, 0.02), norm weights ~ 1 + N(0, 0.05)"
     if variant == "peaked":
         wtxt += (f"; then q / k projections x {PEAKED['enc_qk']} (encoder) / x {PEAKED['dec_qk']} (decoder), embed_tokens x {PEAKED['embed']:.0f}, "
-                 f"lm_head = embed_tokens x {PEAKED['head']:.5f} (peaked attention, decided argmax)")
+                 f"projector linear_2 x {PEAKED['audio']:.0f}, lm_head = embed_tokens x {PEAKED['head']:.5f} (peaked attention, decided argmax)")
     res = {"config": ("BASELINE configs[1]: " if (enc_layers, dec_layers, batch) == (32, 28, 8) else "NOT the BASELINE config: ") +
                      "AF3-7B %d+%d layers, B=%d, S=%d, one 30 s window per sample, bf16" % (enc_layers, dec_layers, batch, ids.shape[1]),
            "weights": wtxt + ", rounded to bf16; the SAME state_dict in all three models", "weight_set": variant,
@@ -594,7 +600,20 @@ if __name__ == "__main__":
     ap.add_argument("--dec-layers", type=int, default=28)
     ap.add_argument("--no-peaked", action="store_true")
     ap.add_argument("--no-long-train", action="store_true")
+    ap.add_argument("--only-peaked", action="store_true", help="calibration: the peaked weight set on the configs[1] batch only")
     a = ap.parse_args()
+    if a.only_peaked:
+        import bench
+
+        r = _leg(torch.device("cuda", 0), bench.af3_7b_config(a.enc_layers, a.dec_layers), "peaked", a.batch, 2, 0, 1e-5, a.enc_layers, a.dec_layers,
+                 lambda s_: print(s_, file=sys.stderr, flush=True))
+        os.makedirs(os.path.dirname(a.out), exist_ok=True)
+        with open(a.out, "w") as f:
+            json.dump(r, f, indent=1)
+        g_ = r["gradients"]
+        print(json.dumps({"checks": r["checks"], "attention_peak": r["attention_peak_fp32_reference"], "logits": r["logits"], "ours_over_floor": g_["ours_over_floor"],
+                          "qk": g_["qk_projection_tensors"], "noise_dominated": len(g_["noise_dominated_in_the_reference_bf16_run"]), "over_bar": g_["over_bar"]}))
+        sys.exit(0)
     r = run(torch.device("cuda", 0), batch=a.batch, long_windows=0 if a.no_long else 10, enc_layers=a.enc_layers, dec_layers=a.dec_layers, peaked=not a.no_peaked,
             long_train=not a.no_long_train)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
