@@ -46,8 +46,10 @@ struct AttnArgs2 {
     float scale;
     int causal;
     int dbg;          // AFK_ATTN_DBG experiments: read only in -DAFK_PROBES builds (AFK_DBG below), ignored otherwise
-    int split_heads;  // dK/dV sweep: one block per QUERY head, partial dK/dV per query head (GQA), reduced afterwards
+    int split_heads;  // dK/dV sweep (GQA): P > 0 = P blocks per kv head, each sweeping ~group / P query heads into one partial dK/dV, reduced afterwards; 0 = one block per kv head
     int wide;         // 16-byte epilogue stores are legal (every output pointer / stride keeps 16-byte alignment)
+    int xcd_map;      // forward / dQ: 1-D grid with the XCD-aware block -> (sample, head, query block) map below; 0 = linear (heads, batch, blocks) order
+    int nz;           // forward / dQ: number of 128-query blocks
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -187,6 +189,55 @@ struct Tile {
     }
 };
 
+// ------------------------------------------------------------------------------------------ block -> work map of the forward and dQ kernels (round 6)
+// The hardware deals workgroups to the 8 XCDs round-robin in linear block order and every XCD has its own 4 MB L2.  With the grid (heads, batch, query
+// blocks) of rounds 2-5 the heads that SHARE a K / V stream - the Hq / Hkv query heads of a GQA group, the query blocks of one head - landed on different XCDs:
+// at the AF3 decoder shape every XCD streamed all 32 (sample, kv head) pairs (16 MB through a 4 MB L2), i.e. nearly every K / V tile load of the launch
+// - 528 MB, 5.3 TB/s over the forward's 100 us - missed L2 and crossed the fabric; the encoder forward re-read each head's K / V 12 times (737 MB).
+// Here block L runs on XCD L % 8 in slot L / 8, and the map gives every XCD a CONTIGUOUS chunk of the work sorted by what it streams:
+//   causal (blocks differ in length): level-major - all blocks of query-block level z (longest first, the order that balances the grid), and inside a level
+//     the heads of one (sample, kv head) group side by side: an XCD owns whole groups (AF3: 4 groups = 2 MB of K / V, L2-resident for the whole launch;
+//     B = 1: one group per XCD pair, levels alternating), the group's heads run in lockstep over the same tiles;
+//   non-causal (equal blocks): head-major - the query blocks of a head back to back on one XCD, running concurrently over the same K / V tiles.
+// When the counts do not divide by 8 the tail (or, non-causal, everything) keeps the linear order.  lvl = dispatch level (0 first).
+struct QBlock { int b, h, z; };
+__device__ __forceinline__ QBlock attn_qblock(const AttnArgs2& p) {
+    const int nz = p.nz, n = p.Hq * p.B, gsz = p.Hq / p.Hkv;
+    int L, item, lvl;
+    if (!p.xcd_map) {
+        return QBlock{(int)blockIdx.y, (int)blockIdx.x, p.causal ? nz - 1 - (int)blockIdx.z : (int)blockIdx.z};
+    }
+    L = blockIdx.x;
+    const int T = n * nz;
+    if (!p.causal) {
+        if ((T & 7) == 0) {
+            const int idx = (L & 7) * (T >> 3) + (L >> 3);
+            item = idx / nz;
+            lvl = idx - item * nz;
+        } else {
+            lvl = L / n;
+            item = L - lvl * n;
+        }
+    } else {
+        const int k = (n & 7) == 0 ? 1 : (n & 3) == 0 ? 2 : (n & 1) == 0 ? 4 : 8;   // levels per super-level: k n divisible by 8
+        const int full = nz / k, c = (k * n) >> 3;                                   // complete super-levels; items per XCD and super-level
+        if (L < full * k * n) {
+            const int slot = L >> 3, sup = slot / c, r = slot - sup * c;
+            const int idx = (L & 7) * c + r;                                         // position in the super-level's (group, level, head) order
+            const int per_group = k * gsz, group = idx / per_group, rem = idx - group * per_group;
+            const int li = rem / gsz;
+            lvl = sup * k + li;
+            item = (group / p.Hkv) * p.Hq + (group % p.Hkv) * gsz + (rem - li * gsz);
+        } else {
+            const int L2 = L - full * k * n;
+            lvl = full * k + L2 / n;
+            item = L2 % n;
+        }
+    }
+    const int b = item / p.Hq;
+    return QBlock{b, item - b * p.Hq, p.causal ? nz - 1 - lvl : lvl};
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // One block = 128 query rows (4 waves x 32), two blocks per CU.  Per 64-key tile and wave:
 //     S^T = K.Q^T (2 x KS MFMAs, two independent accumulators)  ->  one online-softmax step over all 64 keys
@@ -210,7 +261,12 @@ constexpr float RESCALE_THR = 8.f;  // log2 domain
 // LM (round 4): the row sum l comes out of the matrix pipe - one more accumulator block fed with an all-ones A fragment against the SAME
 // probability fragments (l = P^T . 1: every row of the block equals the per-query sum over the tile's keys, it accumulates over tiles and takes
 // the lazy rescale like O).  4 MFMAs per tile replace 29 VALU adds, and the normaliser is the sum of the bf16-ROUNDED probabilities that P.V uses.
-template <int D, bool LM>
+// SCH (round 6): 0 = the K row fragments are plain C++ LDS loads (the compiler schedules them just in time: two ds_read_b128, s_waitcnt lgkmcnt(0..1), two
+// MFMAs - every MFMA pair of the S^T phase starts by waiting out an LDS round trip) and the next tile's LDS-DMA pieces are issued in one burst in front of the
+// tile; 1 = explicit two-deep ring of opaque ds_read_b128 groups (4 fragments = 4 MFMAs per group, the next group in flight behind the one being consumed,
+// counted lgkmcnt) with the DMA pieces of the next tile dealt out between the MFMA groups (issue cost of a piece ~60-180 cycles: under the matrix pipe
+// instead of in front of it).  Same MFMAs on the same operands in the same order: bit-identical results.
+template <int D, bool LM, int SCH>
 __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
     constexpr int KS = T::KS, DT = T::DT;
@@ -223,9 +279,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     // grid dimension must not be the one the work per block depends on - with the 8 causal position blocks of S = 1024 in x, XCD k received
     // every block of length class k and the kernel ran as long as the XCD holding the 16-tile blocks (profiles/r02_attn_probes.md).
     // Position blocks are the slowest dimension, longest first.
-    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);
-    // causal: late query blocks sweep the most keys - dispatch them first so the grid drains evenly
-    const int qb0 = (p.causal ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z) * 128;
+    const QBlock blk = attn_qblock(p);   // causal: late query blocks sweep the most keys - they are dispatched first so the grid drains evenly
+    const int b = blk.b, h = blk.h, hk = h / (p.Hq / p.Hkv);
+    const int qb0 = blk.z * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -261,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) vtr[dt][pc] = lds0 + T::BYTES + offs.tr[dt][pc];
+    uint32_t krow[KS];   // SCH 1: K row-fragment addresses in buffer 0 (kt2 = 1: + 32 rows)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) krow[ks] = lds0 + offs.row[ks];
 
     auto stage = [&](int j) {  // general form (row clamp): prologue and boundary tiles
         char* buf = smem + (j & 1) * 2 * T::BYTES;
@@ -285,23 +344,64 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         const bf16* v0 = Vbase + (int64_t)j * 64 * p.v_rs;
 #pragma unroll
         for (int u0 = 0; u0 < NP; ++u0) {
-            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
-            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
+            // piece u0 = rows 4 RPU u0 further down with the SAME swizzled chunk (neither swizzle term depends on u0): one per-lane offset, the piece
+            // part goes into the scalar base
+            afk_dma16_saddr(k0 + (int64_t)u0 * 4 * T::RPU * p.k_rs, koff[0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0 + (int64_t)u0 * 4 * T::RPU * p.v_rs, voff[0], buf + T::BYTES + 4 * u0 * 1024);
         }
     };
     const int n_full = p.S >> 6;  // tiles whose 64 rows all exist
 
     // one 64-key tile.  MASKED: per-element visibility (key < kv_len, causal key <= q) is applied to the scores.  par_: DynPar / StaticPar<P>.
-    auto tile = [&](int j, auto masked_, auto par_) {
+    // DMA piece i (0 .. 2 NP - 1: K pieces even, V pieces odd) of tile jn into buffer jn & 1 - the pointer form of stage_fast, one piece at a time
+    auto dma_piece = [&](int jn, auto i_) {
+        constexpr int i = decltype(i_)::value, u0 = i >> 1;
+        constexpr bool isv = (i & 1) != 0;
+        const uint32_t dst = lds0 + (jn & 1) * 2 * T::BYTES + wave * 1024 + (isv ? T::BYTES : 0) + 4 * u0 * 1024;
+        if constexpr (isv) afk_dma16_saddr(Vbase + ((int64_t)jn * 64 + u0 * 4 * T::RPU) * p.v_rs, voff[0], dst);
+        else afk_dma16_saddr(Kbase + ((int64_t)jn * 64 + u0 * 4 * T::RPU) * p.k_rs, koff[0], dst);
+    };
+    // dma_: std::true_type = this tile issues the LDS-DMA of tile j + 1 (a full tile) itself, dealt out between its MFMA groups (SCH 1 only)
+    auto tile = [&](int j, auto masked_, auto par_, auto dma_) {
         constexpr bool MASKED = decltype(masked_)::value;
+        constexpr bool DMA = decltype(dma_)::value;
         constexpr int POFF = par_static_off<decltype(par_)>(2 * T::BYTES);           // compile-time buffer offset (folded into the ds offset fields)
         const uint32_t boff = par_dyn_off(par_, 2 * T::BYTES);                        // run-time buffer offset
         const char* kimg = smem + POFF + boff;
         f32x16 st[2] = {zero16(), zero16()};
+        if constexpr (SCH == 0) {
+            static_assert(!DMA || SCH == 1, "interleaved DMA belongs to the ring schedule");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
-            st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+            for (int ks = 0; ks < KS; ++ks) {
+                st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
+                st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+            }
+        } else {
+            constexpr int NGK = KS / 2, PPG = 2 * NP / NGK;   // K fragment groups (2 k-steps x 2 row halves each); DMA pieces per group
+            bf16x8 ra[4], rb[4];
+            auto issue_k = [&](auto g_, bf16x8(&dst)[4]) {
+                constexpr int g = decltype(g_)::value;
+                const uint32_t a0 = krow[2 * g] + boff, a1 = krow[2 * g + 1] + boff;
+                dst[0] = afk_lds_b128<POFF>(a0);
+                dst[1] = afk_lds_b128<POFF + 32 * T::RS>(a0);
+                dst[2] = afk_lds_b128<POFF>(a1);
+                dst[3] = afk_lds_b128<POFF + 32 * T::RS>(a1);
+            };
+            issue_k(std::integral_constant<int, 0>{}, ra);
+            if constexpr (NGK > 1) issue_k(std::integral_constant<int, 1>{}, rb);
+            afk_static_for<NGK>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                bf16x8(&cur)[4] = (g & 1) ? rb : ra;
+                if constexpr (g + 1 < NGK) afk_lgkmcnt<4>();   // LDS returns in order: group g has landed, g + 1 may still be in flight
+                else afk_lgkmcnt<0>();
+                afk_lds_tie(cur[0], cur[1], cur[2], cur[3]);
+                st[0] = MFMA(cur[0], qf[2 * g], st[0]);
+                st[1] = MFMA(cur[1], qf[2 * g], st[1]);
+                st[0] = MFMA(cur[2], qf[2 * g + 1], st[0]);
+                st[1] = MFMA(cur[3], qf[2 * g + 1], st[1]);
+                if constexpr (g + 2 < NGK) issue_k(std::integral_constant<int, g + 2>{}, cur);
+                if constexpr (DMA) afk_static_for<PPG>([&](auto i_) { dma_piece(j + 1, std::integral_constant<int, g * PPG + decltype(i_)::value>{}); });
+            });
         }
         // V^T fragments of d-tile 0: in flight during the softmax; the other d-tiles follow through the two-deep ring below
         bf16x8 fa[4], fb[4];
@@ -370,40 +470,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     const int j0 = kv_lo >> 6, j_int0 = (kv_lo + 63) >> 6;
     if (ntiles > j0) stage(j0);
     AFK_ATTN_BARRIER();
+    // Round 6 (ISA reading): the Q rows were requested by plain global loads and their first use sits inside the tile loops.  The compiler's waitcnt
+    // pass does not see the asm `vmcnt(0)` of AFK_ATTN_BARRIER, so it planted `s_waitcnt vmcnt(0)` in front of the FIRST MFMA of every loop body that
+    // could be the first consumer - i.e. every other interior tile waited for the K / V prefetch it had issued a few instructions earlier.  Naming the
+    // registers as asm operands HERE (all loads have landed: the barrier above drained them) puts the compiler's wait where it costs nothing.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     int j = j0;
+    constexpr std::false_type NO_DMA{};
+    constexpr std::integral_constant<bool, SCH == 1> IN_TILE{};   // SCH 1: the fast tiles issue the next tile's DMA themselves
     for (; j < min(j_int0, ntiles); ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1}, NO_DMA);
         AFK_ATTN_BARRIER();
     }
     const int n_fast = min(n_int, n_full - 1);  // tile j+1 must be a full tile for the pointer form of the prefetch
     if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, DynPar{1});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{1}, IN_TILE);
         AFK_ATTN_BARRIER();
         ++j;
     }
     for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, StaticPar<0>{});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, StaticPar<0>{}, IN_TILE);
         AFK_ATTN_BARRIER();
-        stage_fast(j + 2);
-        tile(j + 1, std::false_type{}, StaticPar<1>{});
+        if constexpr (SCH == 0) stage_fast(j + 2);
+        tile(j + 1, std::false_type{}, StaticPar<1>{}, IN_TILE);
         AFK_ATTN_BARRIER();
     }
     for (; j < n_fast; ++j) {
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, DynPar{j & 1});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{j & 1}, IN_TILE);
         AFK_ATTN_BARRIER();
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));  // a redundant re-stage of the last tile lands in the other buffer and is never read
-        tile(j, std::false_type{}, DynPar{j & 1});
+        tile(j, std::false_type{}, DynPar{j & 1}, NO_DMA);
         AFK_ATTN_BARRIER();
     }
     for (; j < ntiles; ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});  // wave-uniform
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1}, NO_DMA);  // wave-uniform
         AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
@@ -481,8 +589,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_persist_kernel(AttnArgs2 p, i
         const bf16* v0 = x.Vb + (int64_t)j * 64 * p.v_rs;
 #pragma unroll
         for (int u0 = 0; u0 < NP; ++u0) {
-            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
-            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
+            // piece u0 = rows 4 RPU u0 further down with the SAME swizzled chunk (neither swizzle term depends on u0): one per-lane offset, the piece
+            // part goes into the scalar base
+            afk_dma16_saddr(k0 + (int64_t)u0 * 4 * T::RPU * p.k_rs, koff[0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0 + (int64_t)u0 * 4 * T::RPU * p.v_rs, voff[0], buf + T::BYTES + 4 * u0 * 1024);
         }
     };
     bf16x8 qf[KS];
@@ -647,7 +757,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_persist_kernel(AttnArgs2 p, i
 // Same geometry and loop structure as the forward (interior / boundary key tiles, opaque tr-reads issued ahead of the VALU block,
 // K/V prefetch in flight for the whole tile).  Per 64-key tile and wave: S^T = K.Q^T and dP^T = V.dO^T (4 x KS MFMAs on four
 // independent accumulators), dS = P o (dP - delta) with P = 2^(S*c2 - lse), dQ^T += K^T.dS (4 x DT MFMAs).
-template <int D>
+// SCH (round 6): 0 = compiler-scheduled row-fragment reads.  At head_dim 128 that kernel sat at 256 VGPRs with two spilled registers, and the allocator had
+// serialised the first phase to ONE ds_read_b128 in flight: 32 x (read, s_waitcnt lgkmcnt(0), MFMA) per tile - the matrix pipe waited out an LDS round trip
+// per MFMA.  1 = the 64 keys of a tile are processed as two 32-key halves (S^T and dP^T accumulators: 2 x 16 registers instead of 4 x 16), row fragments
+// through an explicit two-deep ring of opaque ds_read_b128 groups (K, V of two k-steps per group) with counted lgkmcnt, the next tile's LDS-DMA pieces
+// dealt out between the MFMA groups.  Same MFMAs on the same operands, same accumulation order per accumulator: bit-identical dQ.
+template <int D, int SCH>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     using T = Tile<D>;
     constexpr int KS = T::KS, DT = T::DT;
@@ -656,8 +771,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const typename T::Offs offs = T::make_offs(lane);
-    const int b = blockIdx.y, h = blockIdx.x, hk = h / (p.Hq / p.Hkv);  // grid = (heads, batch, position blocks), see the forward kernel
-    const int qb0 = (p.causal ? (int)gridDim.z - 1 - (int)blockIdx.z : (int)blockIdx.z) * 128;
+    const QBlock blk = attn_qblock(p);   // the forward kernel's block -> (sample, head, query block) map
+    const int b = blk.b, h = blk.h, hk = h / (p.Hq / p.Hkv);
+    const int qb0 = blk.z * 128;
     const int q0 = qb0 + wave * 32;
     const int q = q0 + l31;
     const int qc = min(q, p.S - 1);
@@ -731,42 +847,46 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         const bf16* v0 = Vbase + (int64_t)j * 64 * p.v_rs;
 #pragma unroll
         for (int u0 = 0; u0 < NP; ++u0) {
-            afk_dma16_saddr(k0, koff[u0], buf + 4 * u0 * 1024);
-            afk_dma16_saddr(v0, voff[u0], buf + T::BYTES + 4 * u0 * 1024);
+            // piece u0 = rows 4 RPU u0 further down with the SAME swizzled chunk (neither swizzle term depends on u0): one per-lane offset, the piece
+            // part goes into the scalar base
+            afk_dma16_saddr(k0 + (int64_t)u0 * 4 * T::RPU * p.k_rs, koff[0], buf + 4 * u0 * 1024);
+            afk_dma16_saddr(v0 + (int64_t)u0 * 4 * T::RPU * p.v_rs, voff[0], buf + T::BYTES + 4 * u0 * 1024);
         }
     };
 
-    auto tile = [&](int j, auto masked_, auto par_) {
+    uint32_t krow[KS];   // SCH 1: K row-fragment addresses in buffer 0 (V: + T::BYTES, second 32-key half: + 32 rows)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) krow[ks] = lds0 + offs.row[ks];
+    auto dma_piece = [&](int jn, auto i_) {   // piece i (K even, V odd) of tile jn into buffer jn & 1, as in the forward kernel
+        constexpr int i = decltype(i_)::value, u0 = i >> 1;
+        constexpr bool isv = (i & 1) != 0;
+        const uint32_t dst = lds0 + (jn & 1) * 2 * T::BYTES + wave * 1024 + (isv ? T::BYTES : 0) + 4 * u0 * 1024;
+        if constexpr (isv) afk_dma16_saddr(Vbase + ((int64_t)jn * 64 + u0 * 4 * T::RPU) * p.v_rs, voff[0], dst);
+        else afk_dma16_saddr(Kbase + ((int64_t)jn * 64 + u0 * 4 * T::RPU) * p.k_rs, koff[0], dst);
+    };
+    auto tile = [&](int j, auto masked_, auto par_, auto dma_) {
         constexpr bool MASKED = decltype(masked_)::value;
+        constexpr bool DMA = decltype(dma_)::value;
         constexpr int POFF = par_static_off<decltype(par_)>(2 * T::BYTES);
         const uint32_t boff = par_dyn_off(par_, 2 * T::BYTES);
         const char* kimg = smem + POFF + boff;
         const char* vimg = kimg + T::BYTES;
-        f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
-            st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
-            dp[0] = MFMA(T::row_frag(vimg, offs, 0, ks), dof[ks], dp[0]);
-            dp[1] = MFMA(T::row_frag(vimg, offs, 1, ks), dof[ks], dp[1]);
-        }
         bf16x8 fa[4], fb[4];  // K^T fragments: d-tile 0 in flight during the VALU block, the rest through the ring
         auto issue = [&](auto g_, bf16x8(&dst)[4]) {
             constexpr int dt = decltype(g_)::value;
             const uint32_t a0 = ktr[dt][0] + boff, a1 = ktr[dt][1] + boff;
             afk_static_for<4>([&](auto s_) { constexpr int s4 = decltype(s_)::value; dst[s4] = afk_lds_tr_frag<POFF + s4 * 16 * T::RS>(a0, a1); });
         };
-        issue(std::integral_constant<int, 0>{}, fa);
         const f32x2 c2v = {c2, c2}, nl = {nlse, nlse}, nd = {ndlt, ndlt};
         bf16x8 dsb[4];
-#pragma unroll
-        for (int kt2 = 0; kt2 < 2; ++kt2)
+        // dS of one 32-key half (kt2) from its score / dP accumulators
+        auto ds_half = [&](int kt2, const f32x16& sh, const f32x16& dh) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const f32x2 s2 = {st[kt2][r], st[kt2][r + 1]};
+                const f32x2 s2 = {sh[r], sh[r + 1]};
                 const f32x2 t2 = __builtin_elementwise_fma(s2, c2v, nl);
                 const f32x2 p2 = {__builtin_amdgcn_exp2f(t2[0]), __builtin_amdgcn_exp2f(t2[1])};
-                const f32x2 d2 = {dp[kt2][r], dp[kt2][r + 1]};
+                const f32x2 d2 = {dh[r], dh[r + 1]};
                 f32x2 ds2 = p2 * (d2 + nd);
                 if (MASKED) {
                     const int key = j * 64 + kt2 * 32 + ROW_OF(r, hi);  // r even: rows key, key+1
@@ -776,6 +896,56 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
                 dsb[2 * kt2 + (r >> 3)][r & 7] = (bf16)ds2[0];
                 dsb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)ds2[1];
             }
+        };
+        if constexpr (SCH == 0) {
+            f32x16 st[2] = {zero16(), zero16()}, dp[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                st[0] = MFMA(T::row_frag(kimg, offs, 0, ks), qf[ks], st[0]);
+                st[1] = MFMA(T::row_frag(kimg, offs, 1, ks), qf[ks], st[1]);
+                dp[0] = MFMA(T::row_frag(vimg, offs, 0, ks), dof[ks], dp[0]);
+                dp[1] = MFMA(T::row_frag(vimg, offs, 1, ks), dof[ks], dp[1]);
+            }
+            issue(std::integral_constant<int, 0>{}, fa);
+            ds_half(0, st[0], dp[0]);
+            ds_half(1, st[1], dp[1]);
+        } else {
+            constexpr int NGK = KS / 2, NT = 2 * NGK, PPG = (2 * NP + NT - 1) / NT;   // groups per half, groups per tile, DMA pieces per group
+            bf16x8 ra[4], rb[4];
+            auto issue_r = [&](auto G_, bf16x8(&dst)[4]) {
+                constexpr int G = decltype(G_)::value, h = G / NGK, g = G % NGK;
+                const uint32_t a0 = krow[2 * g] + boff, a1 = krow[2 * g + 1] + boff;
+                dst[0] = afk_lds_b128<POFF + h * 32 * T::RS>(a0);
+                dst[1] = afk_lds_b128<POFF + T::BYTES + h * 32 * T::RS>(a0);
+                dst[2] = afk_lds_b128<POFF + h * 32 * T::RS>(a1);
+                dst[3] = afk_lds_b128<POFF + T::BYTES + h * 32 * T::RS>(a1);
+            };
+            issue_r(std::integral_constant<int, 0>{}, ra);
+            issue_r(std::integral_constant<int, 1>{}, rb);
+            afk_static_for<2>([&](auto h_) {
+                constexpr int h = decltype(h_)::value;
+                f32x16 sh = zero16(), dh = zero16();
+                afk_static_for<NGK>([&](auto g_) {
+                    constexpr int g = decltype(g_)::value, G = h * NGK + g;
+                    bf16x8(&cur)[4] = (G & 1) ? rb : ra;
+                    if constexpr (G + 1 < NT) afk_lgkmcnt<4>();   // in-order LDS returns: group G has landed, G + 1 may be in flight
+                    else afk_lgkmcnt<0>();
+                    afk_lds_tie(cur[0], cur[1], cur[2], cur[3]);
+                    sh = MFMA(cur[0], qf[2 * g], sh);
+                    dh = MFMA(cur[1], dof[2 * g], dh);
+                    sh = MFMA(cur[2], qf[2 * g + 1], sh);
+                    dh = MFMA(cur[3], dof[2 * g + 1], dh);
+                    if constexpr (G + 2 < NT) issue_r(std::integral_constant<int, G + 2>{}, cur);
+                    if constexpr (DMA)
+                        afk_static_for<PPG>([&](auto i_) {
+                            constexpr int i = G * PPG + decltype(i_)::value;
+                            if constexpr (i < 2 * NP) dma_piece(j + 1, std::integral_constant<int, i>{});
+                        });
+                });
+                if constexpr (h == 1) issue(std::integral_constant<int, 0>{}, fa);   // every row fragment consumed: the K^T ring starts under the VALU block
+                ds_half(h, sh, dh);
+            });
+        }
         afk_frag_ring<DT>(issue, [&](auto g_, bf16x8(&f)[4]) {
             constexpr int dt = decltype(g_)::value;
 #pragma unroll
@@ -787,39 +957,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     if (ntiles > j0) stage(j0);
     AFK_ATTN_BARRIER();
     int j = j0;
+    constexpr std::false_type NO_DMA{};
+    constexpr std::integral_constant<bool, SCH == 1> IN_TILE{};   // SCH 1: the fast tiles issue the next tile's DMA themselves
     for (; j < min(j_int0, ntiles); ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1}, NO_DMA);
         AFK_ATTN_BARRIER();
     }
     const int n_fast = min(n_int, n_full - 1);
     if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, DynPar{1});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{1}, IN_TILE);
         AFK_ATTN_BARRIER();
         ++j;
     }
     for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, StaticPar<0>{});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, StaticPar<0>{}, IN_TILE);
         AFK_ATTN_BARRIER();
-        stage_fast(j + 2);
-        tile(j + 1, std::false_type{}, StaticPar<1>{});
+        if constexpr (SCH == 0) stage_fast(j + 2);
+        tile(j + 1, std::false_type{}, StaticPar<1>{}, IN_TILE);
         AFK_ATTN_BARRIER();
     }
     for (; j < n_fast; ++j) {
-        stage_fast(j + 1);
-        tile(j, std::false_type{}, DynPar{j & 1});
+        if constexpr (SCH == 0) stage_fast(j + 1);
+        tile(j, std::false_type{}, DynPar{j & 1}, IN_TILE);
         AFK_ATTN_BARRIER();
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));
-        tile(j, std::false_type{}, DynPar{j & 1});
+        tile(j, std::false_type{}, DynPar{j & 1}, NO_DMA);
         AFK_ATTN_BARRIER();
     }
     for (; j < ntiles; ++j) {
         stage(min(j + 1, ntiles - 1));
-        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1});
+        if (q0 < p.S && j * 64 < kv_end) tile(j, std::true_type{}, DynPar{j & 1}, NO_DMA);
         AFK_ATTN_BARRIER();
     }
     if (q < p.S) {
@@ -853,9 +1025,13 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     const typename T::Offs offs = T::make_offs(lane);
     const int b = blockIdx.y, group = p.Hq / p.Hkv;  // grid = (heads, batch, key blocks), see the forward kernel; causal: key block 0 is the longest
     const int hy = blockIdx.x;
-    const int hk = p.split_heads ? hy / group : hy;
-    const int g_begin = p.split_heads ? hy % group : 0;
-    const int g_count = p.split_heads ? 1 : group;
+    // split_heads = P > 0: P blocks per kv head, block part = hy % P sweeps query heads [part * group / P, (part + 1) * group / P) of the group and writes
+    // ONE partial dK / dV (round 6: P < group - fewer, longer blocks: a block's prologue + store tail were ~8 us against 2.5 us per tile - and P instead of
+    // `group` partials through HBM); P = group is the one-block-per-query-head form of rounds 2-5
+    const int P = p.split_heads;
+    const int hk = P ? hy / P : hy;
+    const int g_begin = P ? ((hy % P) * group) / P : 0;
+    const int g_count = P ? (((hy % P) + 1) * group) / P - g_begin : group;
     const int kb0 = blockIdx.z * 128;
     const int key0 = kb0 + wave * 32;
     const int key = key0 + l31;
@@ -1206,6 +1382,25 @@ bool attn_wide_stores() {
     return on;
 }
 
+// AFK_ATTN_SCHED=0: the compiler-scheduled fragment reads of rounds 1-5 (A/B); default 1 = explicit read rings + interleaved LDS-DMA (round 6)
+int g_xcd_map = -1;      // -1: not chosen yet (AFK_ATTN_XCD, default 1)
+int attn_xcd_map() {
+    if (g_xcd_map < 0) {
+        const char* e = getenv("AFK_ATTN_XCD");
+        g_xcd_map = e ? (atoi(e) != 0) : 1;
+    }
+    return g_xcd_map;
+}
+int g_dkdv_parts = 0;    // afk_attn_set_dkdv_parts: > 0 overrides AFK_ATTN_DKDV_PARTS / the default (A/B inside one process)
+int g_attn_sched = -1;   // -1: not chosen yet (environment, then the default)
+int attn_sched() {
+    if (g_attn_sched < 0) {
+        const char* e = getenv("AFK_ATTN_SCHED");
+        g_attn_sched = e ? (atoi(e) != 0) : 1;
+    }
+    return g_attn_sched;
+}
+
 template <typename K>
 int set_lds(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 1;
@@ -1233,7 +1428,10 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.LSE = LSE; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     p.wide = attn_wide_stores() && (uintptr_t)O % 16 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 && o_rs % 8 == 0;
-    dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    p.nz = (int)afk_cdiv(S, 128);
+    p.xcd_map = attn_xcd_map();
+    dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)p.nz);
+    if (p.xcd_map) grid = dim3((unsigned)(Hq * B * p.nz));
     hipStream_t st = (hipStream_t)stream;
     afk_count(D == 128 ? AFK_CNT_ATTN2_FWD_D128 : AFK_CNT_ATTN2_FWD_D64);
     // row sum on the matrix pipe (kernel template LM): default at head_dim 128 - measured (profiles/r04_kernel_ab.md): -4 % on the 5-minute decoder
@@ -1241,20 +1439,42 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     // AFK_ATTN_LSUM=0 / 1 forces it off / on for both head sizes (A/B)
     static const int lsum_env = [] { const char* e = getenv("AFK_ATTN_LSUM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool lm = lsum_env < 0 ? D == 128 : lsum_env == 1;
-#define AFK_FWD(DD, LM_)                                                                      \
-    do {                                                                                      \
-        constexpr int L = 4 * Tile<DD>::BYTES;                                                \
-        static int once = set_lds(attn_fwd_lds_kernel<DD, LM_>, L);                           \
-        (void)once;                                                                           \
-        hipLaunchKernelGGL((attn_fwd_lds_kernel<DD, LM_>), grid, dim3(256), L, st, p);        \
+#define AFK_FWD(DD, LM_, SCH_)                                                                      \
+    do {                                                                                            \
+        constexpr int L = 4 * Tile<DD>::BYTES;                                                      \
+        static int once = set_lds(attn_fwd_lds_kernel<DD, LM_, SCH_>, L);                           \
+        (void)once;                                                                                 \
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<DD, LM_, SCH_>), grid, dim3(256), L, st, p);        \
     } while (0)
+    const int sch = attn_sched();
     if (D == 128) {
-        if (lm) AFK_FWD(128, true); else AFK_FWD(128, false);
+        if (sch) { if (lm) AFK_FWD(128, true, 1); else AFK_FWD(128, false, 1); }
+        else { if (lm) AFK_FWD(128, true, 0); else AFK_FWD(128, false, 0); }
     } else {
-        if (lm) AFK_FWD(64, true); else AFK_FWD(64, false);
+        if (sch) { if (lm) AFK_FWD(64, true, 1); else AFK_FWD(64, false, 1); }
+        else { if (lm) AFK_FWD(64, true, 0); else AFK_FWD(64, false, 0); }
     }
 #undef AFK_FWD
     AFK_LAUNCH_CHECK("afk_attn2_fwd");
+    return AFK_OK;
+}
+
+// A/B switch of the round-6 fragment schedule (0 = compiler-scheduled reads of rounds 1-5, 1 = explicit read rings + interleaved LDS-DMA; both bit-identical)
+extern "C" int afk_attn_set_sched(int sched) {
+    AFK_REQUIRE(sched == 0 || sched == 1, "afk_attn_set_sched: 0 or 1");
+    g_attn_sched = sched;
+    return AFK_OK;
+}
+
+extern "C" int afk_attn_set_xcd_map(int on) {
+    AFK_REQUIRE(on == 0 || on == 1, "afk_attn_set_xcd_map: 0 or 1");
+    g_xcd_map = on;
+    return AFK_OK;
+}
+
+extern "C" int afk_attn_set_dkdv_parts(int parts) {
+    AFK_REQUIRE(parts >= 0 && parts <= 64, "afk_attn_set_dkdv_parts: 0 (environment / default) or the number of dK/dV partials per kv head");
+    g_dkdv_parts = parts;
     return AFK_OK;
 }
 
@@ -1358,32 +1578,45 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
     p.wide = attn_wide_stores() && al16(dQ, dq_bs, dq_hs, dq_rs) && al16(dK, dk_bs, dk_hs, dk_rs) && al16(dV, dv_bs, dv_hs, dv_rs) &&
              (!split || ((uintptr_t)gqa_scratch % 16 == 0 && D % 8 == 0));
     AttnArgs2 pk = p;
+    // parts per kv head: AFK_ATTN_DKDV_PARTS (1 .. group; default below).  The scratch is sized for `group` partials, any P <= group fits.
+    static const int parts_env = [] { const char* e = getenv("AFK_ATTN_DKDV_PARTS"); return e ? atoi(e) : 0; }();
+    const int P = split ? std::max(1, std::min(group, g_dkdv_parts > 0 ? g_dkdv_parts : (parts_env > 0 ? parts_env : group))) : 0;
     if (split) {
-        pk.split_heads = 1;
+        pk.split_heads = P;
         pk.dK = (bf16*)gqa_scratch;
         pk.dV = (bf16*)gqa_scratch + (int64_t)B * S * Hq * D;
-        pk.dk_bs = pk.dv_bs = (int64_t)S * Hq * D;
+        pk.dk_bs = pk.dv_bs = (int64_t)S * Hkv * P * D;
         pk.dk_hs = pk.dv_hs = D;
-        pk.dk_rs = pk.dv_rs = (int64_t)Hq * D;
+        pk.dk_rs = pk.dv_rs = (int64_t)Hkv * P * D;
     }
     afk_count(D == 128 ? AFK_CNT_ATTN2_BWD_D128 : AFK_CNT_ATTN2_BWD_D64);
     if (split) afk_count(AFK_CNT_GQA_REDUCE);
-    dim3 gkv((unsigned)(split ? Hq : Hkv), (unsigned)B, (unsigned)afk_cdiv(S, 128));
-    dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    dim3 gkv((unsigned)(split ? Hkv * P : Hkv), (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    p.nz = pk.nz = (int)afk_cdiv(S, 128);
+    p.xcd_map = attn_xcd_map();
+    dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)p.nz);
+    if (p.xcd_map) gq = dim3((unsigned)(Hq * B * p.nz));
+    const int sch = attn_sched();
+    auto launch_dq = [&](auto d_) {
+        constexpr int DD = decltype(d_)::value;
+        constexpr int L = 4 * Tile<DD>::BYTES;
+        if (sch) hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<DD, 1>), gq, dim3(256), L, st, p);
+        else hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<DD, 0>), gq, dim3(256), L, st, p);
+    };
     if (D == 128) {
         constexpr int L = 4 * Tile<128>::BYTES, LKV = L + 2048;  // dK/dV sweep: + one lse/delta strip per buffer
-        static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128>, L);
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<128>, LKV) + set_lds(attn_bwd_dq_lds_kernel<128, 0>, L) + set_lds(attn_bwd_dq_lds_kernel<128, 1>, L);
         (void)once;
-        if (O) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);   // publishes delta for the sweep behind it
+        if (O) launch_dq(std::integral_constant<int, 128>{});   // publishes delta for the sweep behind it
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<128>, gkv, dim3(256), LKV, st, pk);
-        if (!O && !(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<128>, gq, dim3(256), L, st, p);
+        if (!O && !(AFK_DBG(p) & 4)) launch_dq(std::integral_constant<int, 128>{});
     } else {
         constexpr int L = 4 * Tile<64>::BYTES, LKV = L + 2048;
-        static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64>, L);
+        static int once = set_lds(attn_bwd_dkdv_lds_kernel<64>, LKV) + set_lds(attn_bwd_dq_lds_kernel<64, 0>, L) + set_lds(attn_bwd_dq_lds_kernel<64, 1>, L);
         (void)once;
-        if (O) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+        if (O) launch_dq(std::integral_constant<int, 64>{});
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
-        if (!O && !(AFK_DBG(p) & 4)) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel<64>, gq, dim3(256), L, st, p);
+        if (!O && !(AFK_DBG(p) & 4)) launch_dq(std::integral_constant<int, 64>{});
     }
     if (split && !(AFK_DBG(p) & 4)) {
         AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
@@ -1391,8 +1624,8 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
         const int64_t rows = (int64_t)B * S;
         int g = (int)afk_cdiv(rows * (Hkv * D / 8), 256);
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dK, (bf16*)dK, rows, Hkv, group, D, dk_rs);
-        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dV, (bf16*)dV, rows, Hkv, group, D, dv_rs);
+        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dK, (bf16*)dK, rows, Hkv, P, D, dk_rs);
+        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dV, (bf16*)dV, rows, Hkv, P, D, dv_rs);
     }
     AFK_LAUNCH_CHECK("afk_attn2_bwd");
     return AFK_OK;

@@ -219,6 +219,19 @@ int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const
                   int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, void* O, int64_t o_bs,
                   int64_t o_hs, int64_t o_rs, float* LSE, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S, int Spad,
                   int D, float scale, int causal, void* stream);
+/* A/B switch of the attention forward / dQ instruction schedule (round 6): 1 (default; AFK_ATTN_SCHED) = row fragments through explicit rings of opaque
+ * ds_read_b128 groups, the dQ tile as two 32-key halves, LDS-DMA pieces dealt out between the MFMA groups; 0 = the compiler-scheduled reads of rounds 1-5.
+ * Both compute the same MFMAs on the same operands in the same order: bit-identical results (tests/test_ops_gpu.py).  Replaces nothing in the reference:
+ * it selects between two instruction streams of the same SDPA (sdpa_attention.py:79-166). */
+int afk_attn_set_sched(int sched);
+/* Forward / dQ block -> work map (round 6; AFK_ATTN_XCD): 1 (default) = 1-D grid whose linear block order hands every XCD (block id % 8) a contiguous chunk
+ * of the work sorted by the K / V stream it reads - the query heads of a GQA group side by side at each causal level, the query blocks of a head back to back
+ * when not causal - so that heads sharing K / V share an L2; 0 = the (heads, batch, query blocks) grid of rounds 2-5.  Same blocks, same arithmetic. */
+int afk_attn_set_xcd_map(int on);
+/* GQA dK/dV sweep (afk_attn2_bwd*, gqa_scratch given): number of blocks - and of bf16 partial dK/dV images - per kv head.  Each block sweeps ~group / parts
+ * query heads, accumulating in registers; `group` = one block per query head (rounds 2-5).  0 = AFK_ATTN_DKDV_PARTS / the default.  Fewer parts = fewer and
+ * longer blocks, fewer partials through HBM, fewer roundings; the result differs from other part counts in the last bf16 bit (summation grouping). */
+int afk_attn_set_dkdv_parts(int parts);
 /* afk_attn2_fwd with RESIDENT blocks that pull (sample, head, 128-query block) items from an atomic queue, heavy first, and overlap the next item's cold
  * loads (first K / V tile, Q rows) with the current item's last tile and store tail (round 5, opt-in: AFK_ATTN_PERSIST=1).  Same results bit for bit.
  * queue: two device ints, zero before the first call, left at zero by every call (one queue per stream that launches concurrently).  Restrictions: no

@@ -339,7 +339,7 @@ def test_bench_world1_rccl_path_eager(dev):
     import json
 
     plain_eager = _bench(["--no-graph"])
-    dp_eager = _bench(["--no-graph", "--force-dp"])
+    dp_eager = _bench(["--no-graph", "--force-dp", "--no-dp-probe"])   # the startup form probe trains extra steps: off for the bit comparison
     assert dp_eager["rccl_ranks"] == 1 and dp_eager["dp"]["collectives_forced_at_world_1"] and dp_eager["dp"]["backend"] == "nccl", dp_eager["dp"]
     assert dp_eager["step_enqueue"] == "eager_python" and dp_eager["replicas_identical_after_steps"] is True
     assert dp_eager["param_checksum"] == plain_eager["param_checksum"] and dp_eager["loss"] == plain_eager["loss"], (dp_eager["param_checksum"], plain_eager["param_checksum"])
@@ -364,7 +364,7 @@ def test_bench_world1_rccl_inside_hip_graph_experimental(dev):
 
     plain_graph = _bench(["--graph"])
     try:
-        dp_graph = _bench(["--force-dp", "--dp-graph"])
+        dp_graph = _bench(["--force-dp", "--dp-graph", "--no-dp-probe"])
         sh_graph = _bench(["--force-dp", "--dp-graph"], env_extra=SHARDED)
     except BenchAborted as e:
         pytest.xfail(f"--dp-graph (experimental): the process aborted (SIGABRT), output kept in {e.log}: {str(e)[-600:]}")

@@ -932,6 +932,47 @@ def test_attention_forward_persistent_form_bit_equal(dev, B, S, Hq, Hkv, D, caus
         ops.ATTN_PERSIST = old
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,causal,pad", [(8, 1024, 28, 4, 128, True, None), (2, 1500, 20, 20, 64, False, None), (2, 1000, 28, 4, 128, True, "right"),
+                                                     (3, 777, 8, 8, 64, False, "right"), (2, 640, 8, 2, 128, True, "left"), (1, 128, 4, 2, 128, True, None),
+                                                     (1, 2113, 28, 4, 128, True, "left"), (1, 96, 4, 4, 64, False, None), (3, 520, 6, 3, 64, True, None),
+                                                     (1, 7774, 28, 4, 128, True, None), (5, 300, 7, 7, 128, False, "right")])
+def test_attention_schedules_bit_equal(dev, B, S, Hq, Hkv, D, causal, pad):
+    """round 6: the forward and dQ kernels' explicit-ring schedule (afk_attn_set_sched(1): row fragments through counted rings of opaque ds_read_b128 groups, the
+    dQ tile as two 32-key halves, LDS-DMA pieces between the MFMA groups) computes the SAME MFMAs on the same operands in the same order as the
+    compiler-scheduled form of rounds 1-5 (0): O, LSE and every gradient bit-identical - interior, diagonal, ragged, right- and left-padded tiles."""
+    from audio_flamingo_amd import _lib
+
+    ops = _ops()
+    qkv = _rand((B * S, (Hq + 2 * Hkv) * D), dev, 0.5, 11).to(BF)
+    do = _rand((B * S, Hq * D), dev, 0.5, 12).to(BF)
+    kv_len = kv_lo = None
+    if pad == "right":
+        kv_len = torch.tensor([S - 37 * (i + 1) for i in range(B)], device=dev, dtype=torch.int32)
+    elif pad == "left":
+        kv_lo = torch.tensor([29 + 70 * i for i in range(B)], device=dev, dtype=torch.int32)
+    res = {}
+    try:
+        # (schedule, XCD-aware block map): the map (afk_attn_set_xcd_map) only changes WHICH block computes a (sample, head, query block) - same bits again
+        for key in ((0, 0), (1, 0), (1, 1), (0, 1), (1, 1)):
+            _lib.call("afk_attn_set_sched", key[0])
+            _lib.call("afk_attn_set_xcd_map", key[1])
+            o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal, kv_len=kv_len, kv_lo=kv_lo)
+            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal, kv_len=kv_len, kv_lo=kv_lo)
+            torch.cuda.synchronize()
+            if key in res:
+                assert torch.equal(res[key][0], o) and torch.equal(res[key][2], dqkv)   # and deterministic run to run
+            res[key] = (o.clone(), lse[..., :S].clone(), dqkv.clone())
+    finally:
+        _lib.call("afk_attn_set_sched", 1)
+        _lib.call("afk_attn_set_xcd_map", 1)
+    base = res[(0, 0)]
+    assert torch.isfinite(base[0].float()).all() and torch.isfinite(base[2].float()).all()
+    for key, r in res.items():
+        assert torch.equal(base[0], r[0]), f"O differs: (schedule, xcd map) = {key}"
+        assert torch.equal(base[1], r[1]), f"LSE differs: (schedule, xcd map) = {key}"
+        assert torch.equal(base[2], r[2]), f"dQKV differs: (schedule, xcd map) = {key}"
+
+
 @pytest.mark.parametrize("D,Hq,Hkv,B", [(128, 28, 4, 8), (64, 4, 2, 16), (128, 8, 2, 8)])
 def test_attn_decode_group_kernel_bit_equal(dev, D, Hq, Hkv, B):
     """round 5: batched decode attention - ONE block per (sample, KV head, key chunk) serves all Hq / Hkv query heads (attn_decode_group_kernel, taken by

@@ -145,10 +145,11 @@ def _logit_stats(got, ref32, noise=None):
 #           random-init 7B model has FLAT logits (top-1/top-2 gap below the bf16 noise on 97 % of the rows) and near-UNIFORM attention (the q / k projections'
 #           gradients are differences of nearly equal numbers: 93 of 829 tensors are noise in the reference's own bf16 run) - round 5's record had no teeth there.
 # "peaked": the same init, then  (i) every q / k projection (weights and biases) of both towers scaled so that the attention
-#           softmax concentrates (encoder x 2.8, decoder x 1.7: score std ~ 4), (ii) embed_tokens scaled x 200 so that the token identity survives the
+#           softmax concentrates (encoder x 6, decoder x 1.7; calibrated on the GPU in round 6 - encoder x 1.5 ... 4.5 left 50-93 of the 208 q / k
+#           gradient tensors below the reference's own bf16 noise, x 8 saturates the softmax and loses them again, x 6: none), (ii) embed_tokens scaled x 200 so that the token identity survives the
 #           28 random layers in the residual stream and lm_head = embed_tokens / 480 so that the logit of the CURRENT token stands ~ 20 sigma above
 #           the rest: argmax is then decided on (nearly) every row and the q / k gradients carry signal.  Same code path, same shapes, same kernels.
-PEAKED = dict(enc_qk=float(os.environ.get("AFK_PEAK_ENC_QK", "4.5")), dec_qk=float(os.environ.get("AFK_PEAK_DEC_QK", "1.7")),
+PEAKED = dict(enc_qk=float(os.environ.get("AFK_PEAK_ENC_QK", "6")), dec_qk=float(os.environ.get("AFK_PEAK_DEC_QK", "1.7")),
               embed=float(os.environ.get("AFK_PEAK_EMBED", "200")), head=float(os.environ.get("AFK_PEAK_HEAD", str(1.0 / 480))),
               audio=float(os.environ.get("AFK_PEAK_AUDIO", "200")))
 
