@@ -256,6 +256,18 @@ __device__ __forceinline__ QBlock attn_qblock(const AttnArgs2& p) {
         __builtin_amdgcn_s_barrier();                         \
         __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
+// probe builds only (AFK_ATTN_DBG & 2, forward / dQ): the tile barrier WITHOUT the wait for the prefetch - tiles are read before they have landed (wrong
+// results); the time it saves is the time the loop spends waiting for LDS-DMA
+#define AFK_ATTN_BARRIER_P(p_)                                \
+    do {                                                      \
+        if (AFK_DBG(p_) & 2) {                                \
+            __builtin_amdgcn_sched_barrier(0);                \
+            __builtin_amdgcn_s_barrier();                     \
+            __builtin_amdgcn_sched_barrier(0);                \
+        } else {                                              \
+            AFK_ATTN_BARRIER();                               \
+        }                                                     \
+    } while (0)
 constexpr float RESCALE_THR = 8.f;  // log2 domain
 
 // LM (round 4): the row sum l comes out of the matrix pipe - one more accumulator block fed with an all-ones A fragment against the SAME
@@ -400,7 +412,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
                 st[0] = MFMA(cur[2], qf[2 * g + 1], st[0]);
                 st[1] = MFMA(cur[3], qf[2 * g + 1], st[1]);
                 if constexpr (g + 2 < NGK) issue_k(std::integral_constant<int, g + 2>{}, cur);
-                if constexpr (DMA) afk_static_for<PPG>([&](auto i_) { dma_piece(j + 1, std::integral_constant<int, g * PPG + decltype(i_)::value>{}); });
+                if constexpr (DMA)
+                    if (!(AFK_DBG(p) & 1)) afk_static_for<PPG>([&](auto i_) { dma_piece(j + 1, std::integral_constant<int, g * PPG + decltype(i_)::value>{}); });
             });
         }
         // V^T fragments of d-tile 0: in flight during the softmax; the other d-tiles follow through the two-deep ring below
@@ -488,21 +501,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
     if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, DynPar{1}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
         ++j;
     }
     for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, StaticPar<0>{}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
         if constexpr (SCH == 0) stage_fast(j + 2);
         tile(j + 1, std::false_type{}, StaticPar<1>{}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
     }
     for (; j < n_fast; ++j) {
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, DynPar{j & 1}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));  // a redundant re-stage of the last tile lands in the other buffer and is never read
@@ -937,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
                     dh = MFMA(cur[3], dof[2 * g + 1], dh);
                     if constexpr (G + 2 < NT) issue_r(std::integral_constant<int, G + 2>{}, cur);
                     if constexpr (DMA)
-                        afk_static_for<PPG>([&](auto i_) {
+                        if (!(AFK_DBG(p) & 1)) afk_static_for<PPG>([&](auto i_) {
                             constexpr int i = G * PPG + decltype(i_)::value;
                             if constexpr (i < 2 * NP) dma_piece(j + 1, std::integral_constant<int, i>{});
                         });
@@ -968,21 +981,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     if (j < n_fast && (j & 1)) {                // odd tile in front of the unrolled pairs
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, DynPar{1}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
         ++j;
     }
     for (; j + 1 < n_fast; j += 2) {            // interior pairs: buffer parity is a compile-time constant
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, StaticPar<0>{}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
         if constexpr (SCH == 0) stage_fast(j + 2);
         tile(j + 1, std::false_type{}, StaticPar<1>{}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
     }
     for (; j < n_fast; ++j) {
         if constexpr (SCH == 0) stage_fast(j + 1);
         tile(j, std::false_type{}, DynPar{j & 1}, IN_TILE);
-        AFK_ATTN_BARRIER();
+        AFK_ATTN_BARRIER_P(p);
     }
     for (; j < n_int; ++j) {
         stage(min(j + 1, ntiles - 1));
@@ -1430,6 +1443,12 @@ extern "C" int afk_attn2_fwd(const void* Q, int64_t q_bs, int64_t q_hs, int64_t 
     p.wide = attn_wide_stores() && (uintptr_t)O % 16 == 0 && o_bs % 8 == 0 && o_hs % 8 == 0 && o_rs % 8 == 0;
     p.nz = (int)afk_cdiv(S, 128);
     p.xcd_map = attn_xcd_map();
+#ifdef AFK_PROBES
+    {
+        static const char* dbg = getenv("AFK_ATTN_DBG");
+        if (dbg) p.dbg = atoi(dbg);
+    }
+#endif
     dim3 grid((unsigned)Hq, (unsigned)B, (unsigned)p.nz);
     if (p.xcd_map) grid = dim3((unsigned)(Hq * B * p.nz));
     hipStream_t st = (hipStream_t)stream;
@@ -1580,8 +1599,18 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
     AttnArgs2 pk = p;
     // parts per kv head: AFK_ATTN_DKDV_PARTS (1 .. group; default below).  The scratch is sized for `group` partials, any P <= group fits.
     static const int parts_env = [] { const char* e = getenv("AFK_ATTN_DKDV_PARTS"); return e ? atoi(e) : 0; }();
-    const int P = split ? std::max(1, std::min(group, g_dkdv_parts > 0 ? g_dkdv_parts : (parts_env > 0 ? parts_env : group))) : 0;
+    // default (round 6, profiles/r06_attn_ab.md): the SMALLEST part count that still gives the chip two blocks per CU - fewer, longer blocks amortise a block's
+    // prologue + store tail (~8 us against 2.5 us per tile) and fewer partials cross HBM: AF3 decoder (B = 8, S = 1024) P = 2: 345 -> 307 us for the whole
+    // backward, S = 2048 (B = 4) 535 -> 509; B = 1 at S = 7774 P = 3 (level with 7; P = 2 starves the grid: +3 %)
+    int P = 0;
     if (split) {
+        const int64_t per_part = (int64_t)B * Hkv * afk_cdiv(S, 128);
+        int want = g_dkdv_parts > 0 ? g_dkdv_parts : parts_env;
+        if (want <= 0) want = (int)std::min<int64_t>(group, std::max<int64_t>(1, afk_cdiv(512, per_part)));
+        P = std::max(1, std::min(group, want));
+    }
+    const bool direct = split && P == 1;   // one block per kv head sweeps the whole group: no partials, no reduce
+    if (split && !direct) {
         pk.split_heads = P;
         pk.dK = (bf16*)gqa_scratch;
         pk.dV = (bf16*)gqa_scratch + (int64_t)B * S * Hq * D;
@@ -1590,8 +1619,8 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
         pk.dk_rs = pk.dv_rs = (int64_t)Hkv * P * D;
     }
     afk_count(D == 128 ? AFK_CNT_ATTN2_BWD_D128 : AFK_CNT_ATTN2_BWD_D64);
-    if (split) afk_count(AFK_CNT_GQA_REDUCE);
-    dim3 gkv((unsigned)(split ? Hkv * P : Hkv), (unsigned)B, (unsigned)afk_cdiv(S, 128));
+    if (split && !direct) afk_count(AFK_CNT_GQA_REDUCE);
+    dim3 gkv((unsigned)(split && !direct ? Hkv * P : Hkv), (unsigned)B, (unsigned)afk_cdiv(S, 128));
     p.nz = pk.nz = (int)afk_cdiv(S, 128);
     p.xcd_map = attn_xcd_map();
     dim3 gq((unsigned)Hq, (unsigned)B, (unsigned)p.nz);
@@ -1618,7 +1647,7 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
         hipLaunchKernelGGL(attn_bwd_dkdv_lds_kernel<64>, gkv, dim3(256), LKV, st, pk);
         if (!O && !(AFK_DBG(p) & 4)) launch_dq(std::integral_constant<int, 64>{});
     }
-    if (split && !(AFK_DBG(p) & 4)) {
+    if (split && !direct && !(AFK_DBG(p) & 4)) {
         AFK_REQUIRE(dk_hs == D && dv_hs == D && dk_bs == (int64_t)S * dk_rs && dv_bs == (int64_t)S * dv_rs && dk_rs == dv_rs,
                     "afk_attn2_bwd: GQA split path expects dK/dV inside one [B*S, ld] buffer with contiguous heads");
         const int64_t rows = (int64_t)B * S;

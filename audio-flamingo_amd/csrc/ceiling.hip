@@ -68,12 +68,63 @@ __global__ __launch_bounds__(512, 1) void mfma_ceiling_kernel(const bf16* __rest
     if (s == 123.456f) sink[0] = s;   // keeps the accumulators alive; never true in practice
 }
 
+// modes 2 / 3 (round 6): issue pacing of one wave per SIMD - 16 MFMAs per trip over four accumulators, round-robin (2: every MFMA depends on the one
+// four back) or each accumulator four times in a row (3: every MFMA depends on its predecessor, the P.V order of the attention kernels of rounds 1-5).
+// sink[0] = shader cycles per MFMA (s_memtime of wave 0, block 0).
+template <bool CHAIN>
+__global__ __launch_bounds__(256, 1) void mfma_pacing_kernel(const bf16* __restrict__ src, float* __restrict__ sink, int iters) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16x8* s8 = (const bf16x8*)src;
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = s8[(wave * 8 + k) * 64 + lane];
+        b[k] = s8[(wave * 8 + 4 + k) * 64 + lane];
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    uint64_t t0, t1;
+    asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+        if (CHAIN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k], b[k], acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k], b[k], acc[i], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    asm volatile("s_nop 0\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(s) : "memory");
+    if (blockIdx.x == 0 && threadIdx.x == 0) sink[0] = (float)(t1 - t0) / (16.f * iters);
+    if (s == 123.456f) sink[1] = s;
+}
+
 }  // namespace
 
 extern "C" int afk_mfma_ceiling(int mode, int nblocks, int iters, const void* operands, float* sink, double* host_flops, void* stream) {
-    AFK_REQUIRE(mode == 0 || mode == 1, "afk_mfma_ceiling: mode %d (0 = register-resident operands, 1 = + LDS fragment reads)", mode);
+    AFK_REQUIRE(mode >= 0 && mode <= 3, "afk_mfma_ceiling: mode %d (0 = register-resident operands, 1 = + LDS fragment reads, 2 / 3 = issue pacing of one wave per SIMD, "
+                "independent / dependent accumulators: sink[0] = cycles per MFMA)", mode);
     AFK_REQUIRE(nblocks > 0 && iters > 0 && operands && sink, "afk_mfma_ceiling: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    if (mode >= 2) {
+        if (mode == 2) mfma_pacing_kernel<false><<<nblocks, 256, 0, s>>>((const bf16*)operands, sink, iters);
+        else mfma_pacing_kernel<true><<<nblocks, 256, 0, s>>>((const bf16*)operands, sink, iters);
+        AFK_LAUNCH_CHECK("afk_mfma_ceiling");
+        if (host_flops) *host_flops = (double)nblocks * 4.0 * iters * 16 * 2.0 * 32 * 32 * 16;
+        return AFK_OK;
+    }
     if (mode == 0) {
         mfma_ceiling_kernel<0><<<nblocks, 512, 0, s>>>((const bf16*)operands, sink, iters);
     } else {

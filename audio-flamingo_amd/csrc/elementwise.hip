@@ -141,55 +141,6 @@ __global__ __launch_bounds__(256) void silu_mul_bwd_kernel(const bf16* __restric
     }
 }
 
-// Round 6 form of silu_mul_bwd_kernel: a thread owns TWO 16-byte column vectors of one row per trip (six independent loads issued back to back, no 64-bit
-// division per element: the row comes from blockIdx.y / a row stride), operands read with the non-temporal policy (gate|up and dh are dead after this
-// kernel: they should not evict the d(gate|up) lines the dgrad / wgrad GEMMs read next).  Same arithmetic per element: bit-identical output.
-__global__ __launch_bounds__(256) void silu_mul_bwd2_kernel(const bf16* __restrict__ gu, const bf16* __restrict__ dh,
-                                                            bf16* __restrict__ dgu, int64_t rows, int I) {
-    const int vpr = I >> 3;                          // 16-byte vectors per half row
-    const int half = (vpr + 1) >> 1;                 // a thread handles vectors v and v + half
-    for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-        const bf16* grow = gu + r * 2 * I;
-        const bf16* drow = dh + r * I;
-        bf16* orow = dgu + r * 2 * I;
-        for (int v = blockIdx.x * 256 + threadIdx.x; v < half; v += gridDim.x * 256) {
-            const int c0 = v * 8, c1 = (v + half) * 8;
-            const bool two = v + half < vpr;
-            const bf16x8 g0 = __builtin_nontemporal_load((const bf16x8*)(grow + c0));
-            const bf16x8 u0 = __builtin_nontemporal_load((const bf16x8*)(grow + I + c0));
-            const bf16x8 d0 = __builtin_nontemporal_load((const bf16x8*)(drow + c0));
-            bf16x8 g1 = g0, u1 = u0, d1 = d0;
-            if (two) {
-                g1 = __builtin_nontemporal_load((const bf16x8*)(grow + c1));
-                u1 = __builtin_nontemporal_load((const bf16x8*)(grow + I + c1));
-                d1 = __builtin_nontemporal_load((const bf16x8*)(drow + c1));
-            }
-            bf16x8 og0, ou0, og1, ou1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                {
-                    const float gf = (float)g0[e], uf = (float)u0[e], df = (float)d0[e];
-                    const float s = sigmoid_f(gf);
-                    og0[e] = (bf16)(df * uf * (s * (1.f + gf * (1.f - s))));
-                    ou0[e] = (bf16)(df * (gf * s));
-                }
-                {
-                    const float gf = (float)g1[e], uf = (float)u1[e], df = (float)d1[e];
-                    const float s = sigmoid_f(gf);
-                    og1[e] = (bf16)(df * uf * (s * (1.f + gf * (1.f - s))));
-                    ou1[e] = (bf16)(df * (gf * s));
-                }
-            }
-            *(bf16x8*)(orow + c0) = og0;
-            *(bf16x8*)(orow + I + c0) = ou0;
-            if (two) {
-                *(bf16x8*)(orow + c1) = og1;
-                *(bf16x8*)(orow + I + c1) = ou1;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ RoPE (rotate-half), in place on the q|k columns
 // apply_rotary_pos_emb (modeling_qwen2.py:112-135): x*cos + rotate_half(x)*sin with cos/sin rounded to bf16
 // (:102) and every product/sum a bf16 tensor op.  buf = [rows, ld]; heads 0..nheads-1 of width D start at
@@ -862,14 +813,6 @@ extern "C" int afk_silu_mul_fwd(const void* gu, void* h, int64_t rows, int I, vo
 
 extern "C" int afk_silu_mul_bwd(const void* gu, const void* dh, void* dgu, int64_t rows, int I, void* stream) {
     AFK_REQUIRE(gu && dh && dgu && I % 8 == 0 && rows > 0, "afk_silu_mul_bwd: bad args");
-    static const int form = [] { const char* e = getenv("AFK_SILU_BWD_FORM"); return e ? atoi(e) : 2; }();   // 1 = the grid-stride form of rounds 1-5 (A/B)
-    if (form == 2) {
-        const int half = (I / 8 + 1) / 2;
-        const unsigned gx = (unsigned)std::min<int64_t>(afk_cdiv(half, 256), 8), gy = (unsigned)std::min<int64_t>(rows, 4096 / gx);
-        hipLaunchKernelGGL(silu_mul_bwd2_kernel, dim3(gx, gy), dim3(256), 0, ST, (const bf16*)gu, (const bf16*)dh, (bf16*)dgu, rows, I);
-        AFK_LAUNCH_CHECK("afk_silu_mul_bwd");
-        return AFK_OK;
-    }
     hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid(rows * (I / 8), 256)), dim3(256), 0, ST, (const bf16*)gu,
                        (const bf16*)dh, (bf16*)dgu, rows, I);
     AFK_LAUNCH_CHECK("afk_silu_mul_bwd");

@@ -411,7 +411,9 @@ int afk_cu_hog(int nblocks, int lds_bytes, const int* stop_flag, int64_t max_tic
  * segments of 16 v_mfma_f32_32x32x16_bf16 (2 x 2 tiles x 4 k-steps, the MFMA segment of gemm_nt_bf16_k256) on operands taken from `operands`
  * (device, bf16, >= 65536 elements, e.g. N(0,1)).  mode 0: operands resident in registers, no memory access inside the loop.  mode 1: the GEMM's
  * LDS fragment traffic added (12 ds_read_b128 per segment from a 64 KiB LDS image of `operands`).  *host_flops (nullable) receives the flops
- * of the launch; time it with HIP events on `stream`.  sink: device float, never written in practice. */
+ * of the launch; time it with HIP events on `stream`.  sink: device float, never written in practice.  modes 2 / 3: issue pacing of ONE wave per SIMD
+ * (4-wave workgroups) over four accumulators - round-robin (2) or each accumulator four times in a row (3: back-to-back dependent MFMAs);
+ * sink[0] = shader cycles per MFMA, sink needs 2 floats. */
 int afk_mfma_ceiling(int mode, int nblocks, int iters, const void* operands, float* sink, double* host_flops, void* stream);
 
 /* ---- HIP streams with an explicit queue priority (round 6).  The training step runs on three streams: the critical path (forward, dgrad, attention,

@@ -634,7 +634,7 @@ print("OK", rank)
 '''
 
 
-@pytest.mark.parametrize("nproc", [2, 4])
+@pytest.mark.parametrize("nproc", [2, 4, 8])
 def test_sharded_adamw_equals_replicated_gloo_world2(tmp_path, nproc):
     """AFK_DP_FORM=rs_adamw_ag - reduce-scatter, AdamW on this rank's 1 / world share of every bucket (arena.ShardedAdamW), all-gather
     of the bf16 parameters - gives BIT-IDENTICAL parameters to the replicated path over three steps (incl. an all-text step whose audio buckets are gated
