@@ -50,6 +50,11 @@ struct AttnArgs2 {
     int wide;         // 16-byte epilogue stores are legal (every output pointer / stride keeps 16-byte alignment)
     int xcd_map;      // forward / dQ: 1-D grid with the XCD-aware block -> (sample, head, query block) map below; 0 = linear (heads, batch, blocks) order
     int nz;           // forward / dQ: number of 128-query blocks
+    // afk_attn2_bwd_fused_rope: the backward of the rotary embedding (rotation by -theta, the oracle's bf16 rounding points: afk_rope_inplace backward) applied to
+    // dQ in the dQ kernel's epilogue and to dK where its final value is formed (GQA reduce / the sweep's epilogue) - no separate pass over dq | dk
+    const bf16* rope_cos;   // [positions, D] bf16 tables (null: no rotation)
+    const bf16* rope_sin;
+    const int* rope_pos;    // [B * S] position of every row (null: row % S)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -103,6 +108,29 @@ __device__ __forceinline__ void store_block32(bf16* rowp, const f32x16& acc, flo
             *(bf16x4*)(rowp + 8 * qd + 4 * hi) = o;
         }
     }
+}
+
+// RoPE backward on the DT accumulator blocks of ONE row held row-per-lane (store_block32's layout: block dt, register 4 qd + e <-> column 32 dt + 8 qd + 4 hi + e;
+// the rotate-half partner d + D/2 is block dt + DT/2, same register, same lane).  Rounding points of rope_kernel (elementwise.hip) with sign = -1: the incoming
+// gradient is a bf16 tensor (acc x mul rounded), every product is rounded, the sum is rounded - so the accumulators leave as exactly-representable bf16 values
+// and the caller stores them with mul = 1.  ctab / stab = the row's cos / sin table rows (D entries each).
+template <int DT>
+__device__ __forceinline__ void rope_bwd_rows(f32x16 (&acc)[DT], float mul, const bf16* ctab, const bf16* stab, int hi) {
+    constexpr int HB = DT / 2;   // blocks per half head
+#pragma unroll
+    for (int dt = 0; dt < HB; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int d0 = 32 * dt + 8 * qd + 4 * hi;
+            const bf16x4 c1 = *(const bf16x4*)(ctab + d0), s1 = *(const bf16x4*)(stab + d0);
+            const bf16x4 c2 = *(const bf16x4*)(ctab + 16 * DT + d0), s2 = *(const bf16x4*)(stab + 16 * DT + d0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = rbf_strict(acc[dt][4 * qd + e] * mul), b = rbf_strict(acc[dt + HB][4 * qd + e] * mul);   // rbf_strict: see common.h (fp-contract)
+                acc[dt][4 * qd + e] = rbf_strict(rbf_strict(a * (float)c1[e]) + rbf_strict(b * (float)s1[e]));
+                acc[dt + HB][4 * qd + e] = rbf_strict(rbf_strict(b * (float)c2[e]) + rbf_strict(-a * (float)s2[e]));
+            }
+        }
 }
 
 // Buffer parity of a tile: DynPar = run-time (boundary tiles, the odd tile in front of the unrolled interior loop), StaticPar<P> = compile time
@@ -1009,12 +1037,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
     }
     if (q < p.S) {
         bf16* dQp = p.dQ + b * p.dq_bs + h * p.dq_hs + (int64_t)q * p.dq_rs;
-        if (p.wide) {   // (softmax scale folded out of dS)
+        float mul = p.scale;   // (softmax scale folded out of dS)
+        if (p.rope_cos) {
+            const int64_t pr = p.rope_pos ? p.rope_pos[(int64_t)b * p.S + q] : q;
+            rope_bwd_rows<DT>(dqacc, mul, p.rope_cos + pr * D, p.rope_sin + pr * D, hi);
+            mul = 1.f;
+        }
+        if (p.wide) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) store_block32<true>(dQp + dt * 32, dqacc[dt], p.scale, hi);
+            for (int dt = 0; dt < DT; ++dt) store_block32<true>(dQp + dt * 32, dqacc[dt], mul, hi);
         } else {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) store_block32<false>(dQp + dt * 32, dqacc[dt], p.scale, hi);
+            for (int dt = 0; dt < DT; ++dt) store_block32<false>(dQp + dt * 32, dqacc[dt], mul, hi);
         }
     }
 }
@@ -1307,16 +1341,22 @@ __global__ __launch_bounds__(256, (D <= 64 ? 2 : 1)) void attn_bwd_dkdv_lds_kern
     if (key < p.S) {
         bf16* dKp = p.dK + b * p.dk_bs + hy * p.dk_hs + (int64_t)key * p.dk_rs;
         bf16* dVp = p.dV + b * p.dv_bs + hy * p.dv_hs + (int64_t)key * p.dv_rs;
-        if (p.wide) {   // (softmax scale folded out of dS)
+        float kmul = p.scale;   // (softmax scale folded out of dS)
+        if (p.rope_cos && !p.split_heads) {   // this block writes the final dK (partials are rotated by the reduce)
+            const int64_t pr = p.rope_pos ? p.rope_pos[(int64_t)b * p.S + key] : key;
+            rope_bwd_rows<DT>(dkacc, kmul, p.rope_cos + pr * D, p.rope_sin + pr * D, hi);
+            kmul = 1.f;
+        }
+        if (p.wide) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                store_block32<true>(dKp + dt * 32, dkacc[dt], p.scale, hi);
+                store_block32<true>(dKp + dt * 32, dkacc[dt], kmul, hi);
                 store_block32<true>(dVp + dt * 32, dvacc[dt], 1.f, hi);
             }
         } else {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                store_block32<false>(dKp + dt * 32, dkacc[dt], p.scale, hi);
+                store_block32<false>(dKp + dt * 32, dkacc[dt], kmul, hi);
                 store_block32<false>(dVp + dt * 32, dvacc[dt], 1.f, hi);
             }
         }
@@ -1386,6 +1426,65 @@ __global__ __launch_bounds__(256) void gqa_reduce_kernel(const bf16* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
         *(bf16x8*)(out + r * ld_out + hk * D + d) = o;
+    }
+}
+
+// Both GQA reduces in ONE launch, the rotary backward of dK folded in (round 6).  A dK item = one (row, kv head, 8-column vector of the FIRST half head) plus its
+// rotate-half partner vector d + D/2: both are summed over the P partial images in part order (fp32, as gqa_reduce_kernel), rounded to bf16 - the value the
+// separate reduce stored - then rotated with rope_kernel's rounding points (sign = -1).  A dV item = one 8-column vector, summed and rounded.  Items
+// [0, n_k) are dK, [n_k, n_k + n_v) dV.
+__global__ __launch_bounds__(256) void gqa_reduce_rope_kernel(const bf16* __restrict__ pk, const bf16* __restrict__ pv, bf16* __restrict__ dk, bf16* __restrict__ dv,
+                                                              int64_t rows, int Hkv, int P, int D, int64_t ld_k, int64_t ld_v, const bf16* __restrict__ cos_t,
+                                                              const bf16* __restrict__ sin_t, const int* __restrict__ pos, int S) {
+    const int half = D >> 1, vk = Hkv * half / 8, vv = Hkv * D / 8;
+    const int64_t n_k = rows * vk, total = n_k + rows * vv, pw = (int64_t)Hkv * P * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < n_k) {
+            const int v = (int)(i % vk);
+            const int64_t r = i / vk;
+            const int hk = (v * 8) / half, d = (v * 8) % half;
+            float a[8], b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
+            for (int g = 0; g < P; ++g) {
+                const bf16* src = pk + r * pw + (hk * P + g) * D + d;
+                const bf16x8 t1 = *(const bf16x8*)src, t2 = *(const bf16x8*)(src + half);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a[e] += (float)t1[e];
+                    b[e] += (float)t2[e];
+                }
+            }
+            const int64_t pr = pos ? pos[r] : r % S;
+            const bf16x8 c1 = *(const bf16x8*)(cos_t + pr * D + d), s1 = *(const bf16x8*)(sin_t + pr * D + d);
+            const bf16x8 c2 = *(const bf16x8*)(cos_t + pr * D + half + d), s2 = *(const bf16x8*)(sin_t + pr * D + half + d);
+            bf16x8 o1, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = rbf_strict(a[e]), y = rbf_strict(b[e]);
+                o1[e] = (bf16)(rbf_strict(x * (float)c1[e]) + rbf_strict(y * (float)s1[e]));
+                o2[e] = (bf16)(rbf_strict(y * (float)c2[e]) + rbf_strict(-x * (float)s2[e]));
+            }
+            *(bf16x8*)(dk + r * ld_k + hk * D + d) = o1;
+            *(bf16x8*)(dk + r * ld_k + hk * D + half + d) = o2;
+        } else {
+            const int64_t j = i - n_k;
+            const int v = (int)(j % vv);
+            const int64_t r = j / vv;
+            const int hk = (v * 8) / D, d = (v * 8) % D;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int g = 0; g < P; ++g) {
+                const bf16x8 t = *(const bf16x8*)(pv + r * pw + (hk * P + g) * D + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)t[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+            *(bf16x8*)(dv + r * ld_v + hk * D + d) = o;
+        }
     }
 }
 
@@ -1562,8 +1661,11 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
                           int64_t do_hs, int64_t do_rs, const float* LSE, const float* delta, void* dQ, int64_t dq_bs,
                           int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
                           int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
-                          int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream) {
+                          int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream, const void* rope_cos = nullptr,
+                          const void* rope_sin = nullptr, const int* rope_pos = nullptr) {
     AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
+    AFK_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "afk_attn2_bwd_fused_rope: cos and sin tables come together");
+    AFK_REQUIRE(!rope_cos || ((uintptr_t)rope_cos % 16 == 0 && (uintptr_t)rope_sin % 16 == 0), "afk_attn2_bwd_fused_rope: the tables must be 16-byte aligned");
     AFK_REQUIRE(!O || (o_rs % 8 == 0 && o_hs % 8 == 0), "afk_attn2_bwd_fused: O strides must keep 16-byte alignment");
     AFK_REQUIRE(B > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && S > 0 && Spad >= S && Spad % 64 == 0, "afk_attn2_bwd: bad shape");
     AFK_REQUIRE(D == 64 || D == 128, "afk_attn2_bwd: head_dim %d unsupported by the LDS kernels (64/128)", D);
@@ -1582,6 +1684,7 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
     AFK_REQUIRE(!kv_lo || causal, "afk_attn2_bwd: kv_lo (left padding) is defined for causal attention only");
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
+    p.rope_cos = (const bf16*)rope_cos; p.rope_sin = (const bf16*)rope_sin; p.rope_pos = rope_pos;
     hipStream_t st = (hipStream_t)stream;
     // GQA: with few kv heads the dK/dV sweep has too few blocks to fill 256 CUs (decoder: 8x4x8 = 256 long blocks).
     // Given a scratch of 2 * B*S*Hq*D bf16 the sweep runs one block per QUERY head and a reduce folds the group.
@@ -1653,8 +1756,15 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
         const int64_t rows = (int64_t)B * S;
         int g = (int)afk_cdiv(rows * (Hkv * D / 8), 256);
         if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dK, (bf16*)dK, rows, Hkv, P, D, dk_rs);
-        hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dV, (bf16*)dV, rows, Hkv, P, D, dv_rs);
+        if (rope_cos) {
+            const int64_t items = rows * (Hkv * D / 16) + rows * (Hkv * D / 8);
+            int g2 = (int)std::min<int64_t>(afk_cdiv(items, 256), 4096);
+            hipLaunchKernelGGL(gqa_reduce_rope_kernel, dim3(g2), dim3(256), 0, st, pk.dK, pk.dV, (bf16*)dK, (bf16*)dV, rows, Hkv, P, D, dk_rs, dv_rs,
+                               (const bf16*)rope_cos, (const bf16*)rope_sin, rope_pos, S);
+        } else {
+            hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dK, (bf16*)dK, rows, Hkv, P, D, dk_rs);
+            hipLaunchKernelGGL(gqa_reduce_kernel, dim3(g), dim3(256), 0, st, pk.dV, (bf16*)dV, rows, Hkv, P, D, dv_rs);
+        }
     }
     AFK_LAUNCH_CHECK("afk_attn2_bwd");
     return AFK_OK;
@@ -1681,4 +1791,21 @@ extern "C" int afk_attn2_bwd_fused(const void* Q, int64_t q_bs, int64_t q_hs, in
     AFK_REQUIRE(O != nullptr, "afk_attn2_bwd_fused: O is required (use afk_attn2_bwd with a precomputed delta otherwise)");
     return attn2_bwd_impl(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, O, o_bs, o_hs, o_rs, dO, do_bs, do_hs, do_rs, LSE, delta_ws, dQ, dq_bs,
                           dq_hs, dq_rs, dK, dk_bs, dk_hs, dk_rs, dV, dv_bs, dv_hs, dv_rs, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, gqa_scratch, stream);
+}
+
+// afk_attn2_bwd_fused + the backward of the rotary embedding on dQ and dK (the reference rotates q and k before the attention, modeling_qwen2.py:213; its
+// autograd multiplies the incoming gradients by the transposed rotation): cos_t / sin_t [positions, D] bf16 (16-byte aligned), pos [B * S] int32 or null
+// (= row % S).  dQ and dK come out ROTATED - exactly the bits afk_attn2_bwd_fused followed by afk_rope_inplace(backward = 1) on the q and k columns gives;
+// dV is untouched.  Saves the separate pass over dq | dk (29 us per decoder layer at the AF3 shape) and one of the two GQA reduce launches.
+extern "C" int afk_attn2_bwd_fused_rope(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
+                                        int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* O, int64_t o_bs, int64_t o_hs,
+                                        int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs, int64_t do_rs, const float* LSE, float* delta_ws,
+                                        void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs,
+                                        void* dV, int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq,
+                                        int Hkv, int S, int Spad, int D, float scale, int causal, void* gqa_scratch, const void* cos_t, const void* sin_t,
+                                        const int* pos, void* stream) {
+    AFK_REQUIRE(O != nullptr && cos_t && sin_t, "afk_attn2_bwd_fused_rope: O and the cos / sin tables are required");
+    return attn2_bwd_impl(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, O, o_bs, o_hs, o_rs, dO, do_bs, do_hs, do_rs, LSE, delta_ws, dQ, dq_bs,
+                          dq_hs, dq_rs, dK, dk_bs, dk_hs, dk_rs, dV, dv_bs, dv_hs, dv_rs, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, gqa_scratch, stream,
+                          cos_t, sin_t, pos);
 }

@@ -136,6 +136,13 @@ __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 f2bf(float x) { return (bf16)x; }
 // round-trip through bf16 (models the oracle's bf16 tensor boundaries)
 __device__ __forceinline__ float rbf(float x) { return (float)((bf16)x); }
+// rbf whose widening step is integer arithmetic.  hipcc builds with -ffp-contract=fast: for rbf(a * c) + y with bf16-valued a, c, instcombine narrows
+// fptrunc(fmul(fpext a, fpext c)) to a bf16 multiply and the DAG combiner then folds fadd(fpext(fmul a, c), y) into fma(a, c, y) - the product's rounding
+// is gone (found in round 6: 23 % of the fused-RoPE outputs were one ulp off the two-launch form).  With the bits shifted into place there is no fpext to fold.
+__device__ __forceinline__ float rbf_strict(float x) {
+    const bf16 h = (bf16)x;
+    return __uint_as_float((uint32_t)__builtin_bit_cast(unsigned short, h) << 16);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

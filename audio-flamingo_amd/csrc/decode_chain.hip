@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_batched_kerne
         if (g < rot_groups) {
             const int64_t ps = (int64_t)p.pos[m * p.pos_stride] * p.D + row % p.D;
             const float rot = r < HR ? -other : other;
-            const float o = rbf(rbf(mine * (float)p.cos_t[ps]) + rbf(rot * (float)p.sin_t[ps]));
+            const float o = rbf(rbf_strict(mine * (float)p.cos_t[ps]) + rbf_strict(rot * (float)p.sin_t[ps]));   // rbf_strict: contraction-proof (common.h)
             if (row < nq) p.q_out[m * p.ldq + row] = (bf16)o;
             else p.Kc[m * p.k_bs + (int64_t)start * nk + (row - nq)] = (bf16)o;
         } else {
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
         if (g < rot_groups) {
             const int64_t ps = (int64_t)p.pos[m * p.pos_stride] * p.D + row % p.D;
             const float rot = r < HR ? -other : other;
-            const float o = rbf(rbf(mine * (float)p.cos_t[ps]) + rbf(rot * (float)p.sin_t[ps]));
+            const float o = rbf(rbf_strict(mine * (float)p.cos_t[ps]) + rbf_strict(rot * (float)p.sin_t[ps]));   // rbf_strict: contraction-proof (common.h)
             if (row < nq) p.q_out[m * p.ldq + row] = (bf16)o;
             else p.Kc[m * p.k_bs + (int64_t)start * nk + (row - nq)] = (bf16)o;
         } else {

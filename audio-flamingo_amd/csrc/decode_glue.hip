@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void decode_qkv_finish_kernel(const float* __r
             const float a = rbf(sum_splits(ws, splits, stride, (int64_t)m * N + c1) + (float)bias[c1]);
             const float b = rbf(sum_splits(ws, splits, stride, (int64_t)m * N + c2) + (float)bias[c2]);
             const int p = pos[m];
-            const float o1 = rbf(rbf(a * (float)cos_t[(int64_t)p * D + d]) + rbf(-b * (float)sin_t[(int64_t)p * D + d]));
-            const float o2 = rbf(rbf(b * (float)cos_t[(int64_t)p * D + half + d]) + rbf(a * (float)sin_t[(int64_t)p * D + half + d]));
+            const float o1 = rbf(rbf_strict(a * (float)cos_t[(int64_t)p * D + d]) + rbf_strict(-b * (float)sin_t[(int64_t)p * D + d]));   // rbf_strict: contraction-proof (common.h)
+            const float o2 = rbf(rbf_strict(b * (float)cos_t[(int64_t)p * D + half + d]) + rbf_strict(a * (float)sin_t[(int64_t)p * D + half + d]));
             if (head < Hq) {
                 q_out[(int64_t)m * nq + c1] = (bf16)o1;
                 q_out[(int64_t)m * nq + c2] = (bf16)o2;

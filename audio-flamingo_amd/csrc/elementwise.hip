@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ buf, const
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a = (float)x1[e], b = (float)x2[e];
-            o1[e] = (bf16)(rbf(a * (float)c1[e]) + rbf(-sign * b * (float)s1[e]));
-            o2[e] = (bf16)(rbf(b * (float)c2[e]) + rbf(sign * a * (float)s2[e]));
+            o1[e] = (bf16)(rbf_strict(a * (float)c1[e]) + rbf_strict(-sign * b * (float)s1[e]));   // rbf_strict: a contraction-proof rounding point (common.h)
+            o2[e] = (bf16)(rbf_strict(b * (float)c2[e]) + rbf_strict(sign * a * (float)s2[e]));
         }
         *(bf16x4*)x1p = o1;
         *(bf16x4*)x2p = o2;

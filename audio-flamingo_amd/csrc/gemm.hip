@@ -288,10 +288,14 @@ extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* 
     return AFK_OK;
 }
 
+struct RopeEpi { const void *cos_t, *sin_t; const int* pos; int S, cols; };   // afk_gemm_nt_bf16_rope
+
 static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
-                     int res_mod, void* preact_out, float alpha, int flags, void* stream, int splits = 1, void* workspace = nullptr) {
+                     int res_mod, void* preact_out, float alpha, int flags, void* stream, int splits = 1, void* workspace = nullptr,
+                     const RopeEpi* rope = nullptr) {
     AFK_REQUIRE(splits >= 1 && splits <= 64 && (splits == 1 || workspace), "afk_gemm_*_splitk: 1..64 splits, workspace required");
+    AFK_REQUIRE(((flags & AFK_GEMM_ROPE) != 0) == (rope != nullptr), "afk_gemm: AFK_GEMM_ROPE belongs to afk_gemm_nt_bf16_rope");
     AFK_REQUIRE(splits == 1 || splits <= (K + BK - 1) / BK, "afk_gemm_*_splitk: more splits than K tiles");
     const bool gemv = workspace != nullptr && M <= AFK_GEMV_MAX_M && !trans_a && !trans_b;  // skinny-M weight streaming (decode)
     AFK_REQUIRE(!gemv || splits <= (K + 511) / 512, "afk_gemm_nt_bf16_splitk: M <= 16 streams K in blocks of 512: at most ceil(K/512) splits");
@@ -331,6 +335,11 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.gm = g_gm;
     p.splits = splits;
     p.ws = (float*)workspace;
+    p.rope_cos = rope ? (const bf16*)rope->cos_t : nullptr;
+    p.rope_sin = rope ? (const bf16*)rope->sin_t : nullptr;
+    p.rope_pos = rope ? rope->pos : nullptr;
+    p.rope_S = rope ? rope->S : 1;
+    p.rope_cols = rope ? rope->cols : 0;
     {
         const bool f32 = (flags & AFK_GEMM_OUT_F32) != 0;
         bool w = N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)C % (f32 ? 32 : 16) == 0;
@@ -342,13 +351,17 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     // variant choice: the 256x256 ping-pong kernel halves L2->LDS traffic per flop but needs enough tiles to fill 256 CUs
     const int64_t tiles256 = afk_cdiv(M, 256) * afk_cdiv(N, 256);
     const bool use256 = !gemv && (trans_b || (flags & AFK_GEMM_SWIGLU_FWD) || (splits == 1 && (g_variant >= 2 || (g_variant == 0 && tiles256 >= 192))));
+    // the RoPE epilogue exists in the 256 x 256 ping-pong kernel's 16-byte form only: say so instead of running an instantiation without it
+    if (rope && (!use256 || !p.wide || trans_a || trans_b || splits != 1))
+        return afk_set_error(AFK_ERR_UNSUPPORTED, "afk_gemm_nt_bf16_rope: needs the 256 x 256 NT kernel (>= 192 tiles) in its 16-byte epilogue form; use "
+                                                  "afk_gemm_nt_bf16 + afk_rope_inplace for this shape");
 #ifdef AFK_PROBES
     static const int env_impl = [] {
         const char* e = getenv("AFK_GEMM256");
         return (e && e[0] == 'p' && e[1] == 'e') ? 13 : (e && e[0] == 'p') ? 2 : (e && e[0] == 'w') ? 3 : (e && e[0] == 'f') ? 10 : 0;  // pp | persist | w4 | f8
     }();
     // the fused SwiGLU forward exists in the ping-pong kernel only: it never takes a probe schedule
-    const int impl256 = (flags & AFK_GEMM_SWIGLU_FWD) ? 2 : g_variant >= 2 ? g_variant : (env_impl ? env_impl : g_256_impl);   // 2 pp | 3..9 w4 family | 10, 11 f8
+    const int impl256 = (flags & (AFK_GEMM_SWIGLU_FWD | AFK_GEMM_ROPE)) ? 2 : g_variant >= 2 ? g_variant : (env_impl ? env_impl : g_256_impl);   // 2 pp | 3..9 w4 family | 10, 11 f8
     const bool w4 = use256 && !trans_b && impl256 >= 3 && impl256 <= 9;
     const bool f8 = use256 && !trans_b && impl256 >= 10 && impl256 <= 12;
     const bool persist = use256 && !trans_b && impl256 == 13;
@@ -423,6 +436,15 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
                                 int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
                                 int res_mod, void* preact_out, float alpha, int flags, void* stream) {
     return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, res_mod, preact_out, alpha, flags, stream);
+}
+
+extern "C" int afk_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, const void* bias,
+                                     const void* cos_t, const void* sin_t, const int* pos, int S, int rope_cols, void* stream) {
+    AFK_REQUIRE(cos_t && sin_t && (uintptr_t)cos_t % 16 == 0 && (uintptr_t)sin_t % 16 == 0, "afk_gemm_nt_bf16_rope: cos / sin tables (16-byte aligned) are required");
+    AFK_REQUIRE(N % 256 == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % 256 == 0 && S > 0,
+                "afk_gemm_nt_bf16_rope: N and rope_cols must be multiples of 256 (two 128-column heads per tile), S > 0");
+    const RopeEpi r = {cos_t, sin_t, pos, S, rope_cols};
+    return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, 0, nullptr, 1.f, AFK_GEMM_ROPE | (bias ? AFK_GEMM_BIAS : 0), stream, 1, nullptr, &r);
 }
 
 extern "C" int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

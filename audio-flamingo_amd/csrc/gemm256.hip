@@ -270,6 +270,71 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
         }
         return;
     }
+    if constexpr (EPI >= 0 && (EPI & AFK_GEMM_ROPE) != 0) {
+        // qkv projection + rotary embedding (afk_gemm_nt_bf16_rope).  A 256-column tile holds two heads of 128 columns: waves wn = 0, 1 (2, 3) own the first /
+        // second 64 columns of head 0 (1) for the same rows - each wave rounds its Linear output (+ bias) to bf16, parks the 16 pieces in the idle operand
+        // buffers, and after the barrier takes its partner's (wn ^ 1: the rotate-half column d +- 64 of the same row) and applies rope_kernel's arithmetic
+        // (elementwise.hip, sign = +1): x1' = bf16(bf16(x1 c) + bf16(-x2 s)), x2' = bf16(bf16(x2 c) + bf16(x1 s)).  Tiles right of rope_cols (the v heads) skip
+        // the exchange.  Bit-identical to the two-launch form.
+        typedef __attribute__((ext_vector_type(8))) __bf16 b8;
+        const bool rot = n0 < p.rope_cols;                               // block-uniform
+        char* mine = smem + (wm * 4 + wn) * 16384 + lane * 16;           // piece q at + q * 1024
+        const char* theirs = smem + (wm * 4 + (wn ^ 1)) * 16384 + lane * 16;
+        b8 pc[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int n = n0 + wn * 64 + j * 32 + 16 * t + 8 * hi;
+                    b8 bv;
+                    if constexpr ((EPI & AFK_GEMM_BIAS) != 0) bv = *(const b8*)(p.bias + n);
+                    b8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * t + e]), __float_as_uint(acc[i][j][8 * t + 4 + e]), false, false);
+                        float v0 = __uint_as_float(r[0]) * p.alpha, v1 = __uint_as_float(r[1]) * p.alpha;
+                        if constexpr ((EPI & AFK_GEMM_BIAS) != 0) {
+                            v0 += (float)bv[e];
+                            v1 += (float)bv[4 + e];
+                        }
+                        o[e] = (bf16)v0;
+                        o[4 + e] = (bf16)v1;
+                    }
+                    pc[(i * 2 + j) * 2 + t] = o;
+                }
+        if (rot) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) *(b8*)(mine + q * 1024) = pc[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 128 + i * 32 + l31;
+            const int mc = min(m, p.M - 1);
+            const int64_t pr = p.rope_pos ? p.rope_pos[mc] : mc % p.rope_S;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q = (i * 2 + j) * 2 + t;
+                    const int cl = wn * 64 + j * 32 + 16 * t + 8 * hi;   // column inside the tile
+                    b8 o = pc[q];
+                    if (rot) {
+                        const int d = cl & 127;                            // column inside the head (this wave's half: d < 64 for wn even)
+                        const b8 other = *(const b8*)(theirs + q * 1024);
+                        const b8 c = *(const b8*)(p.rope_cos + pr * 128 + d), sn = *(const b8*)(p.rope_sin + pr * 128 + d);
+                        const float sg = (wn & 1) ? 1.f : -1.f;            // first half: x1 c - x2 s; second half: x2 c + x1 s
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)   // rbf_strict: see common.h (fp-contract would fuse one product into the add)
+                            o[e] = (bf16)(rbf_strict((float)pc[q][e] * (float)c[e]) + rbf_strict(sg * (float)other[e] * (float)sn[e]));
+                    }
+                    if (m < p.M) *(b8*)((bf16*)p.C + (int64_t)m * p.ldc + n0 + cl) = o;
+                }
+        }
+        return;
+    }
     // ---- epilogue: lane holds row m = ..+l31 and n = ..+8q+4hi+{0..3}
     if (AFK_GM_NOEPI(p)) return;  // -DAFK_PROBES builds only: timing probe (afk_gemm_set_variant(2 + 256 * 0x40), wrong results): the kernel without its epilogue
 #pragma unroll
@@ -282,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
 
 // the epilogues of the AF3 training step get their own instantiation; anything else (SwiGLU backward, fp32 output, narrow stores) the generic one
 #define AFK_EPI_LIST(X) X(0) X(AFK_GEMM_BIAS) X(AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_RESIDUAL) X(AFK_GEMM_BIAS | AFK_GEMM_GELU) \
-    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(AFK_GEMM_SWIGLU_FWD) X(AFK_GEMM_SWIGLU_BWD) X(-1)
+    X(AFK_GEMM_BIAS | AFK_GEMM_GELU | AFK_GEMM_RESIDUAL) X(AFK_GEMM_ACCUM) X(AFK_GEMM_SWIGLU_FWD) X(AFK_GEMM_SWIGLU_BWD) X(AFK_GEMM_ROPE) X(AFK_GEMM_ROPE | AFK_GEMM_BIAS) X(-1)
 
 int afk_launch_gemm256(const GemmArgs& p, hipStream_t st) {
     static bool attr_set = false;

@@ -20,6 +20,11 @@ struct GemmArgs {
     int splits;  // split-K: blockIdx.y = split, raw fp32 partial sums go to ws[split][M][N]
     float* ws;
     int wide;    // 16-byte epilogue accesses are legal (N % 8 == 0 and every epilogue pointer / leading dimension 16-byte aligned)
+    // AFK_GEMM_ROPE (afk_gemm_nt_bf16_rope): rotate-half RoPE on output columns [0, rope_cols), heads of 128 columns
+    const bf16* rope_cos;
+    const bf16* rope_sin;
+    const int* rope_pos;   // [M] or null (row % rope_S)
+    int rope_S, rope_cols;
 };
 
 // Probe bits of GemmArgs::gm (bit 6 = kernel WITHOUT its epilogue: wrong results; bit 7 = raw dispatch order) and the three rejected 256x256

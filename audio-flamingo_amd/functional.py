@@ -345,8 +345,8 @@ class DecoderLayerFn:
     def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None, kv_lo=None):
         A = lambda k: arena[pfx + k]
         h, rstd1 = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
-        qkv = ops.gemm_nt(h, A("self_attn.qkv.weight").data, bias=A("self_attn.qkv.bias").data)
-        ops.rope_(qkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos)
+        # qkv projection with the rotary embedding in the GEMM's epilogue where the shape allows (ops.gemm_nt_rope, round 6)
+        qkv = ops.gemm_nt_rope(h, A("self_attn.qkv.weight").data, A("self_attn.qkv.bias").data, cos, sin, S=S, rope_cols=(Hq + Hkv) * D, D=D, pos=pos)
         if krange is not None:  # left-padded rows (the reference processor's default): per-query key intervals [lo_b, min(i + 1, hi_b))
             o, lse = ops.attn_interval_fwd(qkv, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
         else:
@@ -391,9 +391,11 @@ class DecoderLayerFn:
         if krange is not None:
             dqkv = ops.attn_interval_bwd(qkv, o, do, lse, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
         else:
-            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+            # the rotary backward rides in the dQ epilogue / the GQA reduce (ops.attn_bwd(rope=...), round 6): no separate pass over dq | dk
+            dqkv = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo, rope=(cos, sin, pos))
         del do
-        ops.rope_(dqkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos, backward=True)
+        if krange is not None:
+            ops.rope_(dqkv, cos, sin, S=S, nheads=Hq + Hkv, D=D, pos=pos, backward=True)
         dh = linear_bwd(arena, dqkv, h, pfx + "self_attn.qkv.weight", bkey=pfx + "self_attn.qkv.bias")
         del dqkv
         nw = A("input_layernorm.weight")

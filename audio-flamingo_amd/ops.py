@@ -39,6 +39,27 @@ def pad64(n: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------- GEMM
+GEMM_FUSE_ROPE = os.environ.get("AFK_FUSE_ROPE_FWD", "1") != "0"   # rotary embedding inside the qkv GEMM's epilogue (afk_gemm_nt_bf16_rope, round 6)
+
+
+def gemm_nt_rope(a, b, bias, cos, sin, *, S, rope_cols, D, pos=None):
+    """qkv = a @ b^T + bias with rotate-half RoPE on the first rope_cols columns (heads of D columns): one launch (afk_gemm_nt_bf16_rope) when the shape allows -
+    head_dim 128, N and rope_cols multiples of 256, enough tiles for the 256 x 256 kernel - else afk_gemm_nt_bf16 + afk_rope_inplace.  The same bits either way
+    (tests/test_ops_gpu.py::test_gemm_rope_epilogue_bit_equal)."""
+    M, N, K = a.shape[0], b.shape[0], a.shape[1]
+    fused = (GEMM_FUSE_ROPE and D == 128 and N % 256 == 0 and rope_cols % 256 == 0 and K % 64 == 0 and ((M + 255) // 256) * (N // 256) >= 192
+             and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0 and a.stride(1) == 1 and b.stride(1) == 1)
+    if fused:
+        _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b"), _chk(cos, BF16, "rope cos"), _chk(sin, BF16, "rope sin")
+        out = torch.empty((M, N), device=a.device, dtype=BF16)
+        _lib.call("afk_gemm_nt_bf16_rope", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                  _p(bias), cos.data_ptr(), sin.data_ptr(), _p(pos), S, rope_cols, _stream())
+        return out
+    out = gemm_nt(a, b, bias=bias)
+    rope_(out, cos, sin, S=S, nheads=rope_cols // D, D=D, pos=pos)
+    return out
+
+
 def gemm_nt(a, b, out=None, *, bias=None, residual=None, res_mod=0, gelu=False, preact_out=None, out_f32=False,
             accumulate=False, alpha=1.0, M=None, N=None, K=None, swiglu_bwd=None, swiglu_fwd_out=None):
     """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T).  a, b: 2-D bf16 with unit inner stride (row stride free).
@@ -534,8 +555,11 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
     return o, lse
 
 
-def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
-    """-> dqkv [B*S, (Hq+2Hkv)*D]"""
+ATTN_FUSE_ROPE_BWD = os.environ.get("AFK_FUSE_ROPE_BWD", "1") != "0"   # rotary backward inside the attention backward (afk_attn2_bwd_fused_rope, round 6)
+
+
+def _attn_bwd_impl(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None, rope=None):
+    """-> (dqkv, rotated): rotated = the rotary backward has been applied inside the kernels"""
     if kv_lo is not None and not (_use_lds(D) and causal and lse.shape[-1] == pad64(S)):
         raise _lib.AfkError("attn_bwd: kv_lo (left padding) runs on the LDS-staged causal kernels only; use attn_interval_bwd")
     ld = qkv.stride(0)
@@ -553,19 +577,27 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, k
     if _use_lds(D) and lse.shape[-1] == spad:
         delta = _row_stat_buffer(B, Hq, S, spad, dev, kernel_writes_tail=ATTN_FUSE_DELTA)
         scratch = torch.empty((2, B * S, Hq * D), device=dev, dtype=BF16) if Hq != Hkv else None
+        if ATTN_FUSE_DELTA and rope is not None and ATTN_FUSE_ROPE_BWD and rope[0].data_ptr() % 16 == 0 and rope[1].data_ptr() % 16 == 0:
+            cos, sin, pos = rope
+            _chk(cos, BF16, "rope cos"), _chk(sin, BF16, "rope sin")
+            _lib.call("afk_attn2_bwd_fused_rope", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
+                      o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
+                      dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
+                      float(scale), int(causal), _p(scratch), cos.data_ptr(), sin.data_ptr(), _p(pos), _stream())
+            return dqkv, True
         if ATTN_FUSE_DELTA:   # delta = rowsum(dO o O) inside the dQ kernel, which runs ahead of the dK/dV sweep: one pass over O and dO less
             _lib.call("afk_attn2_bwd_fused", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                       o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
                       dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
                       float(scale), int(causal), _p(scratch), _stream())
-            return dqkv
+            return dqkv, False
         _lib.call("afk_attn2_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S,
                   spad, D, _stream())
         _lib.call("afk_attn2_bwd", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                   do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
                   dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
                   float(scale), int(causal), _p(scratch), _stream())
-        return dqkv
+        return dqkv, False
     delta = torch.empty((B, Hq, S), device=dev, dtype=torch.float32)
     _lib.call("afk_attn_delta", o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, delta.data_ptr(), B, Hq, S, D,
               _stream())
@@ -576,6 +608,16 @@ def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, k
               do.data_ptr(), S * ldo, D, ldo, qt.data_ptr(), kt.data_ptr(), dot.data_ptr(), lse.data_ptr(), delta.data_ptr(),
               dq.data_ptr(), S * ldd, D, ldd, dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len),
               B, Hq, Hkv, S, spad, D, float(scale), int(causal), _stream())
+    return dqkv, False
+
+
+def attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None, rope=None):
+    """-> dqkv [B*S, (Hq+2Hkv)*D].  rope = (cos, sin, pos or None): the gradient of the rotary embedding is applied to the q | k columns as well - inside the
+    attention backward kernels where the path allows (afk_attn2_bwd_fused_rope: LDS kernels with the fused delta), by afk_rope_inplace(backward) otherwise:
+    the same bits either way (tests/test_ops_gpu.py::test_attention_backward_fused_rope_bit_equal)."""
+    dqkv, rotated = _attn_bwd_impl(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=scale, causal=causal, kv_len=kv_len, kv_lo=kv_lo, rope=rope)
+    if rope is not None and not rotated:
+        rope_(dqkv, rope[0], rope[1], S=S, nheads=Hq + Hkv, D=D, pos=rope[2], backward=True)
     return dqkv
 
 

@@ -973,6 +973,80 @@ def test_attention_schedules_bit_equal(dev, B, S, Hq, Hkv, D, causal, pad):
         assert torch.equal(base[2], r[2]), f"dQKV differs: (schedule, xcd map) = {key}"
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,parts,with_pos,pad", [(8, 1024, 28, 4, 128, 0, False, None), (2, 1000, 28, 4, 128, 7, True, "left"), (2, 384, 8, 8, 128, 0, True, None),
+                                                              (3, 520, 8, 2, 64, 1, False, "right"), (1, 2113, 28, 4, 128, 3, True, None), (2, 200, 4, 1, 128, 2, False, None)])
+def test_attention_backward_fused_rope_bit_equal(dev, B, S, Hq, Hkv, D, parts, with_pos, pad):
+    """round 6: the rotary backward inside the attention backward (afk_attn2_bwd_fused_rope: dQ rotated in the dQ kernel's epilogue, dK in the combined GQA
+    reduce - or in the sweep's epilogue when it writes the final dK: MHA, one part) gives EXACTLY the bits of afk_attn2_bwd_fused followed by
+    afk_rope_inplace(backward) on the q | k columns; dV untouched.  GQA with 7 / 3 / 2 / 1 parts, MHA, explicit positions (left-padded rows), head_dim 64."""
+    from audio_flamingo_amd import _lib
+
+    ops = _ops()
+    qkv = _rand((B * S, (Hq + 2 * Hkv) * D), dev, 0.5, 21).to(BF)
+    do = _rand((B * S, Hq * D), dev, 0.5, 22).to(BF)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    fr = torch.arange(S + 8, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    kv_len = kv_lo = pos = None
+    if pad == "right":
+        kv_len = torch.tensor([S - 23 * (i + 1) for i in range(B)], device=dev, dtype=torch.int32)
+    elif pad == "left":
+        kv_lo = torch.tensor([17 + 50 * i for i in range(B)], device=dev, dtype=torch.int32)
+    if with_pos:
+        lo = kv_lo if kv_lo is not None else torch.zeros(B, device=dev, dtype=torch.int32)
+        pos = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] - lo[:, None]).clamp_min(0).reshape(-1).contiguous()
+    o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+    old = ops.ATTN_FUSE_ROPE_BWD
+    try:
+        _lib.call("afk_attn_set_dkdv_parts", parts)
+        ops.ATTN_FUSE_ROPE_BWD = False
+        ref = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo, rope=(cos, sin, pos))
+        plain = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
+        ops.ATTN_FUSE_ROPE_BWD = True
+        for _ in range(2):
+            got = ops.attn_bwd(qkv, o, do, lse, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo, rope=(cos, sin, pos))
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    finally:
+        ops.ATTN_FUSE_ROPE_BWD = old
+        _lib.call("afk_attn_set_dkdv_parts", 0)
+    nqk = (Hq + Hkv) * D
+    assert torch.equal(got[:, nqk:], plain[:, nqk:]) and not torch.equal(got[:, :nqk], plain[:, :nqk])   # dV untouched, dq | dk really rotated
+
+
+@pytest.mark.parametrize("M,S,Hq,Hkv,K,with_pos,with_bias", [(8192, 1024, 28, 4, 3584, False, True), (7774, 7774, 28, 4, 3584, True, True), (6000, 750, 14, 2, 1024, True, False),
+                                                             (3000, 1000, 28, 4, 512, False, True)])
+def test_gemm_rope_epilogue_bit_equal(dev, M, S, Hq, Hkv, K, with_pos, with_bias):
+    """round 6: the qkv projection with the rotary embedding in the 256 x 256 GEMM's epilogue (afk_gemm_nt_bf16_rope: the two 64-column halves of a head sit in
+    neighbouring waves, which trade their bf16-rounded Linear outputs through LDS) == afk_gemm_nt_bf16 + afk_rope_inplace bit for bit: q and k heads rotated,
+    v columns untouched, ragged M, explicit positions, with and without bias."""
+    ops = _ops()
+    D = 128
+    N, rc = (Hq + 2 * Hkv) * D, (Hq + Hkv) * D
+    a = _rand((M, K), dev, 1.0, 31).to(BF)
+    w = _rand((N, K), dev, K ** -0.5, 32).to(BF)
+    bias = _rand((N,), dev, 0.5, 33).to(BF) if with_bias else None
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    fr = torch.arange(S + 16, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    pos = ((torch.arange(M, device=dev, dtype=torch.int32) * 7) % (S + 16)).contiguous() if with_pos else None
+    old = ops.GEMM_FUSE_ROPE
+    try:
+        ops.GEMM_FUSE_ROPE = False
+        ref = ops.gemm_nt_rope(a, w, bias, cos, sin, S=S, rope_cols=rc, D=D, pos=pos)
+        plain = ops.gemm_nt(a, w, bias=bias)
+        ops.GEMM_FUSE_ROPE = True
+        for _ in range(2):
+            got = ops.gemm_nt_rope(a, w, bias, cos, sin, S=S, rope_cols=rc, D=D, pos=pos)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    finally:
+        ops.GEMM_FUSE_ROPE = old
+    assert torch.equal(got[:, rc:], plain[:, rc:]) and not torch.equal(got[:, :rc], plain[:, :rc])
+
+
 @pytest.mark.parametrize("D,Hq,Hkv,B", [(128, 28, 4, 8), (64, 4, 2, 16), (128, 8, 2, 8)])
 def test_attn_decode_group_kernel_bit_equal(dev, D, Hq, Hkv, B):
     """round 5: batched decode attention - ONE block per (sample, KV head, key chunk) serves all Hq / Hkv query heads (attn_decode_group_kernel, taken by
