@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) AFK_CHAIN_WPE_ATTR void gemv_
         if (g < rot_groups) {
             // rotate_half (modeling_qwen2.py:112-135): first half  a cos - b sin,  second half  b cos + a sin  - three bf16 roundings each
             const float rot = er < HR ? -other : other;
-            const float o = rbf(rbf(mine * e_cos) + rbf(rot * e_sin));
+            const float o = rbf(rbf_strict(mine * e_cos) + rbf_strict(rot * e_sin));   // rbf_strict: contraction-proof (common.h)
             if (erow < nq) p.q_out[erow] = (bf16)o;
             else p.Kc[(int64_t)e_start * nk + (erow - nq)] = (bf16)o;
         } else {

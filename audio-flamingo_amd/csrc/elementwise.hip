@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float t = rbf(tanhf((float)alpha[alpha_vec ? 8 * v + e : 0]));  // tanh of a bf16 parameter is a bf16 tensor in the oracle
-            const float g = on ? rbf(t * (float)hv[e]) : 0.f;
+            const float g = on ? rbf_strict(t * (float)hv[e]) : 0.f;   // rbf_strict: the product's rounding must survive fp-contract (common.h)
             o[e] = (bf16)((float)xv[e] + g);
         }
         *(bf16x8*)(y + r * D + 8 * v) = o;
