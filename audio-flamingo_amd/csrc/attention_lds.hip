@@ -55,6 +55,11 @@ struct AttnArgs2 {
     const bf16* rope_cos;   // [positions, D] bf16 tables (null: no rotation)
     const bf16* rope_sin;
     const int* rope_pos;    // [B * S] position of every row (null: row % S)
+    // lane-major copies of the tables (nullable; only read when rope_pos is null): element ((((rb * 2 + h2) * (D / 16) + j) * 2 + hi) * 32 + l31) * 4 + e =
+    // table[32 rb + l31][h2 * D/2 + 8 j + 4 hi + e] - what lane (l31, hi) of a wave on rows 32 rb .. 32 rb + 31 needs for accumulator piece j is 8 bytes next
+    // to its neighbours' (a row-per-lane read of the [positions, D] table touches 32 cache lines per instruction and re-requests every line 8 times)
+    const bf16* rope_cos_lanes;
+    const bf16* rope_sin_lanes;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -114,16 +119,24 @@ __device__ __forceinline__ void store_block32(bf16* rowp, const f32x16& acc, flo
 // the rotate-half partner d + D/2 is block dt + DT/2, same register, same lane).  Rounding points of rope_kernel (elementwise.hip) with sign = -1: the incoming
 // gradient is a bf16 tensor (acc x mul rounded), every product is rounded, the sum is rounded - so the accumulators leave as exactly-representable bf16 values
 // and the caller stores them with mul = 1.  ctab / stab = the row's cos / sin table rows (D entries each).
-template <int DT>
-__device__ __forceinline__ void rope_bwd_rows(f32x16 (&acc)[DT], float mul, const bf16* ctab, const bf16* stab, int hi) {
+// LANES: ctab / stab point at the wave's 32-row block of the lane-major tables (AttnArgs2::rope_cos_lanes) and l31 selects the lane's row
+template <int DT, bool LANES = false>
+__device__ __forceinline__ void rope_bwd_rows(f32x16 (&acc)[DT], float mul, const bf16* ctab, const bf16* stab, int hi, int l31 = 0) {
     constexpr int HB = DT / 2;   // blocks per half head
 #pragma unroll
     for (int dt = 0; dt < HB; ++dt)
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const int d0 = 32 * dt + 8 * qd + 4 * hi;
-            const bf16x4 c1 = *(const bf16x4*)(ctab + d0), s1 = *(const bf16x4*)(stab + d0);
-            const bf16x4 c2 = *(const bf16x4*)(ctab + 16 * DT + d0), s2 = *(const bf16x4*)(stab + 16 * DT + d0);
+            bf16x4 c1, s1, c2, s2;
+            if constexpr (LANES) {
+                const int o1 = (((dt * 4 + qd) * 2 + hi) * 32 + l31) * 4, o2 = o1 + 2 * DT * 2 * 32 * 4;   // h2 = 1: + (D / 16) pieces x 2 x 32 x 4
+                c1 = *(const bf16x4*)(ctab + o1); s1 = *(const bf16x4*)(stab + o1);
+                c2 = *(const bf16x4*)(ctab + o2); s2 = *(const bf16x4*)(stab + o2);
+            } else {
+                c1 = *(const bf16x4*)(ctab + d0); s1 = *(const bf16x4*)(stab + d0);
+                c2 = *(const bf16x4*)(ctab + 16 * DT + d0); s2 = *(const bf16x4*)(stab + 16 * DT + d0);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a = rbf_strict(acc[dt][4 * qd + e] * mul), b = rbf_strict(acc[dt + HB][4 * qd + e] * mul);   // rbf_strict: see common.h (fp-contract)
@@ -1039,8 +1052,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_lds_kernel(AttnArgs2 p) {
         bf16* dQp = p.dQ + b * p.dq_bs + h * p.dq_hs + (int64_t)q * p.dq_rs;
         float mul = p.scale;   // (softmax scale folded out of dS)
         if (p.rope_cos) {
-            const int64_t pr = p.rope_pos ? p.rope_pos[(int64_t)b * p.S + q] : q;
-            rope_bwd_rows<DT>(dqacc, mul, p.rope_cos + pr * D, p.rope_sin + pr * D, hi);
+            if (p.rope_cos_lanes && !p.rope_pos) {   // positions = row index: the wave's rows q0 .. q0 + 31 are ONE 32-row block of the lane-major tables
+                const int64_t rb = (int64_t)(q0 >> 5) * 32 * D;
+                rope_bwd_rows<DT, true>(dqacc, mul, p.rope_cos_lanes + rb, p.rope_sin_lanes + rb, hi, l31);
+            } else {
+                const int64_t pr = p.rope_pos ? p.rope_pos[(int64_t)b * p.S + q] : q;
+                rope_bwd_rows<DT>(dqacc, mul, p.rope_cos + pr * D, p.rope_sin + pr * D, hi);
+            }
             mul = 1.f;
         }
         if (p.wide) {
@@ -1488,6 +1506,29 @@ __global__ __launch_bounds__(256) void gqa_reduce_rope_kernel(const bf16* __rest
     }
 }
 
+// lane-major copy of a [rows, D] rotary table (AttnArgs2::rope_cos_lanes): out has ceil(rows / 32) * 32 * D elements, rows beyond `rows` read zero.
+// form 1 = the qkv GEMM epilogue's layout (GemmArgs::rope_cos_lanes): element ((rb * (D / 8) + c) * 32 + l31) * 8 + e = table[32 rb + l31][8 c + e]
+__global__ __launch_bounds__(256) void rope_lanes_kernel(const bf16* __restrict__ tab, bf16* __restrict__ out, int rows, int D, int form) {
+    const int64_t total = (int64_t)((rows + 31) / 32) * 32 * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (form == 1) {
+            const int e = (int)(i & 7), l31 = (int)((i >> 3) & 31);
+            const int64_t t = i >> 8;   // rb * (D / 8) + c
+            const int c = (int)(t % (D / 8));
+            const int64_t r = (t / (D / 8)) * 32 + l31;
+            out[i] = r < rows ? tab[r * D + 8 * c + e] : (bf16)0.f;
+            continue;
+        }
+        const int e = (int)(i & 3), l31 = (int)((i >> 2) & 31), hi = (int)((i >> 7) & 1);
+        const int PH = D / 16;      // 8-column pieces per half head
+        const int64_t t = i >> 8;   // (rb * 2 + h2) * PH + j
+        const int j = (int)(t % PH), h2 = (int)((t / PH) & 1);
+        const int64_t rb = t / PH / 2;
+        const int64_t r = rb * 32 + l31;
+        out[i] = r < rows ? tab[r * D + h2 * (D / 2) + 8 * j + 4 * hi + e] : (bf16)0.f;
+    }
+}
+
 // AFK_ATTN_WIDE=0: the 8-byte epilogue stores of rounds 1-3 (A/B)
 bool attn_wide_stores() {
     static const bool on = [] { const char* e = getenv("AFK_ATTN_WIDE"); return !(e && e[0] == '0'); }();
@@ -1662,7 +1703,7 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
                           int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs, void* dV,
                           int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq, int Hkv, int S,
                           int Spad, int D, float scale, int causal, void* gqa_scratch, void* stream, const void* rope_cos = nullptr,
-                          const void* rope_sin = nullptr, const int* rope_pos = nullptr) {
+                          const void* rope_sin = nullptr, const int* rope_pos = nullptr, const void* rope_cos_lanes = nullptr, const void* rope_sin_lanes = nullptr) {
     AFK_REQUIRE(Q && K && V && dO && LSE && delta && dQ && dK && dV, "afk_attn2_bwd: null pointer");
     AFK_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr), "afk_attn2_bwd_fused_rope: cos and sin tables come together");
     AFK_REQUIRE(!rope_cos || ((uintptr_t)rope_cos % 16 == 0 && (uintptr_t)rope_sin % 16 == 0), "afk_attn2_bwd_fused_rope: the tables must be 16-byte aligned");
@@ -1685,6 +1726,9 @@ static int attn2_bwd_impl(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_r
     p.LSE = (float*)LSE; p.delta = delta; p.kv_len = kv_len; p.kv_lo = kv_lo;
     p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.S = S; p.Spad = Spad; p.scale = scale; p.causal = causal;
     p.rope_cos = (const bf16*)rope_cos; p.rope_sin = (const bf16*)rope_sin; p.rope_pos = rope_pos;
+    AFK_REQUIRE((rope_cos_lanes == nullptr) == (rope_sin_lanes == nullptr) && (!rope_cos_lanes || (rope_cos && (uintptr_t)rope_cos_lanes % 8 == 0 && (uintptr_t)rope_sin_lanes % 8 == 0)),
+                "afk_attn2_bwd_fused_rope: the lane-major tables come as a pair, beside the plain ones");
+    p.rope_cos_lanes = (const bf16*)rope_cos_lanes; p.rope_sin_lanes = (const bf16*)rope_sin_lanes;
     hipStream_t st = (hipStream_t)stream;
     // GQA: with few kv heads the dK/dV sweep has too few blocks to fill 256 CUs (decoder: 8x4x8 = 256 long blocks).
     // Given a scratch of 2 * B*S*Hq*D bf16 the sweep runs one block per QUERY head and a reduce folds the group.
@@ -1803,9 +1847,20 @@ extern "C" int afk_attn2_bwd_fused_rope(const void* Q, int64_t q_bs, int64_t q_h
                                         void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs,
                                         void* dV, int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq,
                                         int Hkv, int S, int Spad, int D, float scale, int causal, void* gqa_scratch, const void* cos_t, const void* sin_t,
-                                        const int* pos, void* stream) {
+                                        const int* pos, const void* cos_lanes, const void* sin_lanes, void* stream) {
     AFK_REQUIRE(O != nullptr && cos_t && sin_t, "afk_attn2_bwd_fused_rope: O and the cos / sin tables are required");
     return attn2_bwd_impl(Q, q_bs, q_hs, q_rs, K, k_bs, k_hs, k_rs, V, v_bs, v_hs, v_rs, O, o_bs, o_hs, o_rs, dO, do_bs, do_hs, do_rs, LSE, delta_ws, dQ, dq_bs,
                           dq_hs, dq_rs, dK, dk_bs, dk_hs, dk_rs, dV, dv_bs, dv_hs, dv_rs, kv_len, kv_lo, B, Hq, Hkv, S, Spad, D, scale, causal, gqa_scratch, stream,
-                          cos_t, sin_t, pos);
+                          cos_t, sin_t, pos, cos_lanes, sin_lanes);
+}
+
+// lane-major copy of a rotary table for afk_attn2_bwd_fused_rope (cos_lanes / sin_lanes): table [rows, D] bf16 -> out [ceil(rows / 32) * 32 * D] bf16.
+// Built once per table (the host caches it beside the table); rows = at least the S of the calls that use it.
+extern "C" int afk_rope_lanes_table(const void* table, void* out, int rows, int D, int form, void* stream) {
+    AFK_REQUIRE(table && out && rows > 0 && (D == 64 || D == 128) && (form == 0 || form == 1), "afk_rope_lanes_table: bad args (D = 64 / 128, form 0 / 1)");
+    const int64_t total = (int64_t)((rows + 31) / 32) * 32 * D;
+    hipLaunchKernelGGL(rope_lanes_kernel, dim3((unsigned)std::min<int64_t>(afk_cdiv(total, 256), 2048)), dim3(256), 0, (hipStream_t)stream, (const bf16*)table, (bf16*)out,
+                       rows, D, form);
+    AFK_LAUNCH_CHECK("afk_rope_lanes_table");
+    return AFK_OK;
 }

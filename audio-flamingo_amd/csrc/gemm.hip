@@ -288,7 +288,7 @@ extern "C" int afk_prof_collect(double* total_ms, double* total_flops, int64_t* 
     return AFK_OK;
 }
 
-struct RopeEpi { const void *cos_t, *sin_t; const int* pos; int S, cols; };   // afk_gemm_nt_bf16_rope
+struct RopeEpi { const void *cos_t, *sin_t; const int* pos; int S, cols; const void *cos_lanes, *sin_lanes; };   // afk_gemm_nt_bf16_rope
 
 static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                      int M, int N, int K, const void* bias, const void* residual, int64_t ldr,
@@ -340,6 +340,10 @@ static int gemm_impl(int trans_a, int trans_b, const void* A, int64_t lda, const
     p.rope_pos = rope ? rope->pos : nullptr;
     p.rope_S = rope ? rope->S : 1;
     p.rope_cols = rope ? rope->cols : 0;
+    // the lane-major copies apply when a 32-row accumulator block never straddles two samples and positions are the row index
+    const bool lanes_ok = rope && rope->cos_lanes && rope->sin_lanes && !rope->pos && rope->S % 32 == 0;
+    p.rope_cos_lanes = lanes_ok ? (const bf16*)rope->cos_lanes : nullptr;
+    p.rope_sin_lanes = lanes_ok ? (const bf16*)rope->sin_lanes : nullptr;
     {
         const bool f32 = (flags & AFK_GEMM_OUT_F32) != 0;
         bool w = N % 8 == 0 && ldc % 8 == 0 && (uintptr_t)C % (f32 ? 32 : 16) == 0;
@@ -439,11 +443,14 @@ extern "C" int afk_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64
 }
 
 extern "C" int afk_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, const void* bias,
-                                     const void* cos_t, const void* sin_t, const int* pos, int S, int rope_cols, void* stream) {
+                                     const void* cos_t, const void* sin_t, const int* pos, int S, int rope_cols, const void* cos_lanes, const void* sin_lanes,
+                                     void* stream) {
     AFK_REQUIRE(cos_t && sin_t && (uintptr_t)cos_t % 16 == 0 && (uintptr_t)sin_t % 16 == 0, "afk_gemm_nt_bf16_rope: cos / sin tables (16-byte aligned) are required");
     AFK_REQUIRE(N % 256 == 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % 256 == 0 && S > 0,
                 "afk_gemm_nt_bf16_rope: N and rope_cols must be multiples of 256 (two 128-column heads per tile), S > 0");
-    const RopeEpi r = {cos_t, sin_t, pos, S, rope_cols};
+    AFK_REQUIRE((cos_lanes == nullptr) == (sin_lanes == nullptr) && (!cos_lanes || ((uintptr_t)cos_lanes % 16 == 0 && (uintptr_t)sin_lanes % 16 == 0)),
+                "afk_gemm_nt_bf16_rope: the lane-major tables come as a 16-byte aligned pair");
+    const RopeEpi r = {cos_t, sin_t, pos, S, rope_cols, cos_lanes, sin_lanes};
     return gemm_impl(0, 0, A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, 0, 0, nullptr, 1.f, AFK_GEMM_ROPE | (bias ? AFK_GEMM_BIAS : 0), stream, 1, nullptr, &r);
 }
 

@@ -314,6 +314,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
             const int m = m0 + wm * 128 + i * 32 + l31;
             const int mc = min(m, p.M - 1);
             const int64_t pr = p.rope_pos ? p.rope_pos[mc] : mc % p.rope_S;
+            // lane-major tables (S % 32 == 0, no explicit positions): the 32 rows of this accumulator block are positions pr0 .. pr0 + 31 of one table block
+            const bool lanes = p.rope_cos_lanes != nullptr;
+            const int64_t lbase = lanes ? (((int64_t)((m0 + wm * 128 + i * 32) % p.rope_S) >> 5) * 16 * 32 + l31) * 8 : 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -324,7 +327,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16_k256(GemmArgs p) {
                     if (rot) {
                         const int d = cl & 127;                            // column inside the head (this wave's half: d < 64 for wn even)
                         const b8 other = *(const b8*)(theirs + q * 1024);
-                        const b8 c = *(const b8*)(p.rope_cos + pr * 128 + d), sn = *(const b8*)(p.rope_sin + pr * 128 + d);
+                        const b8 c = lanes ? *(const b8*)(p.rope_cos_lanes + lbase + (d >> 3) * 256) : *(const b8*)(p.rope_cos + pr * 128 + d);
+                        const b8 sn = lanes ? *(const b8*)(p.rope_sin_lanes + lbase + (d >> 3) * 256) : *(const b8*)(p.rope_sin + pr * 128 + d);
                         const float sg = (wn & 1) ? 1.f : -1.f;            // first half: x1 c - x2 s; second half: x2 c + x1 s
 #pragma unroll
                         for (int e = 0; e < 8; ++e)   // rbf_strict: see common.h (fp-contract would fuse one product into the add)

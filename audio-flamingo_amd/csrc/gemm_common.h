@@ -25,6 +25,8 @@ struct GemmArgs {
     const bf16* rope_sin;
     const int* rope_pos;   // [M] or null (row % rope_S)
     int rope_S, rope_cols;
+    const bf16* rope_cos_lanes;   // afk_rope_lanes_table(form 1) copies (nullable): element ((rb * 16 + c) * 32 + l31) * 8 + e = table[32 rb + l31][8 c + e]
+    const bf16* rope_sin_lanes;
 };
 
 // Probe bits of GemmArgs::gm (bit 6 = kernel WITHOUT its epilogue: wrong results; bit 7 = raw dispatch order) and the three rejected 256x256

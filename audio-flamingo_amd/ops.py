@@ -52,8 +52,10 @@ def gemm_nt_rope(a, b, bias, cos, sin, *, S, rope_cols, D, pos=None):
     if fused:
         _chk(a, BF16, "gemm a"), _chk(b, BF16, "gemm b"), _chk(cos, BF16, "rope cos"), _chk(sin, BF16, "rope sin")
         out = torch.empty((M, N), device=a.device, dtype=BF16)
+        lanes = pos is None and S % 32 == 0 and cos.shape[0] >= S and sin.shape[0] >= S   # positions = row % S and no 32-row block straddles two samples
+        cl, sl = (_rope_lanes(cos, S, D, 1), _rope_lanes(sin, S, D, 1)) if lanes else (None, None)
         _lib.call("afk_gemm_nt_bf16_rope", a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
-                  _p(bias), cos.data_ptr(), sin.data_ptr(), _p(pos), S, rope_cols, _stream())
+                  _p(bias), cos.data_ptr(), sin.data_ptr(), _p(pos), S, rope_cols, _p(cl), _p(sl), _stream())
         return out
     out = gemm_nt(a, b, bias=bias)
     rope_(out, cos, sin, S=S, nheads=rope_cols // D, D=D, pos=pos)
@@ -558,6 +560,27 @@ def attn_fwd(qkv, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None):
 ATTN_FUSE_ROPE_BWD = os.environ.get("AFK_FUSE_ROPE_BWD", "1") != "0"   # rotary backward inside the attention backward (afk_attn2_bwd_fused_rope, round 6)
 
 
+_ROPE_LANES = {}   # (table data_ptr, version, rows, D) -> lane-major copy (afk_rope_lanes_table); a handful of entries (one per table the model caches)
+
+
+def _rope_lanes(table, S, D, form=0):
+    """lane-major copy of a rotary table for the dQ epilogue of afk_attn2_bwd_fused_rope, cached per table tensor (weakly: a new tensor at the same address gets
+    a fresh copy because its version / shape is part of the key and the entry holds a weak reference to the source)"""
+    import weakref
+
+    key = (table.data_ptr(), table._version, int(table.shape[0]), D, form)
+    hit = _ROPE_LANES.get(key)
+    if hit is not None and hit[0]() is table:
+        return hit[1]
+    rows = int(table.shape[0])
+    out = torch.empty(((rows + 31) // 32) * 32 * D, device=table.device, dtype=BF16)
+    _lib.call("afk_rope_lanes_table", table.data_ptr(), out.data_ptr(), rows, D, form, _stream())
+    if len(_ROPE_LANES) > 64:
+        _ROPE_LANES.clear()
+    _ROPE_LANES[key] = (weakref.ref(table), out)
+    return out
+
+
 def _attn_bwd_impl(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=None, kv_lo=None, rope=None):
     """-> (dqkv, rotated): rotated = the rotary backward has been applied inside the kernels"""
     if kv_lo is not None and not (_use_lds(D) and causal and lse.shape[-1] == pad64(S)):
@@ -580,10 +603,11 @@ def _attn_bwd_impl(qkv, o, do, lse, B, S, Hq, Hkv, D, *, scale, causal, kv_len=N
         if ATTN_FUSE_DELTA and rope is not None and ATTN_FUSE_ROPE_BWD and rope[0].data_ptr() % 16 == 0 and rope[1].data_ptr() % 16 == 0:
             cos, sin, pos = rope
             _chk(cos, BF16, "rope cos"), _chk(sin, BF16, "rope sin")
+            cl, sl = _rope_lanes(cos, S, D) if pos is None and cos.shape[0] >= S else None, _rope_lanes(sin, S, D) if pos is None and sin.shape[0] >= S else None
             _lib.call("afk_attn2_bwd_fused_rope", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,
                       o.data_ptr(), S * ldo, D, ldo, do.data_ptr(), S * ldo, D, ldo, lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), S * ldd, D, ldd,
                       dk.data_ptr(), S * ldd, D, ldd, dv.data_ptr(), S * ldd, D, ldd, _p(kv_len), _p(kv_lo), B, Hq, Hkv, S, spad, D,
-                      float(scale), int(causal), _p(scratch), cos.data_ptr(), sin.data_ptr(), _p(pos), _stream())
+                      float(scale), int(causal), _p(scratch), cos.data_ptr(), sin.data_ptr(), _p(pos), _p(cl), _p(sl), _stream())
             return dqkv, True
         if ATTN_FUSE_DELTA:   # delta = rowsum(dO o O) inside the dQ kernel, which runs ahead of the dK/dV sweep: one pass over O and dO less
             _lib.call("afk_attn2_bwd_fused", q.data_ptr(), S * ld, D, ld, k.data_ptr(), S * ld, D, ld, v.data_ptr(), S * ld, D, ld,

@@ -98,9 +98,10 @@ int afk_gemm_bf16(int trans_a, int trans_b, const void* A, int64_t lda, const vo
  * (the q and k heads, 128 columns each) - apply_rotary_pos_emb (modeling_qwen2.py:112-135, called on q and k at :213) with afk_rope_inplace's rounding points
  * (the Linear output is a bf16 tensor, cos / sin are bf16, every product and the sum are rounded): the SAME bits as afk_gemm_nt_bf16 + afk_rope_inplace.
  * cos_t / sin_t [positions, 128] bf16 (16-byte aligned), pos [M] int32 or null (row % S).  Needs head_dim 128, N % 256 == 0, rope_cols % 256 == 0, the 16-byte
- * epilogue form (aligned C, ldc % 8 == 0) and a shape the 256 x 256 kernel takes (AFK_ERR_UNSUPPORTED otherwise: call the two-launch form).  bias nullable. */
+ * epilogue form (aligned C, ldc % 8 == 0) and a shape the 256 x 256 kernel takes (AFK_ERR_UNSUPPORTED otherwise: call the two-launch form).  bias nullable.
+ * cos_lanes / sin_lanes (nullable; used when pos is null and S % 32 == 0): afk_rope_lanes_table(form = 1) copies for coalesced table reads in the epilogue. */
 int afk_gemm_nt_bf16_rope(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, const void* bias,
-                          const void* cos_t, const void* sin_t, const int* pos, int S, int rope_cols, void* stream);
+                          const void* cos_t, const void* sin_t, const int* pos, int S, int rope_cols, const void* cos_lanes, const void* sin_lanes, void* stream);
 int afk_gemm_nt_bf16_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                             const void* bias, const void* residual, int64_t ldr, int res_mod, void* preact_out, float alpha,
                             int flags, int splits, void* workspace, void* stream);
@@ -267,14 +268,20 @@ int afk_attn2_bwd_fused(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs,
 /* afk_attn2_bwd_fused with the BACKWARD of the rotary embedding applied to dQ and dK where their final values are formed (dQ kernel epilogue; GQA reduce or the
  * sweep's epilogue for dK): the reference rotates q and k ahead of the attention (apply_rotary_pos_emb, modeling_qwen2.py:112-135, called at :213) and its
  * autograd applies the transposed rotation to their gradients.  cos_t / sin_t: [positions, D] bf16, 16-byte aligned; pos: [B * S] int32 or null (row % S).
- * Result bits = afk_attn2_bwd_fused followed by afk_rope_inplace(backward = 1) on the q | k columns.  dV is not rotated. */
+ * Result bits = afk_attn2_bwd_fused followed by afk_rope_inplace(backward = 1) on the q | k columns.  dV is not rotated.  cos_lanes / sin_lanes: see
+ * afk_rope_lanes_table below (nullable). */
 int afk_attn2_bwd_fused_rope(const void* Q, int64_t q_bs, int64_t q_hs, int64_t q_rs, const void* K, int64_t k_bs, int64_t k_hs,
                              int64_t k_rs, const void* V, int64_t v_bs, int64_t v_hs, int64_t v_rs, const void* O, int64_t o_bs, int64_t o_hs,
                              int64_t o_rs, const void* dO, int64_t do_bs, int64_t do_hs, int64_t do_rs, const float* LSE, float* delta_ws,
                              void* dQ, int64_t dq_bs, int64_t dq_hs, int64_t dq_rs, void* dK, int64_t dk_bs, int64_t dk_hs, int64_t dk_rs,
                              void* dV, int64_t dv_bs, int64_t dv_hs, int64_t dv_rs, const int* kv_len, const int* kv_lo, int B, int Hq,
                              int Hkv, int S, int Spad, int D, float scale, int causal, void* gqa_scratch, const void* cos_t, const void* sin_t,
-                             const int* pos, void* stream);
+                             const int* pos, const void* cos_lanes, const void* sin_lanes, void* stream);
+/* cos_lanes / sin_lanes above (nullable, used only when pos is null): lane-major copies of the same tables, built by this call - table [rows, D] bf16 ->
+ * out [ceil(rows / 32) * 32 * D] bf16, rows >= S.  With them the dQ epilogue reads its cos / sin pieces coalesced (a wave's 32 rows are one block of the copy);
+ * without them each lane reads its own table row (32 cache lines per instruction).  Same results.
+ * form 0 = the layout of the attention backward's dQ epilogue, form 1 = the layout of afk_gemm_nt_bf16_rope's epilogue (its cos_lanes / sin_lanes). */
+int afk_rope_lanes_table(const void* table, void* out, int rows, int D, int form, void* stream);
 /* gqa_scratch: NULL, or 2*B*S*Hq*D bf16 - enables the one-block-per-query-head dK/dV sweep + group reduce (GQA) */
 
 /* Music Flamingo rotary time embedding on the encoder output (apply_rotary_time_emb, transformers/models/musicflamingo/
