@@ -60,6 +60,8 @@ struct AttnArgs2 {
     // to its neighbours' (a row-per-lane read of the [positions, D] table touches 32 cache lines per instruction and re-requests every line 8 times)
     const bf16* rope_cos_lanes;
     const bf16* rope_sin_lanes;
+    int paired;   // attn_fwd_persist_kernel: 1 = no work queue - block k runs item k, then item total - 1 - k (the paired-tile causal schedule of VERDICT r04 / r05:
+                  // with items ordered longest first every block sweeps the same number of key tiles), grid = ceil(total / 2)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -660,8 +662,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_persist_kernel(AttnArgs2 p, i
     load_q(cur);
     stage_tile(cur, 0, 0);
     AFK_ATTN_BARRIER();
+    int pass = 0;
     while (true) {
-        if (threadIdx.x == 0) s_next = (int)gridDim.x + __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read >= 2 barriers later
+        if (threadIdx.x == 0) {   // read >= 2 barriers later
+            if (p.paired) s_next = (pass == 0 && total_items - 1 - (int)blockIdx.x != (int)blockIdx.x) ? total_items - 1 - (int)blockIdx.x : total_items;
+            else s_next = (int)gridDim.x + __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++pass;
         const int q = cur.qb0 + wave * 32 + l31;
         const int ntiles = p.causal ? (cur.qb0 + 128) >> 6 : p.S >> 6;
         const int n_int = p.causal ? cur.qb0 >> 6 : ntiles;
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_persist_kernel(AttnArgs2 p, i
         }
         if (!has_next) break;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !p.paired) {
         const int gone = __hip_atomic_fetch_add(queue + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (gone == (int)gridDim.x - 1) {   // every block has taken its last ticket: leave the queue ready for the next launch (stream order does the rest)
             __hip_atomic_store(queue, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1536,6 +1543,7 @@ bool attn_wide_stores() {
 }
 
 // AFK_ATTN_SCHED=0: the compiler-scheduled fragment reads of rounds 1-5 (A/B); default 1 = explicit read rings + interleaved LDS-DMA (round 6)
+int g_persist_paired = 0; // afk_attn_set_persist_paired: the persistent forward without its queue, two complementary items per block
 int g_xcd_map = -1;      // -1: not chosen yet (AFK_ATTN_XCD, default 1)
 int attn_xcd_map() {
     if (g_xcd_map < 0) {
@@ -1625,6 +1633,12 @@ extern "C" int afk_attn_set_sched(int sched) {
     return AFK_OK;
 }
 
+extern "C" int afk_attn_set_persist_paired(int on) {
+    AFK_REQUIRE(on == 0 || on == 1, "afk_attn_set_persist_paired: 0 or 1");
+    g_persist_paired = on;
+    return AFK_OK;
+}
+
 extern "C" int afk_attn_set_xcd_map(int on) {
     AFK_REQUIRE(on == 0 || on == 1, "afk_attn_set_xcd_map: 0 or 1");
     g_xcd_map = on;
@@ -1663,13 +1677,15 @@ extern "C" int afk_attn2_fwd_persistent(const void* Q, int64_t q_bs, int64_t q_h
     static const int lsum_env = [] { const char* e = getenv("AFK_ATTN_LSUM"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool lm = lsum_env < 0 ? D == 128 : lsum_env == 1;
     static const int slots_env = [] { const char* e = getenv("AFK_ATTN_PERSIST_BLOCKS"); return e ? atoi(e) : 0; }();
+    p.paired = g_persist_paired;
 #define AFK_FWDP(DD, LM_)                                                                                                \
     do {                                                                                                                 \
         constexpr int L = 4 * Tile<DD>::BYTES;                                                                           \
         static int once = set_lds(attn_fwd_persist_kernel<DD, LM_>, L);                                                  \
         (void)once;                                                                                                      \
         const int slots = slots_env > 0 ? slots_env : 512;   /* two resident blocks per CU (237 / 175-189 VGPRs: two waves per SIMD) */          \
-        hipLaunchKernelGGL((attn_fwd_persist_kernel<DD, LM_>), dim3((unsigned)std::min(total, slots)), dim3(256), L, st, p, queue, total); \
+        const int nblk = p.paired ? (total + 1) / 2 : std::min(total, slots);                                            \
+        hipLaunchKernelGGL((attn_fwd_persist_kernel<DD, LM_>), dim3((unsigned)nblk), dim3(256), L, st, p, queue, total); \
     } while (0)
     if (D == 128) {
         if (lm) AFK_FWDP(128, true); else AFK_FWDP(128, false);

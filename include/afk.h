@@ -237,6 +237,9 @@ int afk_attn_set_sched(int sched);
  * of the work sorted by the K / V stream it reads - the query heads of a GQA group side by side at each causal level, the query blocks of a head back to back
  * when not causal - so that heads sharing K / V share an L2; 0 = the (heads, batch, query blocks) grid of rounds 2-5.  Same blocks, same arithmetic. */
 int afk_attn_set_xcd_map(int on);
+/* afk_attn2_fwd_persistent without its work queue (measurement of the paired-tile causal schedule): 1 = block k computes item k and then item total - 1 - k of
+ * the longest-first item order, so every block sweeps the same number of key tiles; grid = ceil(total / 2).  Same results bit for bit. */
+int afk_attn_set_persist_paired(int on);
 /* GQA dK/dV sweep (afk_attn2_bwd*, gqa_scratch given): number of blocks - and of bf16 partial dK/dV images - per kv head.  Each block sweeps ~group / parts
  * query heads, accumulating in registers; `group` = one block per query head (rounds 2-5).  0 = AFK_ATTN_DKDV_PARTS / the default.  Fewer parts = fewer and
  * longer blocks, fewer partials through HBM, fewer roundings; the result differs from other part counts in the last bf16 bit (summation grouping). */

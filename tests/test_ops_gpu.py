@@ -928,6 +928,18 @@ def test_attention_forward_persistent_form_bit_equal(dev, B, S, Hq, Hkv, D, caus
             torch.cuda.synchronize()
             assert torch.equal(o0, o1) and torch.equal(l0[..., :S], l1[..., :S])
             assert ops._attn_queue(dev).tolist() == [0, 0]
+        # round 6: the same kernel without its queue - block k runs items k and total - 1 - k (the paired-tile causal schedule, afk_attn_set_persist_paired)
+        from audio_flamingo_amd import _lib
+
+        _lib.call("afk_attn_set_persist_paired", 1)
+        try:
+            for _ in range(2):
+                o2, l2 = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=causal)
+                torch.cuda.synchronize()
+                assert torch.equal(o0, o2) and torch.equal(l0[..., :S], l2[..., :S])
+                assert ops._attn_queue(dev).tolist() == [0, 0]
+        finally:
+            _lib.call("afk_attn_set_persist_paired", 0)
     finally:
         ops.ATTN_PERSIST = old
 
