@@ -747,3 +747,60 @@ def test_sharded_optimizer_ownership_map_and_budget_plan_accounting():
     pending = g.plan_checkpointing(20, 15274, resident, total, usable_bytes=140 * 2 ** 30, pending_bytes=20 * 2 ** 30)
     assert roomy["dec"] < tight["dec"] and roomy["dec"] < pending["dec"], (roomy, tight, pending)
     assert g.plan_checkpointing(20, 15274, resident, total)["dec"] <= roomy["dec"]                # unknown device state: the budget alone
+
+
+def _attn_qblock_host(L, Hq, Hkv, B, nz, causal):
+    """host restatement of csrc/attention_lds.hip::attn_qblock (the XCD-aware block -> (sample, head, query block) map of the forward and dQ kernels, round 6)"""
+    n, gsz, T = Hq * B, Hq // Hkv, Hq * B * nz
+    if not causal:
+        if T % 8 == 0:
+            idx = (L & 7) * (T >> 3) + (L >> 3)
+            item, lvl = divmod(idx, nz)
+        else:
+            lvl, item = divmod(L, n)
+    else:
+        k = 1 if n % 8 == 0 else 2 if n % 4 == 0 else 4 if n % 2 == 0 else 8
+        full, c = nz // k, (k * n) >> 3
+        if L < full * k * n:
+            sup, r = divmod(L >> 3, c)
+            idx = (L & 7) * c + r
+            group, rem = divmod(idx, k * gsz)
+            li, hh = divmod(rem, gsz)
+            lvl = sup * k + li
+            item = (group // Hkv) * Hq + (group % Hkv) * gsz + hh
+        else:
+            lvl, item = divmod(L - full * k * n, n)
+            lvl += full * k
+    b, h = divmod(item, Hq)
+    return b, h, (nz - 1 - lvl if causal else lvl)
+
+
+def test_attention_xcd_block_map_is_a_bijection_and_keeps_gqa_groups_on_one_xcd():
+    """round 6: the forward / dQ kernels run on a 1-D grid whose block L lands on XCD L % 8; the map must (i) visit every (sample, head, query block) exactly once
+    for every head layout / batch / block count - including counts that do not divide by 8 -, (ii) at the AF3 decoder shape give every XCD whole GQA groups (4 of the
+    32 (sample, kv head) pairs: 2 MB of K / V in a 4 MB L2) and dispatch the long causal blocks first, (iii) with B = 1 give an XCD pair one kv head.  The device
+    function is exercised by tests/test_ops_gpu.py::test_attention_schedules_bit_equal (same bits with the map on and off); this is its host restatement."""
+    for Hq, Hkv in ((28, 4), (20, 20), (8, 2), (4, 4), (4, 2), (7, 1), (3, 3)):
+        for B in (1, 2, 3, 5, 8):
+            for nz in (1, 2, 3, 8, 12, 61):
+                for causal in (True, False):
+                    T = Hq * B * nz
+                    seen = {_attn_qblock_host(L, Hq, Hkv, B, nz, causal) for L in range(T)}
+                    assert len(seen) == T and all(0 <= b < B and 0 <= h < Hq and 0 <= z < nz for b, h, z in seen), (Hq, Hkv, B, nz, causal)
+    per_xcd, order = {}, []
+    for L in range(28 * 8 * 8):
+        b, h, z = _attn_qblock_host(L, 28, 4, 8, 8, True)
+        per_xcd.setdefault(L & 7, set()).add((b, h // 7))
+        order.append(z)
+    assert all(len(v) == 4 for v in per_xcd.values()) and len(set().union(*per_xcd.values())) == 32
+    assert order == sorted(order, reverse=True)                      # level-major, longest (z = 7) first
+    per_xcd = {}
+    for L in range(28 * 60):                                         # B = 1, an even number of levels: levels pair up, one kv head per XCD pair
+        b, h, z = _attn_qblock_host(L, 28, 4, 1, 60, True)
+        per_xcd.setdefault(L & 7, set()).add(h // 7)
+    assert all(v == {x // 2} for x, v in per_xcd.items()), per_xcd
+    heads = {}
+    for L in range(20 * 8 * 12):                                     # encoder (not causal): the 12 query blocks of a head sit on ONE XCD, back to back
+        b, h, z = _attn_qblock_host(L, 20, 20, 8, 12, False)
+        heads.setdefault((b, h), set()).add(L & 7)
+    assert all(len(v) == 1 for v in heads.values())
