@@ -303,7 +303,10 @@ __device__ __forceinline__ QBlock attn_qblock(const AttnArgs2& p) {
 // results); the time it saves is the time the loop spends waiting for LDS-DMA
 #define AFK_ATTN_BARRIER_P(p_)                                \
     do {                                                      \
-        if (AFK_DBG(p_) & 2) {                                \
+        if (AFK_DBG(p_) & 16) {   /* no block barrier at all: how much do the four waves cost each other? (wrong results) */ \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  \
+            __builtin_amdgcn_sched_barrier(0);                \
+        } else if (AFK_DBG(p_) & 2) {                         \
             __builtin_amdgcn_sched_barrier(0);                \
             __builtin_amdgcn_s_barrier();                     \
             __builtin_amdgcn_sched_barrier(0);                \
@@ -479,6 +482,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         }
         // (no inline asm on MFMA results: the compiler's hazard recogniser does not see through asm and would not insert the
         //  MFMA-write -> VALU-read wait states; this file is built with -fno-honor-nans so the maxima fold to bare v_max3_f32)
+        bf16x8 pb[4];
+        if (AFK_DBG(p) & 32) {   // probe builds only (wrong results): no softmax arithmetic - the scores go to the P.V MFMAs as they are.  What the serial VALU block costs.
+#pragma unroll
+            for (int kt2 = 0; kt2 < 2; ++kt2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pb[2 * kt2 + (r >> 3)][r & 7] = (bf16)st[kt2][r];
+            m = 0.f;
+        } else {
         float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);
@@ -497,7 +508,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
         }
         const float nm = (m == NEG_INF) ? 0.f : -m;
         const f32x2 c2v = {c2, c2}, nmv = {nm, nm};
-        bf16x8 pb[4];
         f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
         for (int kt2 = 0; kt2 < 2; ++kt2)
@@ -511,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_lds_kernel(AttnArgs2 p) {
                 pb[2 * kt2 + (r >> 3)][(r & 7) + 1] = (bf16)p2[1];
             }
         if (!LM) l += rs2[0] + rs2[1];
+        }
         if (LM) {   // l += sum over the tile's 64 keys of the (bf16) probabilities: rows of the ones fragment x P - ahead of the V^T ring, no LDS operand
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) lacc = MFMA(ones, pb[s4], lacc);

@@ -1,6 +1,6 @@
 """PROBE (wrong results by design; needs the -DAFK_PROBES build: make PROBES=1 OUT=../lib_probes, AFK_LIB_PATH=<that libafk.so>): how much of the forward / dQ
 tile loop is waiting for the LDS-DMA prefetch?  AFK_ATTN_DBG bit 0 = the fast tiles issue NO LDS-DMA (they re-read stale tiles), bit 1 = the tile barrier does
-not wait for the prefetch (vmcnt).  HIP-event time of the forward alone per setting; one process per setting (the flag is read once)."""
+not wait for the prefetch (vmcnt), bit 4 (16) = no block barrier in the fast tiles at all (each wave only waits for its own DMA pieces).  HIP-event time of the forward alone per setting; one process per setting (the flag is read once)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -26,7 +26,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         out[name] = ts
     print(json.dumps({"AFK_ATTN_DBG": os.environ.get("AFK_ATTN_DBG", "0"), "fwd_us": out}))
 else:
-    for dbg in ("0", "1", "2", "3"):
+    for dbg in ("0", "32", "33", "49"):
         env = dict(os.environ, AFK_ATTN_DBG=dbg, AFK_LIB_PATH=os.path.join(ROOT, "audio-flamingo_amd", "lib_probes", "libafk.so"))
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True, timeout=600)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-500:], flush=True)
