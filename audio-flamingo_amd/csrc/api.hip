@@ -65,6 +65,26 @@ extern "C" int afk_stream_create(int priority, void** host_stream_out) {
     *host_stream_out = (void*)s;
     return AFK_OK;
 }
+// A stream whose kernels may only run on `n_cus` compute units: logical CUs [first_cu, first_cu + n_cus) of the queue's CU mask.  The kernel driver deals the
+// mask bits out XCD-first (bit i -> XCD i % 8, then shader engine, then CU inside it), so a run of 8 k consecutive bits is k CUs on EVERY XCD: the masked
+// stream keeps an equal share of each XCD's L2 / fabric port.  Masked streams are created at the default queue priority (the HIP entry point has no priority form).
+extern "C" int afk_stream_create_cu_mask(int first_cu, int n_cus, void** host_stream_out) {
+    AFK_REQUIRE(host_stream_out, "afk_stream_create_cu_mask: null output");
+    int dev = 0, total = 0;
+    hipError_t e = hipGetDevice(&dev);
+    AFK_REQUIRE(e == hipSuccess, "hipGetDevice: %s", hipGetErrorString(e));
+    e = hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev);
+    AFK_REQUIRE(e == hipSuccess && total > 0, "hipDeviceGetAttribute(MultiprocessorCount): %s", hipGetErrorString(e));
+    AFK_REQUIRE(first_cu >= 0 && n_cus > 0 && first_cu + n_cus <= total, "afk_stream_create_cu_mask: CUs [%d, %d) outside the device's %d", first_cu, first_cu + n_cus, total);
+    uint32_t mask[32] = {};
+    AFK_REQUIRE(total <= 32 * 32, "afk_stream_create_cu_mask: %d CUs", total);
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    e = hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask);
+    AFK_REQUIRE(e == hipSuccess, "hipExtStreamCreateWithCUMask(%d CUs from %d): %s", n_cus, first_cu, hipGetErrorString(e));
+    *host_stream_out = (void*)s;
+    return AFK_OK;
+}
 extern "C" int afk_stream_destroy(void* stream) {
     AFK_REQUIRE(stream, "afk_stream_destroy: null stream");
     hipError_t e = hipStreamDestroy((hipStream_t)stream);

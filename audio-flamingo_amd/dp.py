@@ -23,6 +23,7 @@ moments exactly as torch.optim does for ``grad is None`` (DDP's find_unused_para
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -515,6 +516,9 @@ class DataParallelEngine:
         return DataParallelEngine._NoSync(self)
 
 
+_PROBE_SKIP_ADAMW = os.environ.get("AFK_PROBE_SKIP_ADAMW", "0") == "1"   # bench.py marks a run with it INVALID
+
+
 class BackwardOverlap:
     """Runs, per gradient bucket and as soon as backward has produced it: [RCCL sum-all-reduce] -> fused AdamW on that
     bucket -> refresh of its W^T shadows, all on a side HIP stream while backward continues on the compute stream.
@@ -581,6 +585,8 @@ class BackwardOverlap:
         if getattr(self.opt, "clip_norm", None):
             self.opt.add_sumsq(i, gate=gate, written_only=written_only)
             self._clip_pending.append((i, gate, written_only))
+            return
+        if _PROBE_SKIP_ADAMW:   # timing probe (wrong training): what the step costs without its optimizer launches
             return
         fused = self.opt.step_bucket(i, self.grad_scale, self.thin_blocks, gate=gate, written_only=written_only)
         self.arena.refresh_bucket_shadows(i, skip=fused)   # W^T shadows the optimizer launch wrote itself are skipped

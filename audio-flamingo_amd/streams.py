@@ -8,6 +8,10 @@ dispatcher hands a CU that frees up to the compute queue first; the wgrad GEMMs 
 
 AFK_STREAM_PRIORITIES:  "hl" (default) compute at the highest, wgrad / side at the lowest priority;  "h0" compute highest, the others at the default;
 "0l" compute at the default, the others lowest;  "0" off (every role a plain torch stream at the default priority: the round-5 schedule).
+
+AFK_SIDE_CUS=n (0 / unset = off): the "side" stream is created with a CU mask of n compute units, n / 8 on every XCD (afk_stream_create_cu_mask), at the default
+queue priority.  The optimizer's waves then stop landing on all 256 CUs; the step is power-limited, so the GEMM queues do not miss the CUs (profiles/r04_cu_contention.json).
+AFK_MAIN_CUS=m: the "compute" and "wgrad" streams masked to the LAST m CUs (probe: a disjoint partition when n + m <= the CU count; masked streams lose their priority).
 """
 from __future__ import annotations
 
@@ -47,6 +51,18 @@ def make_stream(device, role: str) -> torch.cuda.Stream:
     device = torch.device(device)
     if role not in _MODES["hl"]:
         raise _lib.AfkError(f"make_stream: unknown role {role!r}")
+    n_mask = int(os.environ.get("AFK_SIDE_CUS", "0") or 0) if role == "side" else int(os.environ.get("AFK_MAIN_CUS", "0") or 0)
+    if n_mask > 0:
+        with torch.cuda.device(device):
+            total = torch.cuda.get_device_properties(device).multi_processor_count
+            n_mask = min(n_mask, total)
+            first = 0 if role == "side" else total - n_mask
+            h = ctypes.c_void_p(0)
+            _lib.call("afk_stream_create_cu_mask", first, n_mask, ctypes.byref(h))
+        s = torch.cuda.ExternalStream(h.value, device=device)
+        s.afk_role, s.afk_priority, s.afk_cus = role, 0, (first, n_mask)
+        _keep.append(h.value)
+        return s
     if not enabled():
         return torch.cuda.Stream(device=device)
     with torch.cuda.device(device):

@@ -1151,7 +1151,9 @@ def main():
             "step_enqueue": "hip_graph_replay" if use_graph else "eager_python",
             "stream_priorities": None if compute_stream is None else {"range_least_greatest": list(_streams.priority_range()), "compute": compute_stream.afk_priority,
                                                                       "wgrad": getattr(model.arena.wgrad_stream, "afk_priority", None),
-                                                                      "side": getattr(getattr(overlap, "side", None), "afk_priority", None)},
+                                                                      "side": getattr(getattr(overlap, "side", None), "afk_priority", None),
+                                                                      "side_cus": getattr(getattr(overlap, "side", None), "afk_cus", None)},
+            **({"INVALID_probe": "AFK_PROBE_SKIP_ADAMW=1: the optimizer launches were skipped (timing probe)"} if os.environ.get("AFK_PROBE_SKIP_ADAMW", "0") == "1" else {}),
             "loss": final_loss, "loss_first_step": first_loss, "rank_losses": rank_losses, "rccl_ranks": world if use_dp else 0,
             "replicas_identical_after_steps": replicas_identical, "param_checksum": param_checksum, "synthetic_batches_rotated": nb, "label_rows_static": bool(model.label_rows_static),
             "dp": None if engine is None else {**dp_info, "backend": args.backend, "comm": engine.comm_kind if engine.native is not None else "torch",

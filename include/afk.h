@@ -453,6 +453,11 @@ int afk_mfma_ceiling(int mode, int nblocks, int iters, const void* operands, flo
  * afk_stream_create clamps `priority` into that range, creates a non-blocking stream on the current device and stores the hipStream_t in *host_stream_out. */
 int afk_stream_priority_range(int* host_least, int* host_greatest);
 int afk_stream_create(int priority, void** host_stream_out);
+/* A stream restricted to logical compute units [first_cu, first_cu + n_cus) of the current device (hipExtStreamCreateWithCUMask; default queue priority).  The mask
+ * bits are dealt out XCD-first, so 8 k consecutive CUs are k CUs on every XCD.  For the HBM-bound side work of the step (the fused AdamW of a bucket beside the
+ * MFMA-bound backward): the step is power-limited, CUs taken from the GEMMs cost them nothing, and the optimizer's waves stop landing on every CU of the chip.
+ * No reference counterpart (torch.optim runs after backward on the one stream, TORCH/optim/adamw.py). */
+int afk_stream_create_cu_mask(int first_cu, int n_cus, void** host_stream_out);
 int afk_stream_destroy(void* stream);
 
 /* ---- EXACT fp32 inference forward (round 5; SURVEY.md 8c "an fp32 mode of our kernels ... should give bit-exact tokens unconditionally on the tiny config").
