@@ -30,7 +30,7 @@ __device__ long long* g_chain_stamps = nullptr;
 
 #define AFK_CHAIN_BATCH_MAX 8
 enum { PRO_PLAIN = 0, PRO_RMS = 1 };
-enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3 };
+enum { EPI_QKV = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_LOGITS = 3, EPI_RESID_NORM = 4 };
 
 struct ChainArgs {
     const bf16* x;        // input row [K]
@@ -54,6 +54,13 @@ struct ChainArgs {
     // batched form (gemv_chain_batched_kernel): M input rows, row strides in elements
     int M, pos_stride;
     int64_t ldx, ld_res, ld_out, ldq, k_bs, vt_bs;
+    // EPI_RESID_NORM (gemv_chain_mfma_kernel): RMSNorm of the finished output rows by the last block to arrive
+    const bf16* n2_w;     // [N] weight of the norm that FOLLOWS this Linear (post_attention_layernorm / the next layer's input_layernorm / the final norm)
+    bf16* n2_out;         // [M][ld_n2]
+    int64_t ld_n2;
+    float n2_eps;
+    int* n2_counter;      // one zero-initialised int32 (self-resetting)
+    int kil;              // gemv_chain_mfma_kernel: stages of the K loop dealt round-robin to the waves of a block (1) or one contiguous slice per wave (0)
     float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
     int* part_idx;        //             ... and its row (lowest row among equals); or null
 };
@@ -474,7 +481,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_batched_kerne
 // two blocks' loads are issued before the current ones are multiplied.  The B operand (lane -> sequence l & 31, same piece) comes from the L2-resident input
 // rows; lanes beyond M repeat row M - 1 and feed result columns nobody reads.
 // RG = 16 (the narrow Linears: twice the groups, so twice the waves and bytes in flight): rows 16 .. 31 of the A operand repeat rows 0 .. 15 and their results are dropped.
-template <int EPI, int S, int RG>
+template <int EPI, int S, int RG, bool XMASK, bool AHEAD = false>
 __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
     constexpr int JR = RG / 8;          // load instructions per 64-element block (8 rows x 128 bytes each)
@@ -507,8 +514,11 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     }
     // this wave's K slice in blocks of 64 elements (K % 64 == 0)
     const int nkb = p.K >> 6;
+    // K split over the S waves: contiguous slices (p.kil == 0: wave w owns blocks [w per, (w + 1) per)), or stages dealt round-robin (p.kil == 1: wave w owns the
+    // NB-block stages w, w + S, ... - at any moment the waves of a block stream ADJACENT 128 NB-byte pieces of the same rows, as the single-sequence kernel's chunks do)
     const int per = (nkb + S - 1) / S;
-    const int b0 = w * per, b1 = min(b0 + per, nkb);
+    const int b0 = p.kil ? w * NB : w * per, b1 = p.kil ? nkb : min(b0 + per, nkb);
+    const int STEP = p.kil ? S * NB : NB;   // blocks from one stage of this wave to its next
     // global side: load j of a block covers group rows 8 j + (lane >> 3), 16-byte piece lane & 7
     const int rowl = lane >> 3, piece = lane & 7;
     const bf16* wp[JR];
@@ -535,12 +545,20 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     bf16x8 ga[8], gb[8];
-    auto xload2 = [&](bf16x8(&dst)[8], int kb) {   // the B fragments of two blocks (L2-resident input rows)
+    // the B fragments (L2-resident input rows), two blocks at a time.  Column j of the MFMA result depends on column j of B alone and only columns < M are read
+    // afterwards, so only the lanes of real sequences load (XMASK: a quarter of the lanes at M = 8 - the other lanes' registers keep their zeros).
+    // HOIST (S <= 8: the registers are there): ALL of a four-block stage's fragments are requested ahead of the next stage's weight loads - loads return in order,
+    // so the second pair, requested behind them (round 4), could only be used once the whole next stage had landed.
+    constexpr bool HOIST = NB == 4 && S <= 8;
+    const bool xlane = !XMASK || l31 < p.M;
+    auto xload2 = [&](bf16x8(&dst)[8], int kb) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int kk = min(kb + b, b1 - 1) << 6;
+            if (xlane) {
 #pragma unroll
-            for (int st = 0; st < 4; ++st) dst[b * 4 + st] = *(const bf16x8*)(xp + kk + st * 16);
+                for (int st = 0; st < 4; ++st) dst[b * 4 + st] = *(const bf16x8*)(xp + kk + st * 16);
+            }
         }
     };
     auto mma2 = [&](const bf16x8(&xv)[8], int kb, int bb) {   // blocks bb, bb + 1 of the stage
@@ -555,25 +573,81 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
             }
         }
     };
+    bf16x8 xa[8], xb[HOIST ? 8 : 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xa[i][e] = (bf16)0.f;
+            if (HOIST) xb[i][e] = (bf16)0.f;
+        }
     auto consume = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], int kb) {
-        bf16x8 xv[8];
-        xload2(xv, kb);                              // ahead of the next stage's weight loads: loads return in order
-        if (kb + NB < b1) gload(nxt, kb + NB);
+        xload2(xa, kb);                              // ahead of the next stage's weight loads: loads return in order
+        if constexpr (HOIST) xload2(xb, kb + 2);
+        if (kb + STEP < b1) gload(nxt, kb + STEP);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
-        mma2(xv, kb, 0);
-        if (NB == 4) {
-            xload2(xv, kb + 2);
-            mma2(xv, kb, 2);
+        mma2(xa, kb, 0);
+        if constexpr (HOIST) {
+            mma2(xb, kb, 2);
+        } else if (NB == 4) {
+            xload2(xa, kb + 2);
+            mma2(xa, kb, 2);
         }
     };
-    if (b0 < b1) {
+    if constexpr (AHEAD) {
+        // the narrow Linears (S <= 8: 256 VGPRs): a stage's input fragments travel WITH its weights, one stage ahead - a wave never sits out an L2 round trip
+        // for its input rows between the arrival of a stage's weights and its MFMAs
+        bf16x8 xs0[4 * NB], xs1[4 * NB];
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xs0[i][e] = xs1[i][e] = (bf16)0.f;
+        auto xloadN = [&](bf16x8(&dst)[4 * NB], int kb) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int kk = min(kb + b, b1 - 1) << 6;
+                if (xlane) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) dst[b * 4 + st] = *(const bf16x8*)(xp + kk + st * 16);
+                }
+            }
+        };
+        auto consumeA = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], const bf16x8(&xc)[4 * NB], bf16x8(&xn)[4 * NB], int kb) {
+            if (kb + STEP < b1) {
+                xloadN(xn, kb + STEP);
+                gload(nxt, kb + STEP);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (kb + b < b1) {   // wave-uniform
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const bf16x8 wf = *(const bf16x8*)(my + b * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xc[b * 4 + st], acc, 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if (b0 < b1) {
+            xloadN(xs0, b0);
+            gload(ga, b0);
+            for (int kb = b0; kb < b1; kb += 2 * STEP) {
+                consumeA(ga, gb, xs0, xs1, kb);
+                if (kb + STEP < b1) consumeA(gb, ga, xs1, xs0, kb + STEP);
+            }
+        }
+    } else if (b0 < b1) {
         gload(ga, b0);
-        for (int kb = b0; kb < b1; kb += 2 * NB) {
+        for (int kb = b0; kb < b1; kb += 2 * STEP) {
             consume(ga, gb, kb);
-            if (kb + NB < b1) consume(gb, ga, kb + NB);
+            if (kb + STEP < b1) consume(gb, ga, kb + STEP);
         }
     }
     // D[i][j]: lane holds column j = l31 (the sequence), rows i = 8 q + 4 hi + e in acc[4 q + e]; the wave's sums go to the head of its own staging area
@@ -585,6 +659,90 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
             for (int e = 0; e < 4; ++e) red[(8 * q + 4 * hi + e) * MBX + l31] = acc[4 * q + e];
     }
     __syncthreads();
+    if constexpr (EPI == EPI_RESID_NORM) {
+        // Linear + residual as EPI_RESID, then the RMSNorm that follows it (Qwen2DecoderLayer :284 -> :294, :297 -> the next layer's :271 / Qwen2Model.norm; Qwen2RMSNorm
+        // :247-252) WITHOUT a launch of its own: the statistic needs every column, i.e. every block of this launch, so the rows go out as agent-scope write-through
+        // stores (two bf16 per 32-bit word), each block bumps a counter behind its drained stores, and the block that arrives last re-reads the M x N outputs with
+        // agent-scope loads, normalises them and writes h.  The hand-over is afk_attn_decode_fused's (attention_decode.hip); nobody waits for anybody.
+        __shared__ int last_flag;
+        float* fin = (float*)&stage[0][4096];
+        const int t = threadIdx.x;
+        if (t < R * MBX) {
+            const int r = t / MBX, m = t % MBX;
+            float tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < S; ++q) tot += ((const float*)&stage[q][0])[r * MBX + m];
+            const int row = rA + r;   // rB = rA + HR: the R rows of a group are consecutive
+            fin[r * MBX + m] = m < p.M ? (float)(bf16)(rbf(tot) + (float)p.residual[m * p.ld_res + row]) : 0.f;
+        }
+        __syncthreads();
+        if (t < HR * MBX) {   // thread (pair j, m): rows rA + 2 j, rA + 2 j + 1 of sequence m as one word
+            const int j = t / MBX, m = t % MBX;
+            if (m < p.M) {
+                const bf16x2 pr = {(bf16)fin[(2 * j) * MBX + m], (bf16)fin[(2 * j + 1) * MBX + m]};
+                __hip_atomic_store((uint32_t*)(p.out + m * p.ld_out + rA + 2 * j), __builtin_bit_cast(uint32_t, pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing waves drain their write-through stores themselves (attention_decode.hip: no fence does it here)
+        __syncthreads();
+        if (t == 0) {
+            const int prev = __hip_atomic_fetch_add(p.n2_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = prev == (int)gridDim.x - 1;
+            if (last_flag) __hip_atomic_store(p.n2_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // self-resetting (graph replays)
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        constexpr int T = 64 * S, WPT = 4;   // the launcher guarantees N / 2 <= WPT * T words per row
+        const int nw2 = p.N >> 1;
+        uint32_t xw[MBX][WPT];
+#pragma unroll
+        for (int m = 0; m < MBX; ++m)
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int w2 = t + T * i;
+                xw[m][i] = (m < p.M && w2 < nw2) ? __hip_atomic_load((const uint32_t*)(p.out + m * p.ld_out) + w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            }
+        uint32_t nwv[WPT];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) nwv[i] = (t + T * i) < nw2 ? ((const uint32_t*)p.n2_w)[t + T * i] : 0u;
+        float* ssred = (float*)&stage[0][0];   // [S][MBX]: the K-slice sums there have been consumed
+        float ss[MBX];
+#pragma unroll
+        for (int m = 0; m < MBX; ++m) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const float lo = __uint_as_float(xw[m][i] << 16), hi_ = __uint_as_float(xw[m][i] & 0xffff0000u);
+                a += lo * lo + hi_ * hi_;
+            }
+            ss[m] = wave_sum(a);
+        }
+        __syncthreads();   // every thread has read its slice sums / fin before the area is reused
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MBX; ++m) ssred[w * MBX + m] = ss[m];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MBX; ++m) {
+            if (m >= p.M) break;
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < S; ++q) a += ssred[q * MBX + m];
+            const float rstd = rsqrtf(a * (1.f / (float)p.N) + p.n2_eps);
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int w2 = t + T * i;
+                if (w2 < nw2) {
+                    const float x0 = __uint_as_float(xw[m][i] << 16), x1 = __uint_as_float(xw[m][i] & 0xffff0000u);
+                    const float g0 = __uint_as_float(nwv[i] << 16), g1 = __uint_as_float(nwv[i] & 0xffff0000u);
+                    const bf16x2 o = {(bf16)(g0 * rbf(x0 * rstd)), (bf16)(g1 * rbf(x1 * rstd))};   // cast BEFORE the weight multiply (:250-252)
+                    ((uint32_t*)(p.n2_out + m * p.ld_n2))[w2] = __builtin_bit_cast(uint32_t, o);
+                }
+            }
+        }
+        return;
+    }
     if (threadIdx.x >= R * MBX) return;
     const int r = threadIdx.x / MBX, m = threadIdx.x % MBX;
     float tot = 0.f;
@@ -662,6 +820,7 @@ int launch_chain(const ChainArgs& p, int rows, int which, int S_dflt, int R_dflt
     return AFK_OK;
 }
 
+#define KIL_DEFAULT 1, 1, 1, 1, 1   // round 6: round-robin stages measured 3-9 % faster on the narrow Linears, level on the wide ones
 template <int EPI>
 int launch_chain_batched(const ChainArgs& p, int rows, int which, int S_dflt, hipStream_t st) {
     // matrix-pipe form when the shape allows (32- / 16-row groups, 64-element blocks); AFK_CHAIN_MFMA=0 / 1 forces the dot-product / the matrix-pipe form (A/B, tests)
@@ -670,25 +829,56 @@ int launch_chain_batched(const ChainArgs& p, int rows, int which, int S_dflt, hi
     // measured on the AF3-7B decode step (ms per step, B = 2 / 4 / 8): dot-product form 3.32 / 3.73 / 4.75, matrix-pipe form 3.66 / 3.89 / 4.43 -> MFMA from five rows on
     const bool use_mfma = e ? e[0] == '1' : p.M >= 5;
     if (shape_ok && use_mfma) {
-        // 1 184 / 4 752 groups of 32 rows (gate|up, lm_head): 4 K slices.  The narrow Linears need more waves than 32-row groups x 8 slices give: K <= 4 096
-        // (qkv, o_proj): 32-row groups x 8 slices; longer K (down: 296 blocks per row): 16-row groups x 16 slices = 3 584 waves, one 1024-thread block per CU.
+        ChainArgs q = p;
+        {   // AFK_CHAIN_KIL = "a/b/c/d/e" per launch kind (qkv / o_proj / down / gate|up / lm_head), or one digit for all (measurement knob)
+            int v[5] = {KIL_DEFAULT};
+            if (const char* c = getenv("AFK_CHAIN_KIL")) {
+                const int n = sscanf(c, "%d/%d/%d/%d/%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+                if (n == 1) v[1] = v[2] = v[3] = v[4] = v[0];
+            }
+            q.kil = v[which] != 0;
+        }
+        // 1 184 / 4 752 groups of 32 rows (gate|up, lm_head): 4 K slices.  The narrow Linears: qkv 32-row groups x 8 slices, o_proj and down 16-row groups x 8 slices
+        // (224 blocks of 512 threads; round 5 ran down as 16 x 16 = one 1024-thread block per CU: 34 us against 30).
         // AFK_CHAIN_MFMA_NARROW = "rg,s" overrides the narrow form (measurement knob)
-        int rg = p.K > 4096 ? 16 : 32, sl = p.K > 4096 ? 16 : 8;
-        if (const char* c = getenv("AFK_CHAIN_MFMA_NARROW")) sscanf(c, "%d,%d", &rg, &sl);
-#define AFK_MFMA(S_, RG_)                                                                                                                                \
+        // round 6, per launch at M = 8 (tools/bench_decode_chain_batched.py, us): qkv 32,8 10.6 / 16,8 16.1 · o_proj 32,8 9.6 / 16,8 8.4 / 16,16 8.2 · down 16,16 33.7 / 16,8 30.1 / 32,8 39.2
+        int rg = which == 0 ? 32 : 16, sl = 8;
+        if (const char* c = getenv("AFK_CHAIN_MFMA_NARROW")) {   // "rg,s" for every narrow Linear, or "rg,s/rg,s/rg,s" = qkv / o_proj (K <= 4096) / down
+            int v[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+            const int n = sscanf(c, "%d,%d/%d,%d/%d,%d", &v[0][0], &v[0][1], &v[1][0], &v[1][1], &v[2][0], &v[2][1]);
+            const int w3 = which <= 2 ? which : 0;
+            if (n == 2) rg = v[0][0], sl = v[0][1];
+            else if (n == 6 && v[w3][0] > 0) rg = v[w3][0], sl = v[w3][1];
+        }
+        static const bool xmask = !(getenv("AFK_CHAIN_XMASK") && getenv("AFK_CHAIN_XMASK")[0] == '0');   // A/B knob: 0 = every lane loads its (clamped) input row
+        const char* ah = getenv("AFK_CHAIN_AHEAD");                                                       // A/B knob: 1 = input fragments requested one stage ahead, with the weights
+        const bool ahead = ah && ah[0] == '1';   // measured SLOWER (234 VGPRs, fewer waves): opt-in
+#define AFK_MFMA_X(S_, RG_, XM_, AH_)                                                                                                                    \
     do {                                                                                                                                                 \
         static bool attr_set = false;                                                                                                                    \
         if (S_ * 8192 > 65536 && !attr_set) {                                                                                                            \
-            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S_, RG_>, hipFuncAttributeMaxDynamicSharedMemorySize, S_ * 8192);              \
+            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S_, RG_, XM_, AH_>, hipFuncAttributeMaxDynamicSharedMemorySize, S_ * 8192);    \
             attr_set = true;                                                                                                                             \
         }                                                                                                                                                \
-        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S_, RG_>), dim3((unsigned)(rows / RG_)), dim3(64 * S_), S_ * 8192, st, p);                      \
+        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S_, RG_, XM_, AH_>), dim3((unsigned)(rows / RG_)), dim3(64 * S_), S_ * 8192, st, q);            \
+    } while (0)
+#define AFK_MFMA(S_, RG_)                                 \
+    do {                                                  \
+        if (xmask) AFK_MFMA_X(S_, RG_, true, false);      \
+        else AFK_MFMA_X(S_, RG_, false, false);           \
+    } while (0)
+#define AFK_MFMA_A(S_, RG_)                               \
+    do {                                                  \
+        if (ahead) AFK_MFMA_X(S_, RG_, true, true);       \
+        else AFK_MFMA(S_, RG_);                           \
     } while (0)
         if (rows / 32 >= 1024) AFK_MFMA(4, 32);
         else if (rg == 16 && sl == 16) AFK_MFMA(16, 16);
-        else if (rg == 16) AFK_MFMA(8, 16);
-        else AFK_MFMA(8, 32);
+        else if (rg == 16) AFK_MFMA_A(8, 16);
+        else AFK_MFMA_A(8, 32);
+#undef AFK_MFMA_A
 #undef AFK_MFMA
+#undef AFK_MFMA_X
         return AFK_OK;
     }
     const int S = chain_knob(which, S_dflt, false);
@@ -808,6 +998,25 @@ extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t l
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2;
     launch_chain_batched<EPI_RESID>(p, N, K > 4096 ? 2 : 1, K > 4096 ? 8 : 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_batched");
+    return AFK_OK;
+}
+
+// Linear + residual + the RMSNorm that follows, 1 .. 8 sequences, always on the matrix-pipe form (16-row groups x 8 K slices): out = bf16(W x) + residual,
+// h_out = norm_w * bf16(out * rsqrt(mean(out^2) + eps)) written by the last block of the launch to arrive (EPI_RESID_NORM above).  counter: one zero-initialised int32.
+extern "C" int afk_decode_chain_linear_residual_norm_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual,
+                                                             int64_t ld_res, void* out, int64_t ld_out, const void* norm_w, float eps, void* h_out, int64_t ld_h,
+                                                             int* counter, void* stream) {
+    AFK_REQUIRE(x && W && residual && out && norm_w && h_out && counter, "afk_decode_chain_linear_residual_norm_batched: null pointer");
+    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 32 == 0 && N / 2 <= 4 * 512 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_norm_batched: unsupported shape (1 <= M <= 8, N %% 32 == 0, N <= 4096, K %% 64 == 0)");
+    AFK_REQUIRE(ld_out % 2 == 0 && ld_h % 2 == 0 && ((uintptr_t)out % 4 == 0) && ((uintptr_t)h_out % 4 == 0) && ((uintptr_t)norm_w % 4 == 0),
+                "afk_decode_chain_linear_residual_norm_batched: out / h_out / norm_w must be 4-byte aligned with even leading dimensions");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
+    p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.n2_w = (const bf16*)norm_w; p.n2_out = (bf16*)h_out; p.ld_n2 = ld_h; p.n2_eps = eps; p.n2_counter = counter;
+    p.kil = 1;
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID_NORM, 8, 16, true, false>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
+    AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_norm_batched");
     return AFK_OK;
 }
 

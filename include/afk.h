@@ -359,6 +359,12 @@ int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, const void* 
                                  int Hq, int Hkv, int D, void* stream);
 int afk_decode_chain_linear_residual_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
                                              void* out, int64_t ld_out, void* stream);
+/* Linear + residual + the RMSNorm that follows it in ONE launch, 1 .. 8 sequences (round 6): out = bf16(W x) + residual (Qwen2DecoderLayer :284 / :297), h_out =
+ * RMSNorm(out) with norm_w (the layer's post_attention_layernorm :294, the NEXT layer's input_layernorm :271, or Qwen2Model.norm; Qwen2RMSNorm :247-252: cast before
+ * the weight multiply).  The statistic needs every output column: the last block of the launch to arrive normalises (hand-over through agent-scope stores and a
+ * self-resetting counter, as afk_attn_decode_fused).  counter: one zero-initialised int32.  N % 32 == 0, N <= 4096, K % 64 == 0; out / h_out 4-byte aligned. */
+int afk_decode_chain_linear_residual_norm_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
+                                                  void* out, int64_t ld_out, const void* norm_w, float eps, void* h_out, int64_t ld_h, int* counter, void* stream);
 int afk_decode_chain_gate_up_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int I, int K, void* act_out, int64_t ld_act, void* stream);
 int afk_decode_chain_lm_head_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int N, int K, float* logits, int64_t ld_logits, void* stream);
 

@@ -1304,6 +1304,45 @@ def test_decode_chain_batched_kernels_vs_standalone_sequence(dev, M, mfma, monke
     _cmp("batched lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M", [1, 5, 8])
+def test_decode_chain_linear_residual_norm_fused(dev, M):
+    """afk_decode_chain_linear_residual_norm_batched (Linear + residual + the RMSNorm that follows in one launch; the last block to arrive normalises) against
+    the two-launch sequence at the AF3-7B widths: the residual stream bit-equal to the plain batched launch of the same form, the normalised rows equal to
+    afk_rmsnorm_fwd of it up to the fp32 summation order of the statistic; repeated launches (the counter resets itself), rows of different sequences do not mix."""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    H, nq, I = 3584, 3584, 18944
+    st = ops._stream()
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    res = _rand((M, H), dev, 1.0, 2).to(BF)
+    nw = (1 + 0.1 * _rand((H,), dev, seed=3)).to(BF)
+    for K_ in (nq, I):
+        a = _rand((M, K_), dev, 1.0, 5).to(BF)
+        wl = _rand((H, K_), dev, 0.02, 6).to(BF)
+        want = torch.empty((M, H), device=dev, dtype=BF)
+        _lib.call("afk_decode_chain_linear_residual_batched", a.data_ptr(), K_, M, wl.data_ptr(), wl.stride(0), H, K_, res.data_ptr(), H, want.data_ptr(), H, st)
+        h_want, _ = ops.rmsnorm_fwd(want, nw, 1e-6)
+        for rep in range(3):
+            out = torch.full((M, H), float("nan"), device=dev, dtype=BF)
+            h = torch.full((M, H), float("nan"), device=dev, dtype=BF)
+            _lib.call("afk_decode_chain_linear_residual_norm_batched", a.data_ptr(), K_, M, wl.data_ptr(), wl.stride(0), H, K_, res.data_ptr(), H, out.data_ptr(), H,
+                      nw.data_ptr(), 1e-6, h.data_ptr(), H, cnt.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert int(cnt) == 0, "the hand-over counter must reset itself"
+            _cmp(f"fused linear+residual K={K_}", out, want.float(), atol=3e-2, rtol=2e-2)
+            if M >= 5:   # the plain launch takes the same matrix-pipe form from five sequences on
+                assert torch.equal(out, want)
+            ref, _ = ops.rmsnorm_fwd(out, nw, 1e-6)
+            neq = int((h != ref).sum())
+            assert neq <= M * H // 200, f"fused norm: {neq} of {M * H} values differ from afk_rmsnorm_fwd of the same rows"
+            _cmp(f"fused norm K={K_}", h, ref.float(), atol=2e-2, rtol=1e-2)
+        solo_o = torch.empty((1, H), device=dev, dtype=BF)
+        solo_h = torch.empty((1, H), device=dev, dtype=BF)
+        _lib.call("afk_decode_chain_linear_residual_norm_batched", a[M - 1:].data_ptr(), K_, 1, wl.data_ptr(), wl.stride(0), H, K_, res[M - 1:].data_ptr(), H, solo_o.data_ptr(), H,
+                  nw.data_ptr(), 1e-6, solo_h.data_ptr(), H, cnt.data_ptr(), st)
+        assert torch.equal(solo_o[0], out[M - 1]) and torch.equal(solo_h[0], h[M - 1])
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()
