@@ -39,8 +39,11 @@ __device__ long long* g_stamps = nullptr;
 //           the whole XCD L2: measured 29 us per launch when EVERY thread fenced, profiles/r04_decode_chain.md).
 // The merge folds the partials in chunk order with the arithmetic of attn_decode_combine_kernel - the result does not depend on which block came last -
 // and resets the counter for the next call.  Nobody waits for anybody.
-template <int D, int FINAL>   // FINAL: 0 = partials only (afk_attn_decode), 1 = merge by the last block, write-through hand-over, 2 = the same with agent-scope fences
-__global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
+// WPE: waves per SIMD the register allocation aims for (amdgpu_waves_per_eu).  Left alone the D = 128 hand-over form takes 142 VGPRs = 3 blocks per CU; a batched step
+// launches 7 blocks per CU (B = 8: 1 792) that each live ~10 us of memory round trips, so residency, not bytes, sets its time (round 6 probe: a quarter of the
+// blocks entered at once, the last after 25 us).  4 -> 102 VGPRs without a spill, 5 -> 96 (+ 6 spilled), 6 -> 80 (+ 18 spilled).
+template <int D, int FINAL, int WPE = 3, int BK = 128>   // BK: keys per register batch; FINAL: 0 = partials only (afk_attn_decode), 1 = merge by the last block, write-through hand-over, 2 = the same with agent-scope fences
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void attn_decode_split_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
                                                                 int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
                                                                 int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
                                                                 float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     }
     // ---- every load of the first 128 keys of the chunk is issued before anything is computed (round 4: the one-load-per-pass loops spent a memory
     // round trip per 16 keys - 10 us for a 100-key chunk); longer chunks continue in batches of the same depth
-    constexpr int UK = 128 / KPP;     // key passes per batch
-    constexpr int UV = 128 / (PARTS * 8);   // value loads per batch and thread
+    constexpr int UK = BK / KPP;     // key passes per batch
+    constexpr int UV = BK / (PARTS * 8);   // value loads per batch and thread
     const int sub = t % LPK, krow = t / LPK;
     const bf16x8 qv = *(const bf16x8*)(Q + b * q_bs + h * q_hs + sub * 8);
     const bf16* kbase = Kc + b * k_bs + hk * k_hs + sub * 8 + (int64_t)c0 * k_rs;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     load_v(0);
     const float c2 = scale * LOG2E;
     float mx = NEG_INF;
-    for (int i0 = 0; i0 < n; i0 += 128) {
+    for (int i0 = 0; i0 < n; i0 += BK) {
         if (i0) load_k(i0);
 #pragma unroll
         for (int u = 0; u < UK; ++u) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_decode_split_kernel(const bf16* __re
     // ---- partial output: thread -> feature d, part -> every PARTS-th group of 8 keys
     // (branch-free: written as `if (g + e < n) acc += ...` the compiler emitted one branch + one LDS round trip per key - 2.7 us of a 11 us launch)
     float acc = 0.f;
-    for (int g0 = 0; g0 < n; g0 += 128) {
+    for (int g0 = 0; g0 < n; g0 += BK) {
         if (g0) load_v(g0);
 #pragma unroll
         for (int u = 0; u < UV; ++u) {
@@ -478,11 +481,22 @@ static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_h
         AFK_LAUNCH_CHECK("afk_attn_decode_fused (group form)");
         return AFK_OK;
     }
+    // AFK_ATTN_DECODE_WPE (A/B knob): 0 = by block count, 3 = the compiler's allocation (130 VGPRs, 3 blocks per CU), 4 / 5 / 6 = that many waves per SIMD with
+    // 128-key register batches, 7 = 64-key batches in 66 VGPRs (7 blocks per CU), 8 = 64-key batches in 76.  Round 6 (tools/bench_decode_chain_batched.py, us per launch,
+    // 800 keys): B = 8  29.1 / 26.3 / 28.9 / 35.8 / 21.3 / 22.7 for 3 / 4 / 5 / 6 / 7 / 8;  B = 4  19.7 / 16.2 / 17.4 / - / 15.9 / 15.1;  B = 1  10.9 / 11.7 / 12.1 / - / 11.5 / 11.2
+    // -> more than three blocks per CU: 7; otherwise the compiler's allocation.
+    static const int wpe_env = [] { const char* e = getenv("AFK_ATTN_DECODE_WPE"); return e ? atoi(e) : 0; }();
+    const int wpe = wpe_env ? wpe_env : ((int64_t)nsplit * Hq * B > 3 * 256 ? 7 : 3);
 #define AFK_AD_ARGS (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs, (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs
 #define AFK_AD(DD)                                                                                                                       \
     do {                                                                                                                                 \
         if (fused && sync == 1) {                                                                                                        \
-            hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1>), grid, dim3(256), 0, st, AFK_AD_ARGS);                                  \
+            if (wpe == 4) hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1, 4>), grid, dim3(256), 0, st, AFK_AD_ARGS);               \
+            else if (wpe == 5) hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1, 5>), grid, dim3(256), 0, st, AFK_AD_ARGS);          \
+            else if (wpe == 6) hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1, 6>), grid, dim3(256), 0, st, AFK_AD_ARGS);          \
+            else if (wpe == 7) hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1, 7, 64>), grid, dim3(256), 0, st, AFK_AD_ARGS);      \
+            else if (wpe == 8) hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1, 5, 64>), grid, dim3(256), 0, st, AFK_AD_ARGS);      \
+            else hipLaunchKernelGGL((attn_decode_split_kernel<DD, 1>), grid, dim3(256), 0, st, AFK_AD_ARGS);                           \
         } else if (fused) {                                                                                                              \
             hipLaunchKernelGGL((attn_decode_split_kernel<DD, 2>), grid, dim3(256), 0, st, AFK_AD_ARGS);                                  \
         } else {                                                                                                                         \

@@ -826,8 +826,8 @@ int launch_chain_batched(const ChainArgs& p, int rows, int which, int S_dflt, hi
     // matrix-pipe form when the shape allows (32- / 16-row groups, 64-element blocks); AFK_CHAIN_MFMA=0 / 1 forces the dot-product / the matrix-pipe form (A/B, tests)
     const char* e = getenv("AFK_CHAIN_MFMA");
     const bool shape_ok = rows % 32 == 0 && p.K % 64 == 0 && (EPI != EPI_QKV || ((p.D / 2) % 16 == 0 && (p.Hkv * p.D) % 32 == 0)) && (EPI != EPI_SWIGLU || (rows / 2) % 16 == 0);
-    // measured on the AF3-7B decode step (ms per step, B = 2 / 4 / 8): dot-product form 3.32 / 3.73 / 4.75, matrix-pipe form 3.66 / 3.89 / 4.43 -> MFMA from five rows on
-    const bool use_mfma = e ? e[0] == '1' : p.M >= 5;
+    // measured on the AF3-7B decode step (ms per step, B = 2 / 4 / 8): dot-product form 3.32 / 3.73 / 4.75, matrix-pipe form 3.66 / 3.89 / 4.43 -> MFMA from five rows on (round 4; round 6 below: from four)
+    const bool use_mfma = e ? e[0] == '1' : p.M >= 4;   // round 6 (per-Linear group shapes, fused norm): B = 4 step 3.73 ms on the dot-product form against 3.65 at B = 5 on the matrix pipe
     if (shape_ok && use_mfma) {
         ChainArgs q = p;
         {   // AFK_CHAIN_KIL = "a/b/c/d/e" per launch kind (qkv / o_proj / down / gate|up / lm_head), or one digit for all (measurement knob)

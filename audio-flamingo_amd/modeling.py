@@ -1033,10 +1033,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         eps = float(self.rms_eps)
         q = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
         o = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
-        # round 6: from five sequences on (the matrix-pipe regime of the batched launches) the RMSNorm that follows o_proj / down rides in that launch
+        # round 6: from four sequences on (the matrix-pipe regime of the batched launches) the RMSNorm that follows o_proj / down rides in that launch
         # (afk_decode_chain_linear_residual_norm_batched: the last block to arrive normalises) - 5 launches per layer instead of 7
         I0 = a[f"{lm}layers.0.mlp.gate_up.weight"].data.shape[0] // 2
-        fuse_norm = (self.decode_fuse_norm and B >= 5 and H % 32 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0)
+        fuse_norm = (self.decode_fuse_norm and B >= 4 and H % 32 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0)
         if fuse_norm:
             cnt = getattr(self, "_chain_norm_counter", None)
             if cnt is None or cnt.device != dev:

@@ -1304,7 +1304,7 @@ def test_decode_chain_batched_kernels_vs_standalone_sequence(dev, M, mfma, monke
     _cmp("batched lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("M", [1, 5, 8])
+@pytest.mark.parametrize("M", [1, 4, 8])
 def test_decode_chain_linear_residual_norm_fused(dev, M):
     """afk_decode_chain_linear_residual_norm_batched (Linear + residual + the RMSNorm that follows in one launch; the last block to arrive normalises) against
     the two-launch sequence at the AF3-7B widths: the residual stream bit-equal to the plain batched launch of the same form, the normalised rows equal to
@@ -1330,7 +1330,7 @@ def test_decode_chain_linear_residual_norm_fused(dev, M):
             torch.cuda.synchronize()
             assert int(cnt) == 0, "the hand-over counter must reset itself"
             _cmp(f"fused linear+residual K={K_}", out, want.float(), atol=3e-2, rtol=2e-2)
-            if M >= 5:   # the plain launch takes the same matrix-pipe form from five sequences on
+            if M >= 4:   # the plain launch takes the same matrix-pipe form from four sequences on
                 assert torch.equal(out, want)
             ref, _ = ops.rmsnorm_fwd(out, nw, 1e-6)
             neq = int((h != ref).sum())
