@@ -58,6 +58,7 @@ class Arena:
         self.step_counter = 0  # bumped by our optimizer (raw-pointer writes do not touch tensor._version)
         self._bucket_ranges: List[tuple] = []
         self._bucket_pending: List[int] = []
+        self.presums = {}   # one hand-over slot {for: bias key, ptr: data_ptr of the gradient tensor, row: bf16 column sums}: left by a gradient's producer for the bias gradient of its consumer (functional.py)
         self._bucket_sizes: List[int] = []
         self.on_bucket_ready: Optional[Callable[[int], None]] = None
         # optional second compute stream for the weight-gradient branch of every Linear backward (functional.linear_bwd):
@@ -157,6 +158,7 @@ class Arena:
 
     def begin_backward(self):
         self._bucket_pending = list(self._bucket_sizes)
+        self.presums.clear()
 
     def enable_wgrad_stream(self, on: bool = True):
         from .streams import make_stream   # lowest queue priority: the wgrad GEMMs fill what the critical path leaves (streams.py)

@@ -228,11 +228,18 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16* __restrict__ 
 // for the 7 MB of a decoder RMSNorm: 187 launches = 3.8 ms of the step), then the 16 slices are folded through LDS in a fixed order
 // (bit-reproducible).  D % 4 == 0 is guaranteed by the callers.
 // gridDim.y = 2 folds the second partial plane (offset D: LayerNorm's db) into out2 in the same launch.
+// gridDim.y = 3 (round 6) folds a third, separately laid out plane [nparts][stride3] into out3 as well: the column sums of the OUTPUT of the column-owned
+// LayerNorm backward = the bias gradient of the Linear below it (afk_layernorm_bwd_colsum).
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, int nparts, int D,
-                                                            int stride, bf16* __restrict__ out, bf16* __restrict__ out2, int accumulate) {
+                                                            int stride, bf16* __restrict__ out, bf16* __restrict__ out2, int accumulate,
+                                                            const float* __restrict__ partials3 = nullptr, int stride3 = 0, bf16* __restrict__ out3 = nullptr,
+                                                            int accumulate3 = 0) {
     __shared__ f32x4 red[16][17];
-    const int offset = blockIdx.y ? D : 0;
+    int offset = blockIdx.y ? D : 0;
     if (blockIdx.y) out = out2;
+    if (blockIdx.y == 2) {
+        partials = partials3, offset = 0, stride = stride3, out = out3, accumulate = accumulate3;
+    }
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = (blockIdx.x * 16 + cl) * 4;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
@@ -266,11 +273,14 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
 }
 
 // Column-owned backward (see the header).  blockDim.x = D / 8 rounded up to whole waves; R rows per group.
-template <bool RMS, bool ADD, int R>
+// CS (round 6): the kernel owns its columns over every row anyway, so it also sums the dx it WRITES (the bf16 values, as a colsum pass over dx would read them)
+// into cs_partials[block][D]: in a pre-LN block dx = (norm branch) + (skip branch) is the gradient of the residual stream, i.e. of the output of the Linear
+// that precedes the norm - its column sums are that Linear's bias gradient (encoder: out_proj below final_layer_norm, the LOWER layer's fc2 below self_attn_layer_norm).
+template <bool RMS, bool ADD, int R, bool CS = false>
 __global__ __launch_bounds__(512, 3) void norm_bwd_cols_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, const bf16* __restrict__ dy,
                                                              const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                              bf16* __restrict__ dx, const bf16* __restrict__ dx_add, float* __restrict__ partials,
-                                                             int64_t rows, int D) {
+                                                             int64_t rows, int D, float* __restrict__ cs_partials = nullptr) {
     constexpr int NS = RMS ? R : 2 * R;                      // statistics per group: sum(g * xh) [, sum(g)] per row
     __shared__ float red[2][16][NS];                         // [parity][wave][stat]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -278,13 +288,14 @@ __global__ __launch_bounds__(512, 3) void norm_bwd_cols_kernel(const bf16* __res
     const bool live = col < D;
     const int colc = live ? col : D - 8;
     const float invD = 1.f / (float)D;
-    float wf[8], pw[8], pb[8];
+    float wf[8], pw[8], pb[8], pc[CS ? 8 : 1];
     {
         const bf16x8 wt = *(const bf16x8*)(w + colc);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             wf[e] = (float)wt[e];
             pw[e] = pb[e] = 0.f;
+            if (CS) pc[e] = 0.f;
         }
     }
     const int64_t ngroups = (rows + R - 1) / R;
@@ -363,6 +374,7 @@ __global__ __launch_bounds__(512, 3) void norm_bwd_cols_kernel(const bf16* __res
                     float v = rstd[r] * (gg - sg - xh * sgx);
                     if (ADD) v = rbf(v) + (float)av[r][e];   // fused residual-gradient merge: dx = bf16(norm-branch) + skip-branch
                     o[e] = (bf16)v;
+                    if (CS) pc[e] += (float)o[e];
                 }
                 *(bf16x8*)(dx + (r0 + r) * D + col) = o;
                 __builtin_amdgcn_sched_barrier(0);
@@ -377,6 +389,11 @@ __global__ __launch_bounds__(512, 3) void norm_bwd_cols_kernel(const bf16* __res
         if (!RMS) {
             *(f32x4*)(outp + D) = f32x4{pb[0], pb[1], pb[2], pb[3]};
             *(f32x4*)(outp + D + 4) = f32x4{pb[4], pb[5], pb[6], pb[7]};
+        }
+        if (CS) {
+            float* outc = cs_partials + (int64_t)blockIdx.x * D + col;
+            *(f32x4*)(outc) = f32x4{pc[0], pc[1], pc[2], pc[3]};
+            *(f32x4*)(outc + 4) = f32x4{pc[4], pc[5], pc[6], pc[7]};
         }
     }
 }
@@ -513,6 +530,92 @@ extern "C" int afk_layernorm_bwd(const void* x, const void* w, const void* dy, c
     hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 64), 2), dim3(256), 0, st, workspace, nb, D, 2 * D, (bf16*)dw, (bf16*)db,
                        accumulate);
     AFK_LAUNCH_CHECK("afk_layernorm_bwd");
+    return AFK_OK;
+}
+
+// GELU backward, column-owned (round 6): dx = bf16(dy * gelu'(pre)) as gelu_bwd_kernel (elementwise.hip), and the column sums of the dx it writes - dx is the
+// grad_output of the Linear that produced `pre` (encoder fc1), so the sums are its bias gradient and the column-sum pass over dx (123 MB per encoder layer at
+// B = 8) disappears.  A thread owns 8 columns over the rows blockIdx.x, blockIdx.x + gridDim.x, ...; partials[blockIdx.x][C], folded by fold_partials_kernel.
+namespace {
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ pre, bf16* __restrict__ dx, int64_t rows, int C,
+                                                              float* __restrict__ partials) {
+    const int col = (blockIdx.y * 256 + threadIdx.x) * 8;
+    if (col >= C) return;
+    float pc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pc[e] = 0.f;
+    const int64_t step = gridDim.x;
+    int64_t r = blockIdx.x;
+    for (; r + 3 * step < rows; r += 4 * step) {   // four rows in flight
+        bf16x8 d[4], p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = *(const bf16x8*)(dy + (r + u * step) * C + col);
+            p[u] = *(const bf16x8*)(pre + (r + u * step) * C + col);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (bf16)((float)d[u][e] * gelu_grad_f((float)p[u][e]));
+                pc[e] += (float)o[e];
+            }
+            *(bf16x8*)(dx + (r + u * step) * C + col) = o;
+        }
+    }
+    for (; r < rows; r += step) {
+        const bf16x8 d = *(const bf16x8*)(dy + r * C + col), p = *(const bf16x8*)(pre + r * C + col);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (bf16)((float)d[e] * gelu_grad_f((float)p[e]));
+            pc[e] += (float)o[e];
+        }
+        *(bf16x8*)(dx + r * C + col) = o;
+    }
+    float* outp = partials + (int64_t)blockIdx.x * C + col;
+    *(f32x4*)(outp) = f32x4{pc[0], pc[1], pc[2], pc[3]};
+    *(f32x4*)(outp + 4) = f32x4{pc[4], pc[5], pc[6], pc[7]};
+}
+}  // namespace
+
+// partial rows of afk_gelu_bwd_colsum (its workspace holds that many x C floats)
+extern "C" int afk_gelu_bwd_colsum_parts(int64_t rows) { return (int)(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
+
+extern "C" int afk_gelu_bwd_colsum(const void* dy, const void* pre, void* dx, int64_t rows, int C, void* colsum, int colsum_accumulate, float* workspace,
+                                   void* stream) {
+    AFK_REQUIRE(dy && pre && dx && colsum && workspace && rows > 0 && C > 0 && C % 8 == 0, "afk_gelu_bwd_colsum: bad arguments (C %% 8 == 0)");
+    AFK_REQUIRE((uintptr_t)dy % 16 == 0 && (uintptr_t)pre % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)workspace % 16 == 0 && (uintptr_t)colsum % 8 == 0,
+                "afk_gelu_bwd_colsum: dy / pre / dx / workspace must be 16-byte aligned, colsum 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int np = afk_gelu_bwd_colsum_parts(rows);
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)np, (unsigned)afk_cdiv(C / 8, 256)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)pre, (bf16*)dx, rows, C,
+                       workspace);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(C, 64), 1), dim3(256), 0, st, workspace, np, C, C, (bf16*)colsum, (bf16*)nullptr, colsum_accumulate);
+    AFK_LAUNCH_CHECK("afk_gelu_bwd_colsum");
+    return AFK_OK;
+}
+
+// LayerNorm backward with the residual merge (dx = bf16(norm branch) + dx_add) that ALSO returns the column sums of the dx it writes: colsum[c] (+)= sum_r dx[r][c]
+// = the bias gradient of the Linear whose output this norm normalised (see norm_bwd_cols_kernel).  Column-owned form only (D % 8 == 0, D <= 4096);
+// workspace: afk_norm_bwd_blocks(rows) x 3 x D floats.
+extern "C" int afk_layernorm_bwd_colsum(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx, const void* dx_add,
+                                        void* dw, void* db, int accumulate, void* colsum, int colsum_accumulate, float* workspace, int64_t rows, int D,
+                                        void* stream) {
+    AFK_REQUIRE(x && w && dy && mean && rstd && dx && dx_add && dw && db && colsum && workspace, "afk_layernorm_bwd_colsum: null pointer");
+    AFK_REQUIRE(D % 8 == 0 && D / 8 <= 512 && rows > 0, "afk_layernorm_bwd_colsum: unsupported D=%d (D %% 8 == 0, D <= 4096)", D);
+    AFK_NORM_BWD_ALIGN("afk_layernorm_bwd_colsum");
+    AFK_REQUIRE((uintptr_t)db % 8 == 0 && (uintptr_t)colsum % 8 == 0, "afk_layernorm_bwd_colsum: db / colsum must be 8-byte aligned");
+    const int nb = std::min(norm_bwd_cols_blocks(rows, D, false), afk_norm_bwd_blocks(rows));
+    hipStream_t st = (hipStream_t)stream;
+    float* cs = workspace + (int64_t)afk_norm_bwd_blocks(rows) * 2 * D;
+    const int nt = (int)afk_cdiv(D / 8, 64) * 64;
+    hipLaunchKernelGGL((norm_bwd_cols_kernel<false, true, 2, true>), dim3(nb), dim3(nt), 0, st, (const bf16*)x, (const bf16*)w, (const bf16*)dy, mean, rstd,
+                       (bf16*)dx, (const bf16*)dx_add, workspace, rows, D, cs);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)afk_cdiv(D, 64), 3), dim3(256), 0, st, workspace, nb, D, 2 * D, (bf16*)dw, (bf16*)db, accumulate,
+                       (const float*)cs, D, (bf16*)colsum, colsum_accumulate);
+    AFK_LAUNCH_CHECK("afk_layernorm_bwd_colsum");
     return AFK_OK;
 }
 

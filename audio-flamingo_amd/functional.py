@@ -74,18 +74,44 @@ NN_DGRAD_DEFAULT = "mlp.gate_up.weight"
 NN_DGRAD_SUFFIXES = tuple(x for x in os.environ.get("AFK_NN_DGRAD", NN_DGRAD_DEFAULT).split(",") if x)
 
 
-def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None):
+# Bias gradients where their operand is produced (round 6, AFK_FUSE_BIAS_SUMS=0 restores the separate column-sum passes): the column-owned LayerNorm backward
+# also sums the residual-stream gradient it writes (= grad_output of the Linear below the norm: out_proj in the same layer, fc2 of the LOWER layer), and the GELU
+# backward sums the d(pre-activation) it writes (= grad_output of fc1).
+FUSE_BIAS_SUMS = os.environ.get("AFK_FUSE_BIAS_SUMS", "1") == "1"
+
+
+def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_dx=True, swiglu_gu=None, bias_presum=None):
     """y = x W^T (+ b):  returns dx, writes dW (and db) into the arena.
     The weight-gradient branch (two operand transposes + wgrad GEMM + bias row-sum) is independent of the data-gradient
     GEMM; with ``arena.wgrad_stream`` set it is enqueued on that stream so the two GEMMs fill each other's tile tails."""
+    # bias_presum: dy's producer has already summed its columns - "done": into the bias gradient itself (accumulate semantics applied there);
+    # a bf16 [N] tensor: into a scratch row that the weight-gradient branch copies / adds into the bias gradient (no column-sum pass either way)
     M = dy.shape[0]
     blk = arena[wkey]
     side = arena.wgrad_stream
     N, K = dy.shape[1], x.shape[1]
+    presum = None
+    if bias_presum is not None:
+        assert bkey is not None and bias_slices is None
+        if isinstance(bias_presum, str):
+            arena.grad_written(arena[bkey])
+        else:
+            presum = (arena[bkey], bias_presum)
+        bkey = None
+
+    def take_presum():
+        if presum is not None:
+            bb0, row = presum
+            if bb0.fresh:
+                bb0.grad.copy_(row)
+            else:
+                bb0.grad.add_(row)
+            arena.grad_written(bb0)
     direct = BWD_FORM == "direct"
     wdirect = direct or BWD_FORM == "wgrad_direct"  # TN wgrad only: no activation transposes, dgrad stays on the NT kernel + W^T shadows
 
     def wgrad_branch():
+        take_presum()
         if wdirect and _tiles256(N, K) * ops.splitk_plan_256(N, K, M) >= DIRECT_MIN_TILES:  # narrow outputs: TN kernel with split-K
             ops.gemm(dy, x, out=blk.grad.reshape(blk.shape[0], -1), trans_a=True, trans_b=True, accumulate=not blk.fresh)
             arena.grad_written(blk)
@@ -119,6 +145,8 @@ def linear_bwd(arena: Arena, dy, x, wkey, *, bkey=None, bias_slices=None, need_d
                 ops.THIN_BLOCKS = 0
         dy.record_stream(side)
         x.record_stream(side)
+        if presum is not None:
+            presum[1].record_stream(side)
     if not need_dx:
         return None
     if (direct or (NN_DGRAD_SUFFIXES and wkey.endswith(NN_DGRAD_SUFFIXES) and swiglu_gu is None)) and _tiles256(M, K) >= DIRECT_MIN_TILES:
@@ -193,6 +221,13 @@ class ConvStemFn:
 
 
 # ---------------------------------------------------------------------------------------------- encoder layer (a5, a6)
+def _lower_fc2_bias(arena, pfx):
+    """pfx = '...layers.<i>.': the key of layer i - 1's fc2 bias (the consumer of the column sums of this layer's dx), or None"""
+    head, _, tail = pfx.rstrip(".").rpartition(".")
+    key = f"{head}.{int(tail) - 1}.fc2.bias" if tail.isdigit() and int(tail) > 0 else None
+    return key if key in arena.blocks else None
+
+
 class EncoderLayerFn:
     """pre-LN attention block + pre-LN GELU MLP   (AudioFlamingo3EncoderLayer.forward, :211-245)"""
 
@@ -223,17 +258,30 @@ class EncoderLayerFn:
         dx3 = dx3.contiguous()
         if f is None:
             f = ops.gelu_fwd(pre)
-        df = linear_bwd(arena, dx3, f, pfx + "fc2.weight", bkey=pfx + "fc2.bias")
+        fuse = FUSE_BIAS_SUMS and E % 8 == 0 and E <= 4096
+        # fc2's grad_output is the gradient this layer received: if the layer above produced it (same storage), its LayerNorm backward has summed its columns already
+        pre2 = None
+        if fuse and arena.presums.get("for") == pfx + "fc2.bias" and arena.presums.get("ptr") == dx3.data_ptr():
+            pre2 = arena.presums["row"]
+        arena.presums.clear()   # one slot, consumed or dropped by the next layer down: nothing stale survives to a later backward
+        df = linear_bwd(arena, dx3, f, pfx + "fc2.weight", bkey=pfx + "fc2.bias", bias_presum=pre2)
         del f
-        dpre = ops.gelu_bwd(df, pre)
+        b1 = A("fc1.bias")
+        if fuse and pre.shape[1] % 8 == 0:
+            dpre = ops.gelu_bwd(df, pre, colsum_out=b1.grad, colsum_accumulate=not b1.fresh)
+            done1 = "done"
+        else:
+            dpre, done1 = ops.gelu_bwd(df, pre), None
         del df
-        dh2 = linear_bwd(arena, dpre, h2, pfx + "fc1.weight", bkey=pfx + "fc1.bias")
+        dh2 = linear_bwd(arena, dpre, h2, pfx + "fc1.weight", bkey=pfx + "fc1.bias", bias_presum=done1)
         del dpre
         lw, lb = A("final_layer_norm.weight"), A("final_layer_norm.bias")
-        dx2 = ops.layernorm_bwd(x2, lw.data, dh2, mean2, rstd2, lw.grad, lb.grad, dx_add=dx3, accumulate=not lw.fresh)
+        bo = A("self_attn.out_proj.bias")
+        dx2 = ops.layernorm_bwd(x2, lw.data, dh2, mean2, rstd2, lw.grad, lb.grad, dx_add=dx3, accumulate=not lw.fresh,
+                                colsum_out=bo.grad if fuse else None, colsum_accumulate=not bo.fresh)
         arena.grad_written(lw), arena.grad_written(lb)
         del dh2
-        do = linear_bwd(arena, dx2, o, pfx + "self_attn.out_proj.weight", bkey=pfx + "self_attn.out_proj.bias")
+        do = linear_bwd(arena, dx2, o, pfx + "self_attn.out_proj.weight", bkey=pfx + "self_attn.out_proj.bias", bias_presum="done" if fuse else None)
         dqkv = ops.attn_bwd(qkv, o, do, lse, W, S, H, H, D, scale=D ** -0.5, causal=False, kv_len=kv_len)
         del do
         # k_proj has no bias (:112): only the q and v thirds of the fused bias receive a gradient
@@ -241,8 +289,14 @@ class EncoderLayerFn:
                         bias_slices=[(0, E), (2 * E, 3 * E)])
         del dqkv
         lw, lb = A("self_attn_layer_norm.weight"), A("self_attn_layer_norm.bias")
-        dx = ops.layernorm_bwd(x, lw.data, dh, mean1, rstd1, lw.grad, lb.grad, dx_add=dx2, accumulate=not lw.fresh)
+        # the dx this layer hands down is the grad_output of the LOWER layer's fc2: its column sums go into a scratch row, registered under dx's storage - the
+        # lower layer takes them only if it receives exactly this tensor (anything else - another consumer of the hidden state, a copy - falls back to the column-sum pass)
+        lower = _lower_fc2_bias(arena, pfx) if fuse else None
+        row = torch.empty(E, device=x.device, dtype=torch.bfloat16) if lower else None
+        dx = ops.layernorm_bwd(x, lw.data, dh, mean1, rstd1, lw.grad, lb.grad, dx_add=dx2, accumulate=not lw.fresh, colsum_out=row, colsum_accumulate=False)
         arena.grad_written(lw), arena.grad_written(lb)
+        if row is not None:
+            arena.presums.update({"for": lower, "ptr": dx.data_ptr(), "row": row})
         return dx, None, None, None, None, None, None, None
 
 

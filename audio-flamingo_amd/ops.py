@@ -317,10 +317,18 @@ def _norm_ws(rows, D, device):
     return torch.empty(nb * 2 * D, device=device, dtype=torch.float32)
 
 
-def layernorm_bwd(x, w, dy, mean, rstd, dw, db, *, dx_add=None, accumulate=False):
+def layernorm_bwd(x, w, dy, mean, rstd, dw, db, *, dx_add=None, accumulate=False, colsum_out=None, colsum_accumulate=False):
+    """colsum_out (with dx_add, D % 8 == 0): also colsum_out[c] (+)= sum_r dx[r][c] - the bias gradient of the Linear whose output this norm normalised"""
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty_like(x)
+    if colsum_out is not None:
+        assert dx_add is not None and D % 8 == 0 and D <= 4096
+        nb = _lib.load().afk_norm_bwd_blocks(rows)
+        ws = torch.empty(nb * 3 * D, device=x.device, dtype=torch.float32)
+        _lib.call("afk_layernorm_bwd_colsum", x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx_add.data_ptr(),
+                  dw.data_ptr(), db.data_ptr(), int(accumulate), colsum_out.data_ptr(), int(colsum_accumulate), ws.data_ptr(), rows, D, _stream())
+        return dx
     ws = _norm_ws(rows, D, x.device)
     _lib.call("afk_layernorm_bwd", x.data_ptr(), w.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
               _p(dx_add), dw.data_ptr(), db.data_ptr(), int(accumulate), ws.data_ptr(), rows, D, _stream())
@@ -354,8 +362,14 @@ def gelu_fwd(x):
     return y
 
 
-def gelu_bwd(dy, pre):
+def gelu_bwd(dy, pre, *, colsum_out=None, colsum_accumulate=False):
+    """colsum_out: also colsum_out[c] (+)= sum_r dx[r][c] (the bias gradient of the Linear that produced `pre`), by a column-owned form of the same arithmetic"""
     dx = torch.empty_like(_chk(dy, BF16))
+    if colsum_out is not None:
+        rows, C = dy.shape
+        ws = torch.empty(_lib.load().afk_gelu_bwd_colsum_parts(rows) * C, device=dy.device, dtype=torch.float32)
+        _lib.call("afk_gelu_bwd_colsum", dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), rows, C, colsum_out.data_ptr(), int(colsum_accumulate), ws.data_ptr(), _stream())
+        return dx
     _lib.call("afk_gelu_bwd", dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), dy.numel(), _stream())
     return dx
 

@@ -124,6 +124,17 @@ int afk_layernorm_bwd(const void* x, const void* w, const void* dy, const float*
                       void* dx, const void* dx_add, void* dw, void* db, int accumulate, float* workspace,
                       int64_t rows, int D, void* stream);
 int afk_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int64_t rows, int D, float eps, void* stream);
+/* afk_gelu_bwd (dx = bf16(dy * gelu'(pre)), exact-erf GELU, activations.py:70-89) that also returns the column sums of the dx it writes: colsum[c] (+)= sum_r dx[r][c]
+ * = the bias gradient of the Linear that produced `pre` (AudioFlamingo3EncoderLayer fc1 :240; torch: bias.grad = grad_output.sum(0)).  workspace:
+ * afk_gelu_bwd_colsum_parts(rows) x C floats.  C % 8 == 0. */
+int afk_gelu_bwd_colsum_parts(int64_t rows);
+int afk_gelu_bwd_colsum(const void* dy, const void* pre, void* dx, int64_t rows, int C, void* colsum, int colsum_accumulate, float* workspace, void* stream);
+/* afk_layernorm_bwd with dx_add (dx = bf16(norm branch) + dx_add: the gradient of the residual stream) that also returns the column sums of the dx it writes:
+ * colsum[c] (+)= sum_r dx[r][c] = the bias gradient of the Linear whose output this LayerNorm normalised (AudioFlamingo3EncoderLayer :211-245: out_proj before
+ * final_layer_norm, the lower layer's fc2 before self_attn_layer_norm; torch: bias.grad = grad_output.sum(0)) - the separate column-sum pass over dx disappears.
+ * workspace: afk_norm_bwd_blocks(rows) x 3 x D floats.  D % 8 == 0, D <= 4096. */
+int afk_layernorm_bwd_colsum(const void* x, const void* w, const void* dy, const float* mean, const float* rstd, void* dx, const void* dx_add, void* dw, void* db,
+                             int accumulate, void* colsum, int colsum_accumulate, float* workspace, int64_t rows, int D, void* stream);
 int afk_rmsnorm_bwd(const void* x, const void* w, const void* dy, const float* rstd, void* dx, const void* dx_add,
                     void* dw, int accumulate, float* workspace, int64_t rows, int D, void* stream);
 

@@ -704,6 +704,35 @@ def test_wgrad_stream_and_optimizer_overlap_match_serial_path(dev):
             assert torch.equal(ma.arena.shadow(k), mb.arena.shadow(k)), f"stale W^T shadow for {k}"
 
 
+def test_fused_bias_sums_match_the_column_sum_passes(dev, monkeypatch):
+    """AFK_FUSE_BIAS_SUMS (round 6): encoder bias gradients taken where their operand is produced (out_proj / the lower layer's fc2 inside the LayerNorm backward,
+    fc1 inside the GELU backward) against the separate column-sum passes on the same model and batch: every OTHER gradient bit-identical (the dx tensors are),
+    the three bias families equal up to the fp32 summation order - twice, the second backward accumulating into the first"""
+    import audio_flamingo_amd.functional as F
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    grads = {}
+    for fuse in (False, True):
+        monkeypatch.setattr(F, "FUSE_BIAS_SUMS", fuse)
+        m = _fresh_model(dev, seed=13)
+        m.zero_grad()
+        m(**kw).loss.backward()
+        m(**kw).loss.backward()   # accumulates
+        torch.cuda.synchronize()
+        grads[fuse] = {k: b.grad.detach().clone() for k, b in m.arena.blocks.items()}
+    fam = ("fc1.bias", "fc2.bias", "self_attn.out_proj.bias")
+    n_fam = 0
+    for k, a in grads[False].items():
+        b = grads[True][k]
+        if "audio_tower.layers" in k and k.endswith(fam):
+            n_fam += 1
+            assert _rel(b, a) < 1e-2, f"{k}: fused bias sums {_rel(b, a)} away from the column-sum pass"
+        else:
+            assert torch.equal(a, b), f"{k}: changed by the bias-sum fusion"
+    assert n_fam >= 3 * _cfg().audio_config.num_hidden_layers - 1
+
+
 def test_graphed_step_matches_eager(dev):
     """graphs.GraphedTrainStep: the whole step (three streams, optimizer inside backward) captured once and replayed must leave
     bit-identical parameters / optimizer state / loss to the eager step, step after step (lr and bias corrections come from device memory)"""

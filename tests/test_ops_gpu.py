@@ -1343,6 +1343,46 @@ def test_decode_chain_linear_residual_norm_fused(dev, M):
         assert torch.equal(solo_o[0], out[M - 1]) and torch.equal(solo_h[0], h[M - 1])
 
 
+@pytest.mark.parametrize("rows,D", [(1500, 1280), (12000, 1280), (37, 64)])
+def test_layernorm_bwd_colsum_and_gelu_bwd_colsum(dev, rows, D):
+    """bias gradients where their operand is produced: afk_layernorm_bwd_colsum / afk_gelu_bwd_colsum write the same dx (bit for bit) and the same dw / db as the
+    plain entry points, and the column sums of that dx - fresh and accumulated - equal a column-sum pass over it up to the fp32 summation order"""
+    ops = _ops()
+    x = _rand((rows, D), dev, 1.0, 1).to(BF)
+    w = (1 + 0.1 * _rand((D,), dev, seed=2)).to(BF)
+    b = (0.1 * _rand((D,), dev, seed=3)).to(BF)
+    dy = _rand((rows, D), dev, 1.0, 4).to(BF)
+    skip = _rand((rows, D), dev, 1.0, 5).to(BF)
+    _, mean, rstd = ops.layernorm_fwd(x, w, b)
+    dw0, db0 = torch.zeros(D, device=dev, dtype=BF), torch.zeros(D, device=dev, dtype=BF)
+    dx0 = ops.layernorm_bwd(x, w, dy, mean, rstd, dw0, db0, dx_add=skip)
+    dw1, db1 = torch.zeros(D, device=dev, dtype=BF), torch.zeros(D, device=dev, dtype=BF)
+    cs = torch.full((D,), float("nan"), device=dev, dtype=BF)
+    dx1 = ops.layernorm_bwd(x, w, dy, mean, rstd, dw1, db1, dx_add=skip, colsum_out=cs)
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    want = dx0.float().sum(0)
+    tol = 2e-2 * want.abs() + 2e-2 * float(dx0.float().abs().sum(0).max()) / 256
+    assert bool(((cs.float() - want).abs() <= tol).all()), f"column sums off by {float((cs.float() - want).abs().max())}"
+    base = _rand((D,), dev, 1.0, 6).to(BF)
+    acc = base.clone()
+    ops.layernorm_bwd(x, w, dy, mean, rstd, dw1, db1, dx_add=skip, colsum_out=acc, colsum_accumulate=True)
+    assert bool(((acc.float() - (want + base.float())).abs() <= tol + 1e-2 * base.float().abs()).all())
+    # GELU backward: [rows, 4 D] as the encoder's fc1
+    C = 4 * D
+    pre = _rand((rows, C), dev, 1.5, 7).to(BF)
+    dyg = _rand((rows, C), dev, 1.0, 8).to(BF)
+    g0 = ops.gelu_bwd(dyg, pre)
+    csg = torch.full((C,), float("nan"), device=dev, dtype=BF)
+    g1 = ops.gelu_bwd(dyg, pre, colsum_out=csg)
+    assert torch.equal(g0, g1)
+    wantg = g0.float().sum(0)
+    tolg = 2e-2 * wantg.abs() + 2e-2 * float(g0.float().abs().sum(0).max()) / 256
+    assert bool(((csg.float() - wantg).abs() <= tolg).all()), f"GELU column sums off by {float((csg.float() - wantg).abs().max())}"
+    ref = torch.empty(C, device=dev, dtype=BF)
+    ops.colsum(g0, ref)
+    assert int((ref != csg).sum()) <= C // 20, "the fused sums and the column-sum pass differ in more than the odd last bit"
+
+
 # ------------------------------------------------------------------------------------------------ CE
 def test_cross_entropy(dev):
     ops = _ops()
