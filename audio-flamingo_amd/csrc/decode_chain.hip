@@ -60,6 +60,9 @@ struct ChainArgs {
     int64_t ld_n2;
     float n2_eps;
     int* n2_counter;      // one zero-initialised int32 (self-resetting)
+    float* ss_out;        // EPI_RESID (matrix-pipe form), or null: ss_out[block][8] = this block's share of sum(out[m][:]^2) per sequence - the consumer's RMSNorm statistic
+    const float* ss_in;   // PRO_RMS, or null: the producer's partial sums [ss_nparts][8] of the rows in x (null: every block takes the statistic from x itself)
+    int ss_nparts;
     int kil;              // gemv_chain_mfma_kernel: stages of the K loop dealt round-robin to the waves of a block (1) or one contiguous slice per wave (0)
     float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
     int* part_idx;        //             ... and its row (lowest row among equals); or null
@@ -481,7 +484,13 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_batched_kerne
 // two blocks' loads are issued before the current ones are multiplied.  The B operand (lane -> sequence l & 31, same piece) comes from the L2-resident input
 // rows; lanes beyond M repeat row M - 1 and feed result columns nobody reads.
 // RG = 16 (the narrow Linears: twice the groups, so twice the waves and bytes in flight): rows 16 .. 31 of the A operand repeat rows 0 .. 15 and their results are dropped.
-template <int EPI, int S, int RG, bool XMASK, bool AHEAD = false>
+// PRO = PRO_RMS (round 6): the input rows arrive RAW and the RMSNorm in front of this Linear (Qwen2RMSNorm :247-252) happens here, as in the single-sequence kernel -
+// no norm launch, no hand-over.  Prologue: the S waves of a block sum the squares of the M rows together (each thread a strided share, per-row partials folded in
+// wave order through LDS) - the K split covers every column, so every block can do this on its own.  Per stage a wave then loads its NB blocks of the M rows
+// COOPERATIVELY (lane -> row lane >> 3, 16-byte piece lane & 7: every lane carries real data), normalises them (cast before the weight multiply), parks the bf16
+// rows in a wave-private LDS strip and reads the MFMA's B fragments back from there (LDS operations of one wave execute in order): 2 NB loads and ~40 VALU
+// instructions per block instead of 4 masked fragment loads per block and a kernel launch per norm.
+template <int EPI, int S, int RG, bool XMASK, bool AHEAD = false, int PRO = PRO_PLAIN>
 __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
     constexpr int JR = RG / 8;          // load instructions per 64-element block (8 rows x 128 bytes each)
@@ -545,6 +554,84 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     bf16x8 ga[8], gb[8];
+    // ---- PRO_RMS: strip of normalised rows [NB blocks][8 rows][128 B] behind the S weight stages, and the row statistic
+    constexpr int HXB = NB * 1024;
+    char* hx = stage_dyn + S * 8192 + w * HXB;
+    const int xm = lane >> 3, xpc = lane & 7;                       // cooperative row / 16-byte piece of this lane
+    const uint32_t hx_wr = xm * 128 + ((xpc ^ xm) << 4);           // piece index xor row: conflict-free 16-byte writes and fragment reads
+    const uint32_t hx_rd_row = (l31 & 7) * 128, hx_rd_swz = l31 & 7;
+    const bf16* xrow = p.x + (int64_t)min(xm, p.M - 1) * p.ldx + xpc * 8;
+    float my_rstd = 0.f;
+    if constexpr (PRO == PRO_RMS) {
+        if (b0 < b1) gload(ga, b0);   // the first weights travel while the statistic is taken
+#ifdef AFK_PROBES
+        if (p.eps < 0.f) my_rstd = 1.f;   // timing probe (wrong results): no statistic pass
+        else
+#endif
+        if (p.ss_in != nullptr) {
+            // the Linear that wrote these rows left its per-block sums of squares (EPI_RESID, ss_out): every WAVE folds the ss_nparts x 8 floats itself - lane -> row
+            // lane >> 3, parts (lane & 7) + 8 i - and the eight lanes of a row meet through three shuffles: no block barrier, one L2 round trip beside the first weights
+            constexpr int NP8 = 32;   // up to 256 parts (N <= 4096 at 16-row groups); every load is issued before the first sum - a loop of load -> add is a round trip per part
+            float v[NP8];
+#pragma unroll
+            for (int i = 0; i < NP8; ++i) {
+                const int gp = 8 * i + xpc;
+                v[i] = gp < p.ss_nparts ? p.ss_in[gp * MBX + xm] : 0.f;
+            }
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < NP8; ++i) a += v[i];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            my_rstd = rsqrtf(a * (1.f / (float)p.K) + p.eps);
+        } else {
+        constexpr int T = 64 * S;
+        const int nch = p.K >> 3;     // 16-byte chunks per row
+        float ss[MBX];
+        constexpr int CPT = (512 + T - 1) / T;   // chunks per thread and row for K <= 4096, all requested before the first is used (longer rows: the loop below)
+        bf16x8 xv[MBX][CPT];
+#pragma unroll
+        for (int m = 0; m < MBX; ++m)
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int c = threadIdx.x + T * i;
+                const bool ok = m < p.M && c < nch;
+                xv[m][i] = *(const bf16x8*)(p.x + (int64_t)(ok ? m : 0) * p.ldx + (ok ? c : 0) * 8);
+                if (!ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xv[m][i][e] = (bf16)0.f;
+                }
+            }
+#pragma unroll
+        for (int m = 0; m < MBX; ++m) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPT; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a += (float)xv[m][i][e] * (float)xv[m][i][e];
+            if (m < p.M) {
+                for (int c = threadIdx.x + T * CPT; c < nch; c += T) {
+                    const bf16x8 v = *(const bf16x8*)(p.x + (int64_t)m * p.ldx + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a += (float)v[e] * (float)v[e];
+                }
+            }
+            ss[m] = wave_sum(a);
+        }
+        float* ssred = (float*)(stage_dyn + S * 8192);   // [S][MBX], at the head of the (still unused) strips: S x (8 + NB) KiB keeps gate|up at four blocks per CU
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < MBX; ++m) ssred[w * MBX + m] = ss[m];
+        }
+        __syncthreads();
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < S; ++q) a += ssred[q * MBX + xm];      // wave order: bit-reproducible
+        my_rstd = rsqrtf(a * (1.f / (float)p.K) + p.eps);
+        __syncthreads();   // wave 0's strip is about to be written
+        }
+    }
     // the B fragments (L2-resident input rows), two blocks at a time.  Column j of the MFMA result depends on column j of B alone and only columns < M are read
     // afterwards, so only the lanes of real sequences load (XMASK: a quarter of the lanes at M = 8 - the other lanes' registers keep their zeros).
     // HOIST (S <= 8: the registers are there): ALL of a four-block stage's fragments are requested ahead of the next stage's weight loads - loads return in order,
@@ -597,7 +684,46 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
             mma2(xa, kb, 2);
         }
     };
-    if constexpr (AHEAD) {
+    if constexpr (PRO == PRO_RMS) {
+        auto consumeN = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], int kb) {
+            bf16x8 xr[NB], gw[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {   // ahead of the next stage's weight loads: loads return in order
+                const int kk = min(kb + b, b1 - 1) << 6;
+                xr[b] = *(const bf16x8*)(xrow + kk);
+                gw[b] = *(const bf16x8*)(p.normw + kk + xpc * 8);
+            }
+            if (kb + STEP < b1) gload(nxt, kb + STEP);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                bf16x8 h;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h[e] = (bf16)((float)gw[b][e] * rbf((float)xr[b][e] * my_rstd));   // cast BEFORE the weight multiply (:250-252)
+                *(bf16x8*)(hx + b * 1024 + hx_wr) = h;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (kb + b < b1) {   // wave-uniform
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const bf16x8 wf = *(const bf16x8*)(my + b * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
+                        const bf16x8 xf = *(const bf16x8*)(hx + b * 1024 + hx_rd_row + ((((2 * st + hi)) ^ hx_rd_swz) << 4));   // lanes >= 8 repeat rows 0 .. 7: columns nobody reads
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
+                    }
+                }
+            }
+        };
+        if (b0 < b1) {   // ga was requested in the prologue
+            for (int kb = b0; kb < b1; kb += 2 * STEP) {
+                consumeN(ga, gb, kb);
+                if (kb + STEP < b1) consumeN(gb, ga, kb + STEP);
+            }
+        }
+    } else if constexpr (AHEAD) {
         // the narrow Linears (S <= 8: 256 VGPRs): a stage's input fragments travel WITH its weights, one stage ahead - a wave never sits out an L2 round trip
         // for its input rows between the arrival of a stage's weights and its MFMAs
         bf16x8 xs0[4 * NB], xs1[4 * NB];
@@ -768,8 +894,18 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
             p.Vt[m * p.vt_bs + (int64_t)(row - nq - nk) * p.spad + start] = (bf16)mine;
         }
     } else if (EPI == EPI_RESID) {
-        if (!valid) return;
-        p.out[m * p.ld_out + row] = (bf16)(rbf(tot) + (float)p.residual[m * p.ld_res + row]);
+        const bf16 ov = (bf16)(rbf(tot) + (float)p.residual[min(m, p.M - 1) * p.ld_res + row]);
+        if (valid) p.out[m * p.ld_out + row] = ov;
+        if (p.ss_out != nullptr) {   // this block's share of the NEXT norm's statistic: sum over its R columns of out^2 per sequence, rows in order
+            fin[r * MBX + m] = valid ? (float)ov * (float)ov : 0.f;
+            __syncthreads();
+            if (threadIdx.x < MBX) {
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) a += fin[rr * MBX + threadIdx.x];
+                p.ss_out[(int64_t)g * MBX + threadIdx.x] = a;
+            }
+        }
     } else if (EPI == EPI_SWIGLU) {
         const float mine = rbf(tot);
         fin[r * MBX + m] = mine;
@@ -998,6 +1134,82 @@ extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t l
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2;
     launch_chain_batched<EPI_RESID>(p, N, K > 4096 ? 2 : 1, K > 4096 ? 8 : 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_batched");
+    return AFK_OK;
+}
+
+// ---------------------------------------------------------------- 1 .. 8 sequences, RMSNorm in the Linear's own prologue (matrix-pipe form only, round 6)
+namespace {
+template <int EPI, int S>
+int launch_chain_norm(ChainArgs p, int rows, hipStream_t st) {
+    constexpr int NBX = 2;   // 32-row groups: two 64-element blocks per stage
+    constexpr int LDS = S * 8192 + S * NBX * 1024;
+    static bool attr_set = false;
+    if (LDS > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    p.kil = 1;
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>), dim3((unsigned)(rows / 32)), dim3(64 * S), LDS, st, p);
+    return AFK_OK;
+}
+}  // namespace
+
+extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int K, const void* bias,
+                                                 const void* cos_t, const void* sin_t, const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs,
+                                                 void* vtcache, int64_t vt_bs, int spad, const int* start_dev, int Hq, int Hkv, int D, const float* ss_part,
+                                                 int ss_nparts, void* stream) {
+    AFK_REQUIRE(x && norm_w && W && bias && cos_t && sin_t && pos && q_out && kcache && vtcache && start_dev, "afk_decode_chain_qkv_norm_batched: null pointer");
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_qkv_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_BATCH_MAX && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && Hq > 0 && Hkv > 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 &&
+                    ((Hq + 2 * Hkv) * D) % 32 == 0 && spad > 0,
+                "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 8, K %% 64 == 0, head_dim %% 32 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = (Hq + 2 * Hkv) * D; p.K = K;
+    p.bias = (const bf16*)bias; p.cos_t = (const bf16*)cos_t; p.sin_t = (const bf16*)sin_t; p.pos = pos; p.pos_stride = 1; p.start = start_dev;
+    p.q_out = (bf16*)q_out; p.ldq = ldq; p.Kc = (bf16*)kcache; p.k_bs = k_bs; p.Vt = (bf16*)vtcache; p.vt_bs = vt_bs; p.spad = spad; p.Hq = Hq; p.Hkv = Hkv; p.D = D;
+    p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
+    launch_chain_norm<EPI_QKV, 8>(p, p.N, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_qkv_norm_batched");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K,
+                                                     void* act_out, int64_t ld_act, const float* ss_part, int ss_nparts, void* stream) {
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_gate_up_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(x && norm_w && W && act_out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 8, I %% 16 == 0, K %% 64 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = 2 * I; p.K = K;
+    p.out = (bf16*)act_out; p.ld_out = ld_act; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
+    launch_chain_norm<EPI_SWIGLU, 4>(p, 2 * I, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_gate_up_norm_batched");
+    return AFK_OK;
+}
+
+extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K,
+                                                     float* logits, int64_t ld_logits, const float* ss_part, int ss_nparts, void* stream) {
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_lm_head_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(x && norm_w && W && logits && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 8, N %% 32 == 0, K %% 64 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K;
+    p.out_f32 = logits; p.ld_out = ld_logits; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
+    launch_chain_norm<EPI_LOGITS, 4>(p, N, ST);
+    AFK_LAUNCH_CHECK("afk_decode_chain_lm_head_norm_batched");
+    return AFK_OK;
+}
+
+// Linear + residual, 1 .. 8 sequences, on the matrix-pipe form (16-row groups x 8 K slices), that also leaves ss_part[N / 16][8]: every block's share of sum_n out[m][n]^2 -
+// the statistic of the RMSNorm that FOLLOWS, folded by the next Linear's prologue (afk_decode_chain_*_norm_batched with ss_part): no pass over the rows, no hand-over.
+extern "C" int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
+                                                           void* out, int64_t ld_out, float* ss_part, void* stream) {
+    AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 8, N %% 32 == 0, K %% 64 == 0)");
+    ChainArgs p = {};
+    p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
+    p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.ss_out = ss_part; p.kil = 1;
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID, 8, 16, true, false>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
+    AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_ss_batched");
     return AFK_OK;
 }
 

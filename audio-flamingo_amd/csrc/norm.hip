@@ -581,7 +581,10 @@ __global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const bf16* __rest
 }  // namespace
 
 // partial rows of afk_gelu_bwd_colsum (its workspace holds that many x C floats)
-extern "C" int afk_gelu_bwd_colsum_parts(int64_t rows) { return (int)(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
+extern "C" int afk_gelu_bwd_colsum_parts(int64_t rows) {
+    static const int cap = [] { const char* e = getenv("AFK_GELU_CS_PARTS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();   // measurement knob: 256 / 512 / 1024 parts = 113.9 / 105.4 / 103.9 us for [12000, 5120] incl. the fold (elementwise form + column-sum pass: 82 + 25)
+    return (int)(rows < cap ? (rows < 1 ? 1 : rows) : cap);
+}
 
 extern "C" int afk_gelu_bwd_colsum(const void* dy, const void* pre, void* dx, int64_t rows, int C, void* colsum, int colsum_accumulate, float* workspace,
                                    void* stream) {

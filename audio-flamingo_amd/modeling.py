@@ -1014,7 +1014,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
 
-    decode_fuse_norm = os.environ.get("AFK_DECODE_FUSE_NORM", "1") == "1"   # batched decode: RMSNorm inside the o_proj / down launches (A/B knob)
+    decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)
     decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
 
     def _decode_layers_chain_batched(self, x, B, cache, pos_rows, krange, start_dev, aws, head):
@@ -1033,50 +1033,75 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         eps = float(self.rms_eps)
         q = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
         o = torch.empty((B, nq), device=dev, dtype=torch.bfloat16)
-        # round 6: from four sequences on (the matrix-pipe regime of the batched launches) the RMSNorm that follows o_proj / down rides in that launch
-        # (afk_decode_chain_linear_residual_norm_batched: the last block to arrive normalises) - 5 launches per layer instead of 7
+        # round 6: from four sequences on (the matrix-pipe regime of the batched launches) no RMSNorm is a launch of its own.  "prologue" (default): the norm in
+        # front of qkv / gate|up / lm_head is taken in that Linear's own prologue (afk_decode_chain_*_norm_batched: every block derives the row statistic and
+        # normalises the rows it consumes) - 5 launches per layer; "producer": the norm rides behind o_proj / down (afk_decode_chain_linear_residual_norm_batched:
+        # the last block to arrive normalises; measured 8 / 5 us of hand-over per launch); "launch": afk_rmsnorm_fwd as in rounds 4-5 (7 launches per layer)
         I0 = a[f"{lm}layers.0.mlp.gate_up.weight"].data.shape[0] // 2
-        fuse_norm = (self.decode_fuse_norm and B >= 4 and H % 32 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0)
-        if fuse_norm:
+        shapes_ok = B >= 4 and H % 64 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0 and (D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0
+        mode = self.decode_norm_mode if shapes_ok else "launch"
+        if mode == "producer":
             cnt = getattr(self, "_chain_norm_counter", None)
             if cnt is None or cnt.device != dev:
                 cnt = self._chain_norm_counter = torch.zeros(1, device=dev, dtype=torch.int32)
-        h = None
+        h = ssx = None
+        _p = lambda t: None if t is None else t.data_ptr()
         for i in range(self.dec_layers):
             A = lambda k: a[f"{lm}layers.{i}.{k}"]
-            if h is None:
-                h, _ = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
             wqkv = A("self_attn.qkv.weight").data
-            _lib.call("afk_decode_chain_qkv_batched", h.data_ptr(), h.stride(0), B, wqkv.data_ptr(), wqkv.stride(0), H, A("self_attn.qkv.bias").data.data_ptr(),
-                      cos.data_ptr(), sin.data_ptr(), pos_rows.data_ptr(), q.data_ptr(), nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
-                      start_dev.data_ptr(), Hq, Hkv, D, st)
+            if mode == "prologue":   # ssx: the partial sums of squares the previous layer's down launch left for these rows (None: the first layer takes the statistic itself)
+                _lib.call("afk_decode_chain_qkv_norm_batched", x.data_ptr(), x.stride(0), B, A("input_layernorm.weight").data.data_ptr(), eps, wqkv.data_ptr(), wqkv.stride(0), H,
+                          A("self_attn.qkv.bias").data.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos_rows.data_ptr(), q.data_ptr(), nq, Kc[i].data_ptr(), Smax * nk,
+                          Vt[i].data_ptr(), Hkv * D * Spad, Spad, start_dev.data_ptr(), Hq, Hkv, D, _p(ssx), H // 16, st)
+            else:
+                if h is None:
+                    h, _ = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
+                _lib.call("afk_decode_chain_qkv_batched", h.data_ptr(), h.stride(0), B, wqkv.data_ptr(), wqkv.stride(0), H, A("self_attn.qkv.bias").data.data_ptr(),
+                          cos.data_ptr(), sin.data_ptr(), pos_rows.data_ptr(), q.data_ptr(), nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
+                          start_dev.data_ptr(), Hq, Hkv, D, st)
             _lib.call("afk_attn_decode_fused", q.data_ptr(), nq, D, Kc[i].data_ptr(), Smax * nk, nk, D, Vt[i].data_ptr(), Hkv * D * Spad, Spad,
                       o.data_ptr(), nq, D, krange.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, aws.data_ptr(), st)
             wo = A("self_attn.o_proj.weight").data
             x2 = torch.empty_like(x)
-            if fuse_norm:
+            h2 = None
+            if mode == "producer":
                 h2 = torch.empty_like(x)
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           A("post_attention_layernorm.weight").data.data_ptr(), eps, h2.data_ptr(), H, cnt.data_ptr(), st)
+            elif mode == "prologue":
+                ss2 = torch.empty((H // 16, 8), device=dev, dtype=torch.float32)
+                _lib.call("afk_decode_chain_linear_residual_ss_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
+                          ss2.data_ptr(), st)
             else:
                 _lib.call("afk_decode_chain_linear_residual_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H, st)
                 h2, _ = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
             wgu = A("mlp.gate_up.weight").data
             I = wgu.shape[0] // 2
             act = torch.empty((B, I), device=dev, dtype=torch.bfloat16)
-            _lib.call("afk_decode_chain_gate_up_batched", h2.data_ptr(), h2.stride(0), B, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), I, st)
+            if mode == "prologue":
+                _lib.call("afk_decode_chain_gate_up_norm_batched", x2.data_ptr(), x2.stride(0), B, A("post_attention_layernorm.weight").data.data_ptr(), eps, wgu.data_ptr(),
+                          wgu.stride(0), I, H, act.data_ptr(), I, ss2.data_ptr(), H // 16, st)
+            else:
+                _lib.call("afk_decode_chain_gate_up_batched", h2.data_ptr(), h2.stride(0), B, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), I, st)
             wd = A("mlp.down_proj.weight").data
             x = torch.empty_like(x2)
-            if fuse_norm:   # the norm that follows: the next layer's input_layernorm, or the model's final norm
+            if mode == "producer":   # the norm that follows: the next layer's input_layernorm, or the model's final norm
                 nxt = a[f"{lm}layers.{i + 1}.input_layernorm.weight"].data if i + 1 < self.dec_layers else a[lm + "norm.weight"].data
                 h = torch.empty_like(x2)
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H,
                           nxt.data_ptr(), eps, h.data_ptr(), H, cnt.data_ptr(), st)
+            elif mode == "prologue":
+                ssx = torch.empty((H // 16, 8), device=dev, dtype=torch.float32)
+                _lib.call("afk_decode_chain_linear_residual_ss_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, ssx.data_ptr(), st)
             else:
                 _lib.call("afk_decode_chain_linear_residual_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, st)
                 h = None
-        y = h if fuse_norm else ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, eps)[0]
         logits = torch.empty((B, head.shape[0]), device=dev, dtype=torch.float32)
+        if mode == "prologue":
+            _lib.call("afk_decode_chain_lm_head_norm_batched", x.data_ptr(), x.stride(0), B, a[lm + "norm.weight"].data.data_ptr(), eps, head.data_ptr(), head.stride(0),
+                      head.shape[0], H, logits.data_ptr(), head.shape[0], _p(ssx), H // 16, st)
+            return logits
+        y = h if mode == "producer" else ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, eps)[0]
         _lib.call("afk_decode_chain_lm_head_batched", y.data_ptr(), y.stride(0), B, head.data_ptr(), head.stride(0), head.shape[0], H, logits.data_ptr(), head.shape[0], st)
         return logits
 

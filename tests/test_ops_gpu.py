@@ -1305,6 +1305,86 @@ def test_decode_chain_batched_kernels_vs_standalone_sequence(dev, M, mfma, monke
 
 
 @pytest.mark.parametrize("M", [1, 4, 8])
+def test_decode_chain_norm_in_prologue_batched(dev, M):
+    """afk_decode_chain_{qkv,gate_up,lm_head}_norm_batched (RMSNorm taken in the Linear's own prologue, rows normalised through a wave-private LDS strip) against
+    afk_rmsnorm_fwd + the plain matrix-pipe launches at the AF3-7B widths: equal up to the fp32 summation order of the row statistic (a differing last bit of a
+    normalised bf16 value here and there), rows of different sequences do not mix, only the new cache slot is written"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    H, Hq, Hkv, D, I = 3584, 28, 4, 128, 18944
+    nq, nk = Hq * D, Hkv * D
+    N = nq + 2 * nk
+    st = ops._stream()
+    x = _rand((M, H), dev, 1.0, 1).to(BF)
+    nw = (1 + 0.1 * _rand((H,), dev, seed=2)).to(BF)
+    h, _ = ops.rmsnorm_fwd(x, nw, 1e-6)
+    w = _rand((N, H), dev, 0.02, 3).to(BF)
+    bias = _rand((N,), dev, 0.1, 4).to(BF)
+    Smax, start = 256, 41
+    spad = ops.pad64(Smax)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    fr = torch.arange(64, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    pos_t = torch.tensor([37 - 3 * m for m in range(M)], device=dev, dtype=torch.int32)
+    start_t = torch.tensor([start], device=dev, dtype=torch.int32)
+    qkv = ops.gemm_nt(h, w, bias=bias)
+    ops.rope_(qkv, cos, sin, S=1, nheads=Hq + Hkv, D=D, pos=pos_t)
+    Kc = torch.zeros((M, Smax, nk), device=dev, dtype=BF)
+    Vt = torch.zeros((M, Hkv, D, spad), device=dev, dtype=BF)
+    q = torch.zeros((M, nq), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_qkv_norm_batched", x.data_ptr(), H, M, nw.data_ptr(), 1e-6, w.data_ptr(), w.stride(0), H, bias.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+              pos_t.data_ptr(), q.data_ptr(), nq, Kc.data_ptr(), Smax * nk, Vt.data_ptr(), Hkv * D * spad, spad, start_t.data_ptr(), Hq, Hkv, D, None, 0, st)
+    torch.cuda.synchronize()
+    _cmp("norm-prologue q", q, qkv[:, :nq].float(), atol=3e-2, rtol=2e-2)
+    _cmp("norm-prologue k", Kc[:, start], qkv[:, nq:nq + nk].float(), atol=3e-2, rtol=2e-2)
+    _cmp("norm-prologue v", Vt[:, :, :, start].reshape(M, -1), qkv[:, nq + nk:].float(), atol=3e-2, rtol=2e-2)
+    Kc[:, start] = 0
+    Vt[:, :, :, start] = 0
+    assert float(Kc.float().abs().sum()) == 0.0 and float(Vt.float().abs().sum()) == 0.0, "only the new cache slot may be written"
+    wgu = _rand((2 * I, H), dev, 0.02, 7).to(BF)
+    act = torch.empty((M, I), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_gate_up_norm_batched", x.data_ptr(), H, M, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), I, None, 0, st)
+    _cmp("norm-prologue gate|up", act, ops.silu_mul_fwd(ops.gemm_nt(h, wgu)).float(), atol=3e-2, rtol=3e-2)
+    plain = torch.empty((M, I), device=dev, dtype=BF)   # the plain matrix-pipe launch on afk_rmsnorm_fwd's rows: the same products, so almost every value is bit-equal
+    import os as _os
+    _os.environ["AFK_CHAIN_MFMA"] = "1"
+    try:
+        _lib.call("afk_decode_chain_gate_up_batched", h.data_ptr(), H, M, wgu.data_ptr(), wgu.stride(0), I, H, plain.data_ptr(), I, st)
+    finally:
+        del _os.environ["AFK_CHAIN_MFMA"]
+    assert int((plain != act).sum()) <= M * I // 50, f"{int((plain != act).sum())} of {M * I} values differ from the norm-launch form"
+    solo = torch.empty((1, I), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_gate_up_norm_batched", x[M - 1:].data_ptr(), H, 1, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, solo.data_ptr(), I, None, 0, st)
+    assert torch.equal(solo[0], act[M - 1])
+    # the statistic from the PRODUCER's partial sums: o_proj-like Linear + residual writes the rows and ss_part, the next Linear folds them
+    a_in = _rand((M, nq), dev, 1.0, 11).to(BF)
+    wl = _rand((H, nq), dev, 0.02, 12).to(BF)
+    res = _rand((M, H), dev, 1.0, 13).to(BF)
+    rows_w = torch.empty((M, H), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_linear_residual_batched", a_in.data_ptr(), nq, M, wl.data_ptr(), wl.stride(0), H, nq, res.data_ptr(), H, rows_w.data_ptr(), H, st)
+    rows_s = torch.empty((M, H), device=dev, dtype=BF)
+    ssp = torch.full((H // 16, 8), float("nan"), device=dev, dtype=torch.float32)
+    _lib.call("afk_decode_chain_linear_residual_ss_batched", a_in.data_ptr(), nq, M, wl.data_ptr(), wl.stride(0), H, nq, res.data_ptr(), H, rows_s.data_ptr(), H, ssp.data_ptr(), st)
+    _cmp("linear+residual (ss form)", rows_s, rows_w.float(), atol=3e-2, rtol=2e-2)
+    want_ss = (rows_s.float() ** 2).sum(1)
+    got_ss = ssp.sum(0)[:M]
+    assert bool(((got_ss - want_ss).abs() <= 1e-4 * want_ss).all()) and float(ssp[:, M:].abs().sum()) == 0.0
+    act_b = torch.empty((M, I), device=dev, dtype=BF)
+    act_p = torch.empty((M, I), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_gate_up_norm_batched", rows_s.data_ptr(), H, M, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act_b.data_ptr(), I, None, 0, st)
+    _lib.call("afk_decode_chain_gate_up_norm_batched", rows_s.data_ptr(), H, M, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act_p.data_ptr(), I, ssp.data_ptr(), H // 16, st)
+    assert int((act_b != act_p).sum()) <= M * I // 50, f"{int((act_b != act_p).sum())} of {M * I} values differ between the two sources of the statistic"
+    _cmp("norm-prologue gate|up, producer's statistic", act_p, act_b.float(), atol=3e-2, rtol=3e-2)
+    V = 4096
+    wh = _rand((V, H), dev, 0.02, 8).to(BF)
+    logits = torch.empty((M, V), device=dev, dtype=torch.float32)
+    _lib.call("afk_decode_chain_lm_head_norm_batched", x.data_ptr(), H, M, nw.data_ptr(), 1e-6, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), V, None, 0, st)
+    assert torch.equal(logits, logits.to(BF).float())
+    _cmp("norm-prologue lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("M", [1, 4, 8])
 def test_decode_chain_linear_residual_norm_fused(dev, M):
     """afk_decode_chain_linear_residual_norm_batched (Linear + residual + the RMSNorm that follows in one launch; the last block to arrive normalises) against
     the two-launch sequence at the AF3-7B widths: the residual stream bit-equal to the plain batched launch of the same form, the normalised rows equal to
