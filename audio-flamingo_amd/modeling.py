@@ -1014,6 +1014,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y, _ = ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, self.rms_eps)
         return y
 
+    decode_mfma_from = int(os.environ.get("AFK_DECODE_MFMA_FROM", "2"))   # batched decode: sequences per step from which the norm-in-prologue matrix-pipe launches run
     decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)
     decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
 
@@ -1038,7 +1039,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         # normalises the rows it consumes) - 5 launches per layer; "producer": the norm rides behind o_proj / down (afk_decode_chain_linear_residual_norm_batched:
         # the last block to arrive normalises; measured 8 / 5 us of hand-over per launch); "launch": afk_rmsnorm_fwd as in rounds 4-5 (7 launches per layer)
         I0 = a[f"{lm}layers.0.mlp.gate_up.weight"].data.shape[0] // 2
-        shapes_ok = B >= 4 and H % 64 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0 and (D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0
+        shapes_ok = B >= self.decode_mfma_from and H % 64 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0 and (D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0
         mode = self.decode_norm_mode if shapes_ok else "launch"
         if mode == "producer":
             cnt = getattr(self, "_chain_norm_counter", None)
