@@ -414,6 +414,198 @@ __global__ __launch_bounds__(256) void attn_decode_group_kernel(const bf16* __re
     finish();
 }
 
+// Round 6 - the group form on the MATRIX PIPE (afk_attn_decode_set_group(3) / AFK_ATTN_DECODE_GROUP=3; default for batched steps, see attn_decode_impl).  The per-head
+// form brings 7 blocks per CU to a B = 8 step and is bound by wave dispatch (224 blocks per XCD, ~36 ns each) + one 10 us block life; the VALU group form above has 256
+// blocks but G times the dot-product work per thread.  Here a block = (sample, KV head, key chunk) serves the G <= 8 query heads of the group with two small GEMMs:
+//   S[key][head]  = K[key][:] . Q[head][:]      v_mfma_f32_32x32x16_bf16, A = 32 key rows (16-byte pieces straight from the cache rows), B = the G query rows
+//   O[d][head]   += Vt[d][key] . P[key][head]   A = 32 rows of the transposed value cache (8 consecutive keys per lane), B = the bf16 probabilities
+// wave w owns key tiles w, w + 4, ... of the scores and feature tile(s) w (, w + 4) of the output; softmax (chunk maximum, exp2, sum of the bf16-rounded
+// probabilities - what the P.V product sees, as the training kernels count) goes through the score rows in LDS exactly as above, and so do the partials, the
+// hand-over and the merge (same workspace layout).  Summation order differs from the per-head kernel: equal within fp32 / bf16 rounding, not bit for bit.
+template <int D, int G>
+__global__ __launch_bounds__(256) void attn_decode_gmma_kernel(const bf16* __restrict__ Q, int64_t q_bs, int64_t q_hs, const bf16* __restrict__ Kc,
+                                                               int64_t k_bs, int64_t k_rs, int64_t k_hs, const bf16* __restrict__ Vt,
+                                                               int64_t vt_bs, int spad, const int* __restrict__ krange, int Hq, int Hkv,
+                                                               float scale, float* __restrict__ ws, bf16* __restrict__ O, int64_t o_bs, int64_t o_hs) {
+    constexpr int PARTS = 256 / D;
+    constexpr int SROW = GCHUNK + 8;
+    constexpr int KS = D / 16;          // k-steps of the score GEMM
+    constexpr int DT = D / 32;          // 32-feature tiles of the output
+    __shared__ __attribute__((aligned(16))) float sc[GROUP_LDS_FLOATS];   // [G][SROW] scores / probabilities; later the merge's staging area
+    __shared__ float red[2][G][4];
+    __shared__ int last_flag;
+    const int split = blockIdx.x, nsplit = gridDim.x, hk = blockIdx.y, b = blockIdx.z, h0 = hk * G;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int lo = krange[2 * b], hi_key = krange[2 * b + 1];
+    const int a0 = lo & ~7, total = max(hi_key - a0, 0);
+    const int chunk = min((((total + nsplit - 1) / nsplit) + 7) & ~7, GCHUNK);
+    const int c0 = a0 + split * chunk, c1 = min(c0 + chunk, hi_key);
+    const int n = max(c1 - c0, 0);
+    auto slot = [&](int g) { return ws + ((int64_t)(b * Hq + h0 + g) * nsplit + split) * (D + 2); };
+    auto put = [&](float* dst, float v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [&](const float* src) -> float { return __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto finish = [&]() {   // hand-over + merge: attn_decode_group_kernel's, word for word
+        int* counters = (int*)(ws + (int64_t)gridDim.z * Hq * nsplit * (D + 2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            const int prev = __hip_atomic_fetch_add(&counters[b * Hq + h0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_flag = (prev == nsplit - 1);
+            if (last_flag) __hip_atomic_store(&counters[b * Hq + h0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_flag) return;
+        const float* base = ws + (int64_t)(b * Hq + h0) * nsplit * (D + 2);
+        const int tot = G * nsplit * (D + 2);
+        constexpr int NL = 16;
+        for (int i = t; i < tot; i += 256 * NL) {
+            float v[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+                if (i + 256 * u < tot) sc[i + 256 * u] = v[u];
+        }
+        __syncthreads();
+        for (int g = t / D; g < G; g += PARTS) {
+            const int d = t % D;
+            const float* sg = sc + g * nsplit * (D + 2);
+            float M = NEG_INF;
+            for (int s = 0; s < nsplit; ++s) M = fmaxf(M, sg[s * (D + 2)]);
+            float L = 0.f, o = 0.f;
+            if (M != NEG_INF) {
+                for (int s = 0; s < nsplit; ++s) {
+                    const float wgt = __builtin_amdgcn_exp2f(sg[s * (D + 2)] - M);
+                    L += wgt * sg[s * (D + 2) + 1];
+                    o += wgt * sg[s * (D + 2) + 2 + d];
+                }
+            }
+            O[b * o_bs + (h0 + g) * o_hs + d] = (bf16)(L > 0.f ? o / L : 0.f);
+        }
+    };
+    if (n <= 0 || c1 <= lo) {
+        for (int g = 0; g < G; ++g) {
+            if (t < D) put(slot(g) + 2 + t, 0.f);
+            if (t == 0) { put(slot(g), NEG_INF); put(slot(g) + 1, 0.f); }
+        }
+        finish();
+        return;
+    }
+    // ---- operands of the first key tile and the first value batch are requested before anything is computed
+    const int gq = min(l31, G - 1);                                             // lanes beyond the group repeat its last head: columns nobody reads
+    const bf16* qrow = Q + b * q_bs + (h0 + gq) * q_hs + hi * 8;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int s4 = 0; s4 < KS; ++s4) qf[s4] = *(const bf16x8*)(qrow + s4 * 16);
+    const bf16* kbase = Kc + b * k_bs + hk * k_hs + hi * 8 + (int64_t)c0 * k_rs;
+    auto load_k = [&](bf16x8(&dst)[KS], int tile) {
+        const bf16* kr = kbase + (int64_t)min(tile * 32 + l31, n - 1) * k_rs;  // clamped: valid memory, masked below
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) dst[s4] = *(const bf16x8*)(kr + s4 * 16);
+    };
+    const int ntile = (n + 31) >> 5;
+    bf16x8 kf[KS];
+    if (w < ntile) load_k(kf, w);
+    constexpr int VB = 8;   // value k-steps (16 keys each) per register batch
+    const int nks = (n + 15) >> 4;
+    const bf16* vbase = Vt + b * vt_bs + ((int64_t)hk * D + l31) * spad + c0 + hi * 8;   // + dtile * 32 * spad, + ks * 16
+    auto load_v = [&](bf16x8(&dst)[VB], int dt, int ks0) {
+#pragma unroll
+        for (int u = 0; u < VB; ++u) {
+            const int ks = min(ks0 + u, nks - 1);
+            const int koff = ks * 16 + hi * 8 < n ? ks * 16 : -hi * 8;   // a half-step entirely behind the last key re-reads the chunk's first keys (valid memory; zeroed below)
+            dst[u] = *(const bf16x8*)(vbase + (int64_t)dt * 32 * spad + koff);
+        }
+    };
+    bf16x8 vf[VB];
+    if (w < DT) load_v(vf, w, 0);
+    const float c2 = scale * LOG2E;
+    // ---- scores: S tile = 32 keys x 32 (G used) heads per MFMA chain; lane (head l31, hi) holds keys 8 q + 4 hi + e of the tile
+    float mx = NEG_INF;
+    for (int tile = w; tile < ntile; tile += 4) {
+        if (tile != w) load_k(kf, tile);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < KS; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s4], qf[s4], acc, 0, 0, 0);
+        if (l31 < G) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = tile * 32 + 8 * q + 4 * hi + e;
+                    const int key = c0 + i;
+                    const float sv = (i < n && key >= lo) ? acc[4 * q + e] * c2 : NEG_INF;   // log2 domain
+                    if (i < n) sc[l31 * SROW + i] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+        }
+    }
+    // chunk maximum per head: the two lane halves of a wave, then the four waves
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lane < G) red[0][lane][w] = mx;
+    __syncthreads();
+    // ---- probabilities (every thread a strided share of the G x n scores), rounded to bf16 as the P.V product reads them; zeros up to a whole k-step
+    float ls[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) ls[g] = 0.f;
+    const int npad = nks << 4;
+    for (int i = t; i < npad; i += 256) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float m = fmaxf(fmaxf(red[0][g][0], red[0][g][1]), fmaxf(red[0][g][2], red[0][g][3]));
+            const float msafe = (m == NEG_INF) ? 0.f : m;
+            const float pr = i < n ? rbf(__builtin_amdgcn_exp2f(sc[g * SROW + i] - msafe)) : 0.f;
+            sc[g * SROW + i] = pr;
+            ls[g] += pr;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float v = wave_sum(ls[g]);
+        if (lane == 0) red[1][g][w] = v;
+    }
+    __syncthreads();
+    // ---- output: wave w owns feature tiles w, w + 4, ...; O tile = 32 features x 32 (G used) heads, k = keys
+    for (int dt = w; dt < DT; dt += 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int ks0 = 0; ks0 < nks; ks0 += VB) {
+            if (ks0 || dt != w) load_v(vf, dt, ks0);
+#pragma unroll
+            for (int u = 0; u < VB; ++u) {
+                const int ks = ks0 + u;
+                if (ks < nks) {   // block-uniform
+                    const int k0 = ks * 16 + hi * 8;
+                    bf16x8 pv, vv = vf[u];
+                    const float* pp = &sc[gq * SROW + k0];
+                    const f32x4 p0 = *(const f32x4*)pp, p1 = *(const f32x4*)(pp + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        pv[e] = (bf16)(e < 4 ? p0[e & 3] : p1[e & 3]);
+                        if (k0 + e >= n) vv[e] = (bf16)0.f;   // what lies behind the last key may be anything (0 x NaN)
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vv, pv, acc, 0, 0, 0);
+                }
+            }
+        }
+        if (l31 < G) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) put(slot(l31) + 2 + dt * 32 + 8 * q + 4 * hi + e, acc[4 * q + e]);
+        }
+    }
+    if (t < G) {
+        const float m = fmaxf(fmaxf(red[0][t][0], red[0][t][1]), fmaxf(red[0][t][2], red[0][t][3]));
+        put(slot(t), m);
+        put(slot(t) + 1, red[1][t][0] + red[1][t][1] + red[1][t][2] + red[1][t][3]);
+    }
+    finish();
+}
+
 template <int D>
 __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __restrict__ ws, int nsplit, bf16* __restrict__ O, int64_t o_bs,
                                                                int64_t o_hs, int Hq) {
@@ -436,9 +628,10 @@ __global__ __launch_bounds__(D) void attn_decode_combine_kernel(const float* __r
 
 extern "C" int afk_attn_decode_workspace_floats(int B, int Hq, int D, int nsplit) { return B * Hq * nsplit * (D + 2) + B * Hq; }   // + arrival counters (afk_attn_decode_fused)
 
-static std::atomic<int> g_group_mode{[] { const char* e = getenv("AFK_ATTN_DECODE_GROUP"); return e ? atoi(e) : 0; }()};
+static std::atomic<int> g_group_mode{[] { const char* e = getenv("AFK_ATTN_DECODE_GROUP"); return e ? atoi(e) : -1; }()};
 extern "C" int afk_attn_decode_set_group(int mode) {
-    AFK_REQUIRE(mode >= 0 && mode <= 2, "afk_attn_decode_set_group: mode %d (0 per-head, 1 group form from 128 blocks on, 2 group form whenever it fits)", mode);
+    AFK_REQUIRE(mode >= -1 && mode <= 3,
+                "afk_attn_decode_set_group: mode %d (-1 default: per-head, matrix-pipe group form for large launches; 0 per-head; 1 / 2 VALU group form from 128 blocks on / whenever it fits; 3 matrix-pipe group form)", mode);
     g_group_mode.store(mode, std::memory_order_relaxed);
     return AFK_OK;
 }
@@ -458,12 +651,33 @@ static int attn_decode_impl(bool fused, const void* Q, int64_t q_bs, int64_t q_h
     // argument that the G per-head blocks re-fetch the same K / V chunk, bit-identical to the per-head form - and MEASURED 1-2 % SLOWER on the B = 8 step
     // (4.50 / 4.54 vs 4.45 / 4.46 ms, alternating runs on one box, profiles/r05_kernel_ab.md): with nsplit = 8 the blocks of one chunk index already share
     // an XCD (linear block id mod 8 = chunk index), so the L2 serves the G - 1 re-reads, and 256 blocks of 4 waves hide less latency than 1 792.
-    // afk_attn_decode_set_group / AFK_ATTN_DECODE_GROUP: 1 = group form from 128 blocks on, 2 = whenever its limits hold
+    // afk_attn_decode_set_group / AFK_ATTN_DECODE_GROUP: -1 = default (below), 0 = per-head, 1 = VALU group form from 128 blocks on, 2 = whenever its limits hold, 3 = matrix-pipe group form
     const int group_mode = g_group_mode.load(std::memory_order_relaxed);
     const int G = Hq / Hkv;
     const bool group_fits = fused && sync == 1 && G >= 2 && (int64_t)spad <= (int64_t)nsplit * GCHUNK && G * nsplit * (D + 2) <= GROUP_LDS_FLOATS &&
                             (G == 2 || G == 4 || G == 7 || G == 8);
-    if (group_fits && group_mode && (group_mode == 2 || B * Hkv * nsplit >= GROUP_MIN_BLOCKS)) {
+    // matrix-pipe group form (round 6): on request, or by itself (mode -1, the default) when the per-head form would bring more than four blocks per CU - measured at the
+    // AF3-7B geometry, 800 keys, us per launch: B = 8  21.1 per-head / 17.6 here (1 500 keys: 27.4 / 21.7), B = 4  15.7 / 17.0, B = 2  13.0 / 15.6
+    const bool gmma_auto = group_mode == -1 && (int64_t)nsplit * Hq * B > 4 * 256;
+    if (group_fits && (group_mode == 3 || gmma_auto) && G <= 8 && spad % 8 == 0) {
+        const dim3 ggrid((unsigned)nsplit, (unsigned)Hkv, (unsigned)B);
+#define AFK_ADM(DD, GG)                                                                                                                                   \
+    hipLaunchKernelGGL((attn_decode_gmma_kernel<DD, GG>), ggrid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs,         \
+                       (const bf16*)Vt, vt_bs, spad, krange, Hq, Hkv, scale, workspace, (bf16*)O, o_bs, o_hs)
+#define AFK_ADM_D(DD)                                      \
+    do {                                                   \
+        if (G == 2) AFK_ADM(DD, 2);                        \
+        else if (G == 4) AFK_ADM(DD, 4);                   \
+        else if (G == 7) AFK_ADM(DD, 7);                   \
+        else AFK_ADM(DD, 8);                               \
+    } while (0)
+        if (D == 128) AFK_ADM_D(128); else AFK_ADM_D(64);
+#undef AFK_ADM_D
+#undef AFK_ADM
+        AFK_LAUNCH_CHECK("afk_attn_decode_fused (matrix-pipe group form)");
+        return AFK_OK;
+    }
+    if (group_fits && group_mode > 0 && group_mode != 3 && (group_mode == 2 || B * Hkv * nsplit >= GROUP_MIN_BLOCKS)) {
         const dim3 ggrid((unsigned)nsplit, (unsigned)Hkv, (unsigned)B);
 #define AFK_ADG(DD, GG)                                                                                                                                   \
     hipLaunchKernelGGL((attn_decode_group_kernel<DD, GG>), ggrid, dim3(256), 0, st, (const bf16*)Q, q_bs, q_hs, (const bf16*)Kc, k_bs, k_rs, k_hs,        \

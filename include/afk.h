@@ -324,10 +324,12 @@ int afk_attn_decode(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, i
 int afk_attn_decode_fused(const void* Q, int64_t q_bs, int64_t q_hs, const void* Kc, int64_t k_bs, int64_t k_rs, int64_t k_hs,
                           const void* Vt, int64_t vt_bs, int spad, void* O, int64_t o_bs, int64_t o_hs, const int* krange, int B,
                           int Hq, int Hkv, int D, float scale, int nsplit, float* workspace, void* stream);
-/* Form of afk_attn_decode_fused for GQA caches (round 5): 0 (default) one block per (sample, QUERY head, chunk); 1 = one block per (sample, KV head, chunk)
- * serving all Hq / Hkv query heads of the group when the launch has >= 128 such blocks, 2 = whenever the form's limits hold (Hq / Hkv in {2, 4, 7, 8},
- * spad <= nsplit * 1024, (Hq / Hkv) * nsplit * (D + 2) <= 8384).  Results are bit-identical between the forms; the group form measured 1-2 % slower on
- * the B = 8 decode step of AF3-7B and is kept for A/B runs.  Env AFK_ATTN_DECODE_GROUP sets the initial mode. */
+/* Form of afk_attn_decode_fused for GQA caches: 0 one block per (sample, QUERY head, chunk); 1 = one block per (sample, KV head, chunk) serving all Hq / Hkv query
+ * heads of the group on the vector units when the launch has >= 128 such blocks, 2 = whenever the form's limits hold (Hq / Hkv in {2, 4, 7, 8}, spad <= nsplit * 1024,
+ * (Hq / Hkv) * nsplit * (D + 2) <= 8384) - forms 0 .. 2 are bit-identical to each other; 3 (round 6) = the group form on the matrix pipe (K.Q^T and Vt.P as
+ * v_mfma_f32_32x32x16_bf16 chains, probabilities rounded to bf16 as SDPA's bf16 softmax output is: equal to the others within that rounding, not bit for bit);
+ * -1 (default) = form 0, and form 3 by itself when form 0 would launch more than 1 024 blocks (B = 8 step of AF3-7B: 21.1 -> 17.6 us per layer).
+ * Env AFK_ATTN_DECODE_GROUP sets the initial mode. */
 int afk_attn_decode_set_group(int mode);
 
 /* Decode-step glue (csrc/decode_glue.hip): the weight-streaming first pass alone, and one kernel per Linear of a decoder layer that sums

@@ -1078,7 +1078,57 @@ def test_attn_decode_group_kernel_bit_equal(dev, D, Hq, Hkv, B):
     try:
         _group_checks(_lib, ops, dev, q, kc, vt, kr, B, Hq, Hkv, D, Smax, spad, nk, nq)
     finally:
-        _lib.call("afk_attn_decode_set_group", 0)
+        _lib.call("afk_attn_decode_set_group", -1)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,B", [(128, 28, 4, 8), (128, 28, 4, 2), (64, 16, 4, 8), (128, 8, 4, 5), (64, 8, 1, 3)])
+def test_attn_decode_matrix_pipe_group_form(dev, D, Hq, Hkv, B):
+    """round 6: the group form on the matrix pipe (attn_decode_gmma_kernel, afk_attn_decode_set_group(3)): K.Q^T and Vt.P as v_mfma_f32_32x32x16_bf16 chains, probabilities
+    rounded to bf16 as the product reads them.  Against the per-head launches (same inputs: equal within bf16 rounding of the probabilities) and against fp32 softmax
+    attention; ragged / left-padded ranges, a nearly empty sample, a key range that ends at the last cache slot, repeated calls, counters left at zero, determinism"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    Smax = 1280   # a multiple of 64: spad == Smax, the last chunk ends at the row's end
+    spad = ops.pad64(Smax)
+    nk, nq = Hkv * D, Hq * D
+    q = _rand((B, nq), dev, 1.0, 1).to(BF)
+    kc = _rand((B, Smax, nk), dev, 1.0, 2).to(BF)
+    vt = _rand((B, Hkv, D, spad), dev, 1.0, 3).to(BF)
+    vt[:, :, :, 1275:] = float("nan")   # behind the last key of sample 1: must never reach a sum
+    kr = torch.tensor([[(13 * b) % 50, max(1280 - 150 * b, 60)] for b in range(B)], device=dev, dtype=torch.int32)
+    kr[0] = torch.tensor([0, 1280], device=dev, dtype=torch.int32)
+    vt[0] = _rand((Hkv, D, spad), dev, 1.0, 4).to(BF)
+    if B > 1:
+        kr[1] = torch.tensor([3, 1275], device=dev, dtype=torch.int32)
+    kr[-1] = torch.tensor([5, 9], device=dev, dtype=torch.int32)
+    for ns in (8, 4):
+        nws = _lib.load().afk_attn_decode_workspace_floats(B, Hq, D, ns)
+        args = lambda o, ws: (q.data_ptr(), nq, D, kc.data_ptr(), Smax * nk, nk, D, vt.data_ptr(), Hkv * D * spad, spad, o.data_ptr(), nq, D,
+                              kr.data_ptr(), B, Hq, Hkv, D, float(D ** -0.5), ns, ws.data_ptr(), ops._stream())
+        o2 = torch.empty((B, nq), device=dev, dtype=BF)
+        _lib.call("afk_attn_decode", *args(o2, torch.empty(nws, device=dev, dtype=torch.float32)))
+        ws1 = torch.zeros(nws, device=dev, dtype=torch.float32)
+        outs = []
+        _lib.call("afk_attn_decode_set_group", 3)
+        try:
+            for rep in range(3):
+                o1 = torch.full((B, nq), 7.0, device=dev, dtype=BF)
+                _lib.call("afk_attn_decode_fused", *args(o1, ws1))
+                torch.cuda.synchronize()
+                outs.append(o1)
+                assert int(ws1[-B * Hq:].view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
+        finally:
+            _lib.call("afk_attn_decode_set_group", -1)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert bool(torch.isfinite(outs[0].float()).all())
+        _cmp(f"matrix-pipe group form vs per-head ns={ns}", outs[0], o2.float(), atol=2e-2, rtol=2e-2)
+    for b in range(B):
+        lo, hi = int(kr[b, 0]), int(kr[b, 1])
+        qq = q[b].float().view(Hq, D)
+        kk = kc[b, lo:hi].float().view(hi - lo, Hkv, D).repeat_interleave(Hq // Hkv, 1)
+        vv = vt[b, :, :, lo:hi].float().permute(2, 0, 1).repeat_interleave(Hq // Hkv, 1)
+        pr = torch.softmax(torch.einsum("hd,shd->hs", qq, kk) * D ** -0.5, -1)
+        _cmp(f"matrix-pipe group decode attention b={b}", outs[0][b], torch.einsum("hs,shd->hd", pr, vv).reshape(-1), atol=2e-2, rtol=2e-2)
 
 
 def _group_checks(_lib, ops, dev, q, kc, vt, kr, B, Hq, Hkv, D, Smax, spad, nk, nq):
@@ -1138,6 +1188,7 @@ def test_last_block_hand_over_under_memory_load(dev):
     o_want = torch.empty((B, nq), device=dev, dtype=BF)
     _lib.call("afk_attn_decode", *dargs(o_want, torch.empty(nws, device=dev, dtype=torch.float32), ops._stream()))
     torch.cuda.synchronize()
+    _lib.call("afk_attn_decode_set_group", 0)   # the per-head form: bit-comparable with the two-launch result (a launch this size takes the matrix-pipe group form by default)
     N = 150
     outs, douts = [], []
     with torch.cuda.stream(load_stream):
@@ -1161,6 +1212,7 @@ def test_last_block_hand_over_under_memory_load(dev):
     bad = sum(int(not torch.equal(o, want)) for o in outs)
     dbad = sum(int(not torch.equal(o, o_want)) for o, _ in douts)
     assert bad == 0 and dbad == 0, f"hand-over lost partials: colsum {bad}/{len(outs)}, decode attention {dbad}/{len(douts)} launches differ"
+    _lib.call("afk_attn_decode_set_group", -1)
     assert all(int(w[-B * Hq:].view(torch.int32).abs().sum()) == 0 for _, w in douts) and all(int(c.abs().sum()) == 0 for c in cnt.values())
 
 
