@@ -62,7 +62,7 @@ struct ChainArgs {
     int* n2_counter;      // one zero-initialised int32 (self-resetting)
     float* ss_out;        // EPI_RESID (matrix-pipe form), or null: ss_out[block][8] = this block's share of sum(out[m][:]^2) per sequence - the consumer's RMSNorm statistic
     const float* ss_in;   // PRO_RMS, or null: the producer's partial sums [ss_nparts][8] of the rows in x (null: every block takes the statistic from x itself)
-    int ss_nparts;
+    int ss_nparts, ss_first;
     int kil;              // gemv_chain_mfma_kernel: stages of the K loop dealt round-robin to the waves of a block (1) or one contiguous slice per wave (0)
     float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
     int* part_idx;        //             ... and its row (lowest row among equals); or null
@@ -563,7 +563,10 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     const bf16* xrow = p.x + (int64_t)min(xm, p.M - 1) * p.ldx + xpc * 8;
     float my_rstd = 0.f;
     if constexpr (PRO == PRO_RMS) {
-        if (b0 < b1) gload(ga, b0);   // the first weights travel while the statistic is taken
+        // the partial sums are requested AHEAD of the first weights (loads return in order: behind them the statistic would only be known once 8 KiB of weights had
+        // landed): qkv 15.5 -> 14.2 us, lm_head 175 -> 171.5 at M = 8, gate|up level (AFK_CHAIN_SS_FIRST=0: A/B)
+        const bool ss_first = p.ss_in != nullptr && p.ss_first;
+        if (b0 < b1 && !ss_first) gload(ga, b0);   // the first weights travel while the statistic is taken
 #ifdef AFK_PROBES
         if (p.eps < 0.f) my_rstd = 1.f;   // timing probe (wrong results): no statistic pass
         else
@@ -578,6 +581,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
                 const int gp = 8 * i + xpc;
                 v[i] = gp < p.ss_nparts ? p.ss_in[gp * MBX + xm] : 0.f;
             }
+            if (b0 < b1 && ss_first) gload(ga, b0);
             float a = 0.f;
 #pragma unroll
             for (int i = 0; i < NP8; ++i) a += v[i];
@@ -1153,7 +1157,9 @@ int launch_chain_norm(ChainArgs p, int rows, hipStream_t st) {
         hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
+    static const int ssf = [] { const char* e = getenv("AFK_CHAIN_SS_FIRST"); return e && e[0] == '0' ? 0 : 1; }();
     p.kil = 1;
+    p.ss_first = ssf;
     hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>), dim3((unsigned)(rows / 32)), dim3(64 * S), LDS, st, p);
     return AFK_OK;
 }
