@@ -99,12 +99,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
         // staged in the score buffer - nobody reads scores any more
         const float* base = ws + (int64_t)(b * Hq + h) * nsplit * (D + 2);
         const int tot = nsplit * (D + 2);
-        for (int i = t; i < tot; i += 1024) {
-            float v[4];
+        constexpr int NLM = 5;   // 8 chunks x (128 + 2) words = 1 040: with four loads per thread and round (1 024 words) the last 16 words cost a second memory round trip
+        for (int i = t; i < tot; i += 256 * NLM) {
+            float v[NLM];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));   // clamped: four loads in flight, no branch between them
+            for (int u = 0; u < NLM; ++u) v[u] = get(base + min(i + 256 * u, tot - 1));   // clamped: all loads of a round in flight, no branch between them
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NLM; ++u)
                 if (i + 256 * u < tot) sc[i + 256 * u] = v[u];
         }
         __syncthreads();
