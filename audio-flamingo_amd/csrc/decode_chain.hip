@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64 * (S > 4 ? S : 4)) void gemv_chain_batched_kerne
 // COOPERATIVELY (lane -> row lane >> 3, 16-byte piece lane & 7: every lane carries real data), normalises them (cast before the weight multiply), parks the bf16
 // rows in a wave-private LDS strip and reads the MFMA's B fragments back from there (LDS operations of one wave execute in order): 2 NB loads and ~40 VALU
 // instructions per block instead of 4 masked fragment loads per block and a kernel launch per norm.
-template <int EPI, int S, int RG, bool XMASK, bool AHEAD = false, int PRO = PRO_PLAIN>
+template <int EPI, int S, int RG, int PRO = PRO_PLAIN>
 __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
     constexpr int JR = RG / 8;          // load instructions per 64-element block (8 rows x 128 bytes each)
@@ -637,11 +637,11 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
         }
     }
     // the B fragments (L2-resident input rows), two blocks at a time.  Column j of the MFMA result depends on column j of B alone and only columns < M are read
-    // afterwards, so only the lanes of real sequences load (XMASK: a quarter of the lanes at M = 8 - the other lanes' registers keep their zeros).
+    // afterwards, so only the lanes of real sequences load (a quarter of the lanes at M = 8 - the other lanes' registers keep their zeros; no effect on the time measured, round 6).
     // HOIST (S <= 8: the registers are there): ALL of a four-block stage's fragments are requested ahead of the next stage's weight loads - loads return in order,
     // so the second pair, requested behind them (round 4), could only be used once the whole next stage had landed.
     constexpr bool HOIST = NB == 4 && S <= 8;
-    const bool xlane = !XMASK || l31 < p.M;
+    const bool xlane = l31 < p.M;
     auto xload2 = [&](bf16x8(&dst)[8], int kb) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -730,52 +730,6 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
             for (int kb = b0; kb < b1; kb += 2 * STEP) {
                 consumeN(ga, gb, kb);
                 if (kb + STEP < b1) consumeN(gb, ga, kb + STEP);
-            }
-        }
-    } else if constexpr (AHEAD) {
-        // the narrow Linears (S <= 8: 256 VGPRs): a stage's input fragments travel WITH its weights, one stage ahead - a wave never sits out an L2 round trip
-        // for its input rows between the arrival of a stage's weights and its MFMAs
-        bf16x8 xs0[4 * NB], xs1[4 * NB];
-#pragma unroll
-        for (int i = 0; i < 4 * NB; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xs0[i][e] = xs1[i][e] = (bf16)0.f;
-        auto xloadN = [&](bf16x8(&dst)[4 * NB], int kb) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const int kk = min(kb + b, b1 - 1) << 6;
-                if (xlane) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) dst[b * 4 + st] = *(const bf16x8*)(xp + kk + st * 16);
-                }
-            }
-        };
-        auto consumeA = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], const bf16x8(&xc)[4 * NB], bf16x8(&xn)[4 * NB], int kb) {
-            if (kb + STEP < b1) {
-                xloadN(xn, kb + STEP);
-                gload(nxt, kb + STEP);
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (kb + b < b1) {   // wave-uniform
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const bf16x8 wf = *(const bf16x8*)(my + b * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xc[b * 4 + st], acc, 0, 0, 0);
-                    }
-                }
-            }
-        };
-        if (b0 < b1) {
-            xloadN(xs0, b0);
-            gload(ga, b0);
-            for (int kb = b0; kb < b1; kb += 2 * STEP) {
-                consumeA(ga, gb, xs0, xs1, kb);
-                if (kb + STEP < b1) consumeA(gb, ga, xs1, xs0, kb + STEP);
             }
         }
     } else if (b0 < b1) {
@@ -928,6 +882,258 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     }
 }
 
+// 9 .. 16 sequences per step (round 6): the norm-in-prologue / LDS-strip launches above for NG = 2 GROUPS of eight sequences in one pass over the weights (NG = 4
+// compiles and is correct but loses to the tile path: see AFK_CHAIN_SEQ_MAX).
+// Rounds 3-5 sent batches above eight down the split-K tile path (B = 9: 5.7 ms per step against 3.6 at B = 8 - fewer tokens per second than the smaller batch).  A
+// group is an independent instance of the eight-sequence arithmetic (its own rows, statistic, accumulator block, epilogue) - index for index the code of
+// gemv_chain_mfma_kernel - sharing the weight stages: a stage's weights are written to the wave's LDS area once and every group multiplies them with its own strip of
+// (normalised) rows, which reuses ONE strip (LDS operations of a wave execute in order).  Every block barrier is executed by every thread (no early exits: the
+// epilogue runs once per group).  ss_in / ss_out are [NG][parts][8].
+template <int EPI, int S, int RG, int PRO, int NG>
+__global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p) {
+    constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
+    constexpr int JR = RG / 8, NB = 8 / JR, BLK = RG * 128;
+    static_assert(S >= 4 && S <= 8 && (RG == 32 || RG == 16) && (PRO == PRO_RMS || PRO == PRO_PLAIN_LDS) && NG >= 2 && NG <= 4, "see gemv_chain_mfma_kernel");
+    static_assert(EPI == EPI_QKV || EPI == EPI_RESID || EPI == EPI_SWIGLU || EPI == EPI_LOGITS, "no hand-over epilogue here");
+    extern __shared__ __attribute__((aligned(16))) char stage_dyn[];
+    char(*stage)[8192] = (char(*)[8192])stage_dyn;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = blockIdx.x;
+    int rA, rB;
+    const int half = p.D >> 1, nq = p.Hq * p.D, nk = p.Hkv * p.D;
+    const int rot_groups = (p.Hq + p.Hkv) * half / HR;
+    if (EPI == EPI_QKV) {
+        if (g < rot_groups) {
+            const int per_head = half / HR;
+            rA = (g / per_head) * p.D + (g % per_head) * HR;
+            rB = rA + half;
+        } else {
+            rA = nq + nk + R * (g - rot_groups);
+            rB = rA + HR;
+        }
+    } else if (EPI == EPI_SWIGLU) {
+        rA = HR * g;
+        rB = (p.N >> 1) + rA;
+    } else {
+        rA = R * g;
+        rB = rA + HR;
+    }
+    const int nkb = p.K >> 6;
+    const int b0 = w * NB, b1 = nkb, STEP = S * NB;   // stages dealt round-robin to the waves
+    const int rowl = lane >> 3, piece = lane & 7;
+    const bf16* wp[JR];
+    uint32_t wr_off[JR];
+    char* my = &stage[w][0];
+#pragma unroll
+    for (int j = 0; j < JR; ++j) {
+        const int r = 8 * j + rowl;
+        wp[j] = p.W + (int64_t)(r < HR ? rA + r : rB + r - HR) * p.ldw + piece * 8;
+        wr_off[j] = r * 128 + ((piece ^ ((r >> 1) & 7)) << 4);
+    }
+    const int fr = l31 & (RG - 1);
+    const uint32_t rd_row = fr * 128, rd_swz = (fr >> 1) & 7;
+    auto gload = [&](bf16x8(&dst)[8], int kb) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int kk = min(kb + b, b1 - 1) << 6;
+#pragma unroll
+            for (int j = 0; j < JR; ++j) dst[b * JR + j] = __builtin_nontemporal_load((const bf16x8*)(wp[j] + kk));
+        }
+    };
+    f32x16 acc[NG];
+#pragma unroll
+    for (int sg = 0; sg < NG; ++sg)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[sg][i] = 0.f;
+    bf16x8 ga[8], gb[8];
+    constexpr int HXB = NB * 1024;
+    char* hx = stage_dyn + S * 8192 + w * HXB;
+    const int xm = lane >> 3, xpc = lane & 7;
+    const uint32_t hx_wr = xm * 128 + ((xpc ^ xm) << 4);
+    const uint32_t hx_rd_row = (l31 & 7) * 128, hx_rd_swz = l31 & 7;
+    auto Mg = [&](int sg) { return max(0, min(MBX, p.M - MBX * sg)); };   // sequences of group sg (0: an empty group computes on row 0 and stores nothing)
+    const bf16* xrow[NG];
+#pragma unroll
+    for (int sg = 0; sg < NG; ++sg) xrow[sg] = p.x + (int64_t)min(MBX * sg + min(xm, max(Mg(sg), 1) - 1), p.M - 1) * p.ldx + xpc * 8;
+    float my_rstd[NG];
+#pragma unroll
+    for (int sg = 0; sg < NG; ++sg) my_rstd[sg] = 0.f;
+    if constexpr (PRO == PRO_RMS) {
+        if (p.ss_in != nullptr) {   // per group: the producer's partial sums, all loads of a group in flight together, before the first weights
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) {
+                constexpr int NP8 = 32;
+                const float* ssg = p.ss_in + (int64_t)sg * p.ss_nparts * MBX;
+                float v[NP8];
+#pragma unroll
+                for (int i = 0; i < NP8; ++i) {
+                    const int gp = 8 * i + xpc;
+                    v[i] = gp < p.ss_nparts ? ssg[gp * MBX + xm] : 0.f;
+                }
+                if (sg == 0 && b0 < b1) gload(ga, b0);   // the first weights right behind the first group's partial sums
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < NP8; ++i) a += v[i];
+                a += __shfl_xor(a, 1, 64);
+                a += __shfl_xor(a, 2, 64);
+                a += __shfl_xor(a, 4, 64);
+                my_rstd[sg] = rsqrtf(a * (1.f / (float)p.K) + p.eps);
+            }
+        } else {                    // the first layer's rows: the block takes the statistic itself, group after group (two barriers each, executed by every thread)
+            if (b0 < b1) gload(ga, b0);
+            constexpr int T = 64 * S;
+            const int nch = p.K >> 3;
+            float* ssred = (float*)(stage_dyn + S * 8192);
+#pragma unroll 1
+            for (int sg = 0; sg < NG; ++sg) {
+                float ss[MBX];
+#pragma unroll
+                for (int m = 0; m < MBX; ++m) {
+                    float a = 0.f;
+                    if (m < Mg(sg)) {
+                        for (int c = t; c < nch; c += T) {
+                            const bf16x8 v = *(const bf16x8*)(p.x + (int64_t)(MBX * sg + m) * p.ldx + c * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a += (float)v[e] * (float)v[e];
+                        }
+                    }
+                    ss[m] = wave_sum(a);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int m = 0; m < MBX; ++m) ssred[w * MBX + m] = ss[m];
+                }
+                __syncthreads();
+                float a = 0.f;
+#pragma unroll
+                for (int q = 0; q < S; ++q) a += ssred[q * MBX + xm];
+                const float rs = rsqrtf(a * (1.f / (float)p.K) + p.eps);
+#pragma unroll
+                for (int s2 = 0; s2 < NG; ++s2)
+                    if (s2 == sg) my_rstd[s2] = rs;
+                __syncthreads();
+            }
+        }
+    } else {
+        if (b0 < b1) gload(ga, b0);
+    }
+    auto consumeG = [&](bf16x8(&cur)[8], bf16x8(&nxt)[8], int kb) {
+        bf16x8 xr[NG][NB], gw[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {   // ahead of the next stage's weight loads: loads return in order
+            const int kk = min(kb + b, b1 - 1) << 6;
+#pragma unroll
+            for (int sg = 0; sg < NG; ++sg) xr[sg][b] = *(const bf16x8*)(xrow[sg] + kk);
+            if constexpr (PRO == PRO_RMS) gw[b] = *(const bf16x8*)(p.normw + kk + xpc * 8);
+        }
+        if (kb + STEP < b1) gload(nxt, kb + STEP);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
+#pragma unroll
+        for (int sg = 0; sg < NG; ++sg) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                bf16x8 h = xr[sg][b];
+                if constexpr (PRO == PRO_RMS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = (bf16)((float)gw[b][e] * rbf((float)xr[sg][b][e] * my_rstd[sg]));   // cast BEFORE the weight multiply (:250-252)
+                }
+                *(bf16x8*)(hx + b * 1024 + hx_wr) = h;
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (kb + b < b1) {   // wave-uniform
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const bf16x8 wf = *(const bf16x8*)(my + b * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
+                        const bf16x8 xf = *(const bf16x8*)(hx + b * 1024 + hx_rd_row + ((((2 * st + hi)) ^ hx_rd_swz) << 4));
+                        acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[sg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    if (b0 < b1) {
+        for (int kb = b0; kb < b1; kb += 2 * STEP) {
+            consumeG(ga, gb, kb);
+            if (kb + STEP < b1) consumeG(gb, ga, kb + STEP);
+        }
+    }
+    // ---- epilogue, once per group: the eight-sequence epilogue of gemv_chain_mfma_kernel with every barrier executed by every thread
+    float* red = (float*)my;                      // [R][MBX], head of this wave's own staging area
+    float* fin = (float*)&stage[0][4096];         // [R][MBX]
+    const bool fin_t = t < R * MBX;
+    const int r = fin_t ? t / MBX : 0, m = t % MBX;
+    const int row = r < HR ? rA + r : rB + r - HR;
+#pragma unroll 1
+    for (int sg = 0; sg < NG; ++sg) {
+        if (l31 < MBX) {
+            f32x16 a16 = acc[0];
+#pragma unroll
+            for (int s2 = 1; s2 < NG; ++s2)
+                if (s2 == sg) a16 = acc[s2];
+#pragma unroll
+            for (int q = 0; q < RG / 8; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[(8 * q + 4 * hi + e) * MBX + l31] = a16[4 * q + e];
+        }
+        __syncthreads();
+        const int mg = MBX * sg + m;               // the sequence of this thread
+        const bool valid = fin_t && m < Mg(sg);
+        float tot = 0.f;
+        if (fin_t) {
+#pragma unroll
+            for (int q = 0; q < S; ++q) tot += ((const float*)&stage[q][0])[r * MBX + m];   // K slices summed in slice order
+        }
+        float mine = 0.f;
+        if (EPI == EPI_QKV) {
+            mine = rbf(tot + (float)p.bias[row]);
+            if (fin_t) fin[r * MBX + m] = mine;
+        } else if (EPI == EPI_SWIGLU) {
+            mine = rbf(tot);
+            if (fin_t) fin[r * MBX + m] = mine;
+        } else if (EPI == EPI_RESID) {
+            const bf16 ov = (bf16)(rbf(tot) + (float)p.residual[(int64_t)min(mg, p.M - 1) * p.ld_res + row]);
+            if (valid) p.out[(int64_t)mg * p.ld_out + row] = ov;
+            if (fin_t && p.ss_out != nullptr) fin[r * MBX + m] = valid ? (float)ov * (float)ov : 0.f;
+        } else {
+            if (valid) p.out_f32[(int64_t)mg * p.ld_out + row] = rbf(tot);
+        }
+        __syncthreads();
+        if (EPI == EPI_QKV) {
+            if (valid) {
+                const float other = fin[(r ^ HR) * MBX + m];
+                const int start = *p.start;
+                if (g < rot_groups) {
+                    const int64_t ps = (int64_t)p.pos[mg * p.pos_stride] * p.D + row % p.D;
+                    const float rot = r < HR ? -other : other;
+                    const float o = rbf(rbf_strict(mine * (float)p.cos_t[ps]) + rbf_strict(rot * (float)p.sin_t[ps]));   // rbf_strict: contraction-proof (common.h)
+                    if (row < nq) p.q_out[(int64_t)mg * p.ldq + row] = (bf16)o;
+                    else p.Kc[(int64_t)mg * p.k_bs + (int64_t)start * nk + (row - nq)] = (bf16)o;
+                } else {
+                    p.Vt[(int64_t)mg * p.vt_bs + (int64_t)(row - nq - nk) * p.spad + start] = (bf16)mine;
+                }
+            }
+        } else if (EPI == EPI_SWIGLU) {
+            if (valid && r < HR) {
+                const float u = fin[(r + HR) * MBX + m];
+                p.out[(int64_t)mg * p.ld_out + row] = (bf16)(rbf(mine * sigmoid_f(mine)) * u);
+            }
+        } else if (EPI == EPI_RESID) {
+            if (p.ss_out != nullptr && t < MBX) {
+                float a = 0.f;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) a += fin[rr * MBX + t];
+                p.ss_out[((int64_t)sg * gridDim.x + g) * MBX + t] = a;
+            }
+        }
+        __syncthreads();   // red / fin are rewritten by the next group
+    }
+}
+
 // AFK_CHAIN_S / AFK_CHAIN_R = "qkv,linear(K<=4096),linear(K>4096),gate_up,lm_head" (measurement knobs; 0 = default)
 int chain_knob(int which, int dflt, bool is_r) {   // read per launch (a getenv; nothing inside a replayed graph): the tests switch forms in-process
     int v[5] = {0, 0, 0, 0, 0};
@@ -995,35 +1201,20 @@ int launch_chain_batched(const ChainArgs& p, int rows, int which, int S_dflt, hi
             if (n == 2) rg = v[0][0], sl = v[0][1];
             else if (n == 6 && v[w3][0] > 0) rg = v[w3][0], sl = v[w3][1];
         }
-        static const bool xmask = !(getenv("AFK_CHAIN_XMASK") && getenv("AFK_CHAIN_XMASK")[0] == '0');   // A/B knob: 0 = every lane loads its (clamped) input row
-        const char* ah = getenv("AFK_CHAIN_AHEAD");                                                       // A/B knob: 1 = input fragments requested one stage ahead, with the weights
-        const bool ahead = ah && ah[0] == '1';   // measured SLOWER (234 VGPRs, fewer waves): opt-in
-#define AFK_MFMA_X(S_, RG_, XM_, AH_)                                                                                                                    \
+#define AFK_MFMA(S_, RG_)                                                                                                                              \
     do {                                                                                                                                                 \
         static bool attr_set = false;                                                                                                                    \
         if (S_ * 8192 > 65536 && !attr_set) {                                                                                                            \
-            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S_, RG_, XM_, AH_>, hipFuncAttributeMaxDynamicSharedMemorySize, S_ * 8192);    \
+            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S_, RG_>, hipFuncAttributeMaxDynamicSharedMemorySize, S_ * 8192);              \
             attr_set = true;                                                                                                                             \
         }                                                                                                                                                \
-        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S_, RG_, XM_, AH_>), dim3((unsigned)(rows / RG_)), dim3(64 * S_), S_ * 8192, st, q);            \
-    } while (0)
-#define AFK_MFMA(S_, RG_)                                 \
-    do {                                                  \
-        if (xmask) AFK_MFMA_X(S_, RG_, true, false);      \
-        else AFK_MFMA_X(S_, RG_, false, false);           \
-    } while (0)
-#define AFK_MFMA_A(S_, RG_)                               \
-    do {                                                  \
-        if (ahead) AFK_MFMA_X(S_, RG_, true, true);       \
-        else AFK_MFMA(S_, RG_);                           \
+        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S_, RG_>), dim3((unsigned)(rows / RG_)), dim3(64 * S_), S_ * 8192, st, q);                      \
     } while (0)
         if (rows / 32 >= 1024) AFK_MFMA(4, 32);
         else if (rg == 16 && sl == 16) AFK_MFMA(16, 16);
-        else if (rg == 16) AFK_MFMA_A(8, 16);
-        else AFK_MFMA_A(8, 32);
-#undef AFK_MFMA_A
+        else if (rg == 16) AFK_MFMA(8, 16);
+        else AFK_MFMA(8, 32);
 #undef AFK_MFMA
-#undef AFK_MFMA_X
         return AFK_OK;
     }
     const int S = chain_knob(which, S_dflt, false);
@@ -1148,19 +1339,35 @@ extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t l
 
 // ---------------------------------------------------------------- 1 .. 8 sequences, RMSNorm in the Linear's own prologue (matrix-pipe form only, round 6)
 namespace {
+#define AFK_CHAIN_SEQ_MAX (2 * AFK_CHAIN_BATCH_MAX)   // the norm-in-prologue / LDS-strip launches: up to two groups of eight sequences (four groups were built and measured
+                                                     // SLOWER than the split-K tile path - B = 17: 6.75 ms, B = 32: 7.28 against 7.03: every group re-reads the stage's weight
+                                                     // fragments from LDS, 64 KiB of LDS reads per 8 KiB of weights and wave at four groups)
+template <int EPI, int S, int RG, int PRO, int NG>
+int launch_chain_ng(const ChainArgs& p, int rows, hipStream_t st) {
+    constexpr int LDS = S * 8192 + S * (64 / RG) * 1024;
+    static bool attr_set = false;
+    if (LDS > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>), dim3((unsigned)(rows / RG)), dim3(64 * S), LDS, st, p);
+    return AFK_OK;
+}
 template <int EPI, int S>
 int launch_chain_norm(ChainArgs p, int rows, hipStream_t st) {
     constexpr int NBX = 2;   // 32-row groups: two 64-element blocks per stage
     constexpr int LDS = S * 8192 + S * NBX * 1024;
+    p.kil = 1;
+    if (p.M > AFK_CHAIN_BATCH_MAX) return launch_chain_ng<EPI, S, 32, PRO_RMS, 2>(p, rows, st);       // 9 .. 16: two
     static bool attr_set = false;
     if (LDS > 65536 && !attr_set) {
-        hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI, S, 32, PRO_RMS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     static const int ssf = [] { const char* e = getenv("AFK_CHAIN_SS_FIRST"); return e && e[0] == '0' ? 0 : 1; }();
     p.kil = 1;
     p.ss_first = ssf;
-    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S, 32, true, false, PRO_RMS>), dim3((unsigned)(rows / 32)), dim3(64 * S), LDS, st, p);
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI, S, 32, PRO_RMS>), dim3((unsigned)(rows / 32)), dim3(64 * S), LDS, st, p);
     return AFK_OK;
 }
 }  // namespace
@@ -1171,9 +1378,9 @@ extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int
                                                  int ss_nparts, void* stream) {
     AFK_REQUIRE(x && norm_w && W && bias && cos_t && sin_t && pos && q_out && kcache && vtcache && start_dev, "afk_decode_chain_qkv_norm_batched: null pointer");
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_qkv_norm_batched: 1 .. 256 partial sums");
-    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_BATCH_MAX && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && Hq > 0 && Hkv > 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 &&
+    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_SEQ_MAX && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && Hq > 0 && Hkv > 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 &&
                     ((Hq + 2 * Hkv) * D) % 32 == 0 && spad > 0,
-                "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 8, K %% 64 == 0, head_dim %% 32 == 0)");
+                "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 16, K %% 64 == 0, head_dim %% 32 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = (Hq + 2 * Hkv) * D; p.K = K;
     p.bias = (const bf16*)bias; p.cos_t = (const bf16*)cos_t; p.sin_t = (const bf16*)sin_t; p.pos = pos; p.pos_stride = 1; p.start = start_dev;
@@ -1187,8 +1394,8 @@ extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int
 extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K,
                                                      void* act_out, int64_t ld_act, const float* ss_part, int ss_nparts, void* stream) {
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_gate_up_norm_batched: 1 .. 256 partial sums");
-    AFK_REQUIRE(x && norm_w && W && act_out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 8, I %% 16 == 0, K %% 64 == 0)");
+    AFK_REQUIRE(x && norm_w && W && act_out && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 16, I %% 16 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = 2 * I; p.K = K;
     p.out = (bf16*)act_out; p.ld_out = ld_act; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
@@ -1200,8 +1407,8 @@ extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx,
 extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K,
                                                      float* logits, int64_t ld_logits, const float* ss_part, int ss_nparts, void* stream) {
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_lm_head_norm_batched: 1 .. 256 partial sums");
-    AFK_REQUIRE(x && norm_w && W && logits && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 8, N %% 32 == 0, K %% 64 == 0)");
+    AFK_REQUIRE(x && norm_w && W && logits && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 16, N %% 32 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K;
     p.out_f32 = logits; p.ld_out = ld_logits; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
@@ -1214,11 +1421,16 @@ extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx,
 // the statistic of the RMSNorm that FOLLOWS, folded by the next Linear's prologue (afk_decode_chain_*_norm_batched with ss_part): no pass over the rows, no hand-over.
 extern "C" int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
                                                            void* out, int64_t ld_out, float* ss_part, void* stream) {
-    AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 8, N %% 32 == 0, K %% 64 == 0)");
+    AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 16, N %% 32 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.ss_out = ss_part; p.kil = 1;
+    if (M > AFK_CHAIN_BATCH_MAX) {   // 9 .. 16 sequences: two groups of eight in one pass over the weights; ss_part is [groups][N / 16][8]
+        launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 2>(p, N, ST);
+        AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_ss_batched");
+        return AFK_OK;
+    }
     // input rows through the LDS strip (cooperative 16-byte loads, fragments read back from LDS) instead of four lane-masked fragment loads per block from the L2:
     // down 30.9 -> 26.5 us at M = 8, o_proj level (AFK_CHAIN_XLDS=0: A/B)
     static const bool xlds = [] { const char* e = getenv("AFK_CHAIN_XLDS"); return !(e && e[0] == '0'); }();
@@ -1226,12 +1438,12 @@ extern "C" int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_
         constexpr int LDS = 8 * 8192 + 8 * 4 * 1024;
         static bool attr_set = false;
         if (!attr_set) {
-            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI_RESID, 8, 16, true, false, PRO_PLAIN_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            hipFuncSetAttribute((const void*)gemv_chain_mfma_kernel<EPI_RESID, 8, 16, PRO_PLAIN_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             attr_set = true;
         }
-        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID, 8, 16, true, false, PRO_PLAIN_LDS>), dim3((unsigned)(N / 16)), dim3(512), LDS, ST, p);
+        hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID, 8, 16, PRO_PLAIN_LDS>), dim3((unsigned)(N / 16)), dim3(512), LDS, ST, p);
     } else
-    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID, 8, 16, true, false>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID, 8, 16>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
     AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_ss_batched");
     return AFK_OK;
 }
@@ -1250,7 +1462,7 @@ extern "C" int afk_decode_chain_linear_residual_norm_batched(const void* x, int6
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.n2_w = (const bf16*)norm_w; p.n2_out = (bf16*)h_out; p.ld_n2 = ld_h; p.n2_eps = eps; p.n2_counter = counter;
     p.kil = 1;
-    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID_NORM, 8, 16, true, false>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
+    hipLaunchKernelGGL((gemv_chain_mfma_kernel<EPI_RESID_NORM, 8, 16>), dim3((unsigned)(N / 16)), dim3(512), 8 * 8192, ST, p);
     AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_norm_batched");
     return AFK_OK;
 }

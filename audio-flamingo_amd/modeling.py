@@ -1015,6 +1015,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return y
 
     decode_mfma_from = int(os.environ.get("AFK_DECODE_MFMA_FROM", "2"))   # batched decode: sequences per step from which the norm-in-prologue matrix-pipe launches run
+    decode_chain_batch_max = int(os.environ.get("AFK_DECODE_CHAIN_BATCH_MAX", "16"))   # 9 .. 16 sequences: two groups of eight through the same launches (8 = the split-K tile path of rounds 3-5 above eight)
     decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)
     decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
 
@@ -1039,7 +1040,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         # normalises the rows it consumes) - 5 launches per layer; "producer": the norm rides behind o_proj / down (afk_decode_chain_linear_residual_norm_batched:
         # the last block to arrive normalises; measured 8 / 5 us of hand-over per launch); "launch": afk_rmsnorm_fwd as in rounds 4-5 (7 launches per layer)
         I0 = a[f"{lm}layers.0.mlp.gate_up.weight"].data.shape[0] // 2
-        shapes_ok = B >= self.decode_mfma_from and H % 64 == 0 and H <= 4096 and nq % 64 == 0 and I0 % 64 == 0 and (D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0
+        shapes_ok = B >= self.decode_mfma_from and self._prologue_shapes_ok(head)
         mode = self.decode_norm_mode if shapes_ok else "launch"
         if mode == "producer":
             cnt = getattr(self, "_chain_norm_counter", None)
@@ -1070,7 +1071,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           A("post_attention_layernorm.weight").data.data_ptr(), eps, h2.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ss2 = torch.empty((H // 16, 8), device=dev, dtype=torch.float32)
+                ss2 = torch.empty(((B + 7) // 8, H // 16, 8), device=dev, dtype=torch.float32)   # [groups of eight sequences][blocks of the launch][8]
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           ss2.data_ptr(), st)
             else:
@@ -1092,7 +1093,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H,
                           nxt.data_ptr(), eps, h.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ssx = torch.empty((H // 16, 8), device=dev, dtype=torch.float32)
+                ssx = torch.empty(((B + 7) // 8, H // 16, 8), device=dev, dtype=torch.float32)
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, ssx.data_ptr(), st)
             else:
                 _lib.call("afk_decode_chain_linear_residual_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, st)
@@ -1105,6 +1106,18 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         y = h if mode == "producer" else ops.rmsnorm_fwd(x, a[lm + "norm.weight"].data, eps)[0]
         _lib.call("afk_decode_chain_lm_head_batched", y.data_ptr(), y.stride(0), B, head.data_ptr(), head.stride(0), head.shape[0], H, logits.data_ptr(), head.shape[0], st)
         return logits
+
+    def _prologue_shapes_ok(self, head):
+        """the norm-in-prologue matrix-pipe launches (afk_decode_chain_*_norm_batched / _linear_residual_ss_batched) take this geometry"""
+        H, nq, nk = self.H, self.Hq * self.D, self.Hkv * self.D
+        return (H % 64 == 0 and H <= 4096 and nq % 64 == 0 and self.I % 64 == 0 and (self.D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0)
+
+    def _chain_batch_cap(self, head):
+        """largest batch of the one-launch-per-Linear decode step: 8 sequences, or (round 6) 16 = two groups of eight where the norm-in-prologue launches apply"""
+        cap = min(self.decode_chain_batch, 8)
+        if cap == 8 and self.decode_norm_mode == "prologue" and self.decode_chain_batch_max > 8 and self._prologue_shapes_ok(head):
+            cap = min(self.decode_chain_batch_max, 16)
+        return cap
 
     def _chain_ok(self, B):
         """single-sequence decode on csrc/decode_chain.hip: one launch per Linear (head sizes of the decode attention kernel, 16-byte rows)"""
@@ -1207,7 +1220,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         else:
             pos1 = (st["cur"] - st["lo"]).contiguous()
             kr1 = torch.stack([st["lo"], (st["cur"] + 1).expand(B)], -1).reshape(B, 1, 2).contiguous()
-        if (self._chain_ok(1) and 2 <= B <= min(self.decode_chain_batch, 8) and st["head"].shape[0] % 8 == 0 and self.I % 4 == 0):
+        if (self._chain_ok(1) and 2 <= B <= self._chain_batch_cap(st["head"]) and st["head"].shape[0] % 8 == 0 and self.I % 4 == 0):
             if "aws" not in st:
                 st["aws"] = torch.zeros(_lib.load().afk_attn_decode_workspace_floats(B, self.Hq, self.D, self.decode_splits), device=x.device, dtype=torch.float32)
             return self._decode_layers_chain_batched(x.contiguous(), B, st["cache"], pos1, kr1, st["cur"], st["aws"], st["head"])

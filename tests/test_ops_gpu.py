@@ -1356,7 +1356,7 @@ def test_decode_chain_batched_kernels_vs_standalone_sequence(dev, M, mfma, monke
     _cmp("batched lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("M", [1, 4, 8])
+@pytest.mark.parametrize("M", [1, 4, 8, 9, 13, 16])
 def test_decode_chain_norm_in_prologue_batched(dev, M):
     """afk_decode_chain_{qkv,gate_up,lm_head}_norm_batched (RMSNorm taken in the Linear's own prologue, rows normalised through a wave-private LDS strip) against
     afk_rmsnorm_fwd + the plain matrix-pipe launches at the AF3-7B widths: equal up to the fp32 summation order of the row statistic (a differing last bit of a
@@ -1378,7 +1378,7 @@ def test_decode_chain_norm_in_prologue_batched(dev, M):
     fr = torch.arange(64, device=dev, dtype=torch.float32)[:, None] * inv[None]
     emb = torch.cat([fr, fr], -1)
     cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
-    pos_t = torch.tensor([37 - 3 * m for m in range(M)], device=dev, dtype=torch.int32)
+    pos_t = torch.tensor([37 - 3 * (m % 12) for m in range(M)], device=dev, dtype=torch.int32)
     start_t = torch.tensor([start], device=dev, dtype=torch.int32)
     qkv = ops.gemm_nt(h, w, bias=bias)
     ops.rope_(qkv, cos, sin, S=1, nheads=Hq + Hkv, D=D, pos=pos_t)
@@ -1402,10 +1402,18 @@ def test_decode_chain_norm_in_prologue_batched(dev, M):
     import os as _os
     _os.environ["AFK_CHAIN_MFMA"] = "1"
     try:
-        _lib.call("afk_decode_chain_gate_up_batched", h.data_ptr(), H, M, wgu.data_ptr(), wgu.stride(0), I, H, plain.data_ptr(), I, st)
+        for m0 in range(0, M, 8):   # the plain entry point takes eight sequences at a time
+            mm = min(8, M - m0)
+            _lib.call("afk_decode_chain_gate_up_batched", h[m0:].data_ptr(), H, mm, wgu.data_ptr(), wgu.stride(0), I, H, plain[m0:].data_ptr(), I, st)
     finally:
         del _os.environ["AFK_CHAIN_MFMA"]
     assert int((plain != act).sum()) <= M * I // 50, f"{int((plain != act).sum())} of {M * I} values differ from the norm-launch form"
+    if M > 8:   # a group of eight is an independent instance of the eight-sequence launch: bit for bit
+        for m0 in range(0, M, 8):
+            mm = min(8, M - m0)
+            part = torch.empty((mm, I), device=dev, dtype=BF)
+            _lib.call("afk_decode_chain_gate_up_norm_batched", x[m0:].data_ptr(), H, mm, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, part.data_ptr(), I, None, 0, st)
+            assert torch.equal(part, act[m0:m0 + mm]), f"group at sequence {m0} differs from the eight-sequence launch"
     solo = torch.empty((1, I), device=dev, dtype=BF)
     _lib.call("afk_decode_chain_gate_up_norm_batched", x[M - 1:].data_ptr(), H, 1, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, solo.data_ptr(), I, None, 0, st)
     assert torch.equal(solo[0], act[M - 1])
@@ -1414,14 +1422,18 @@ def test_decode_chain_norm_in_prologue_batched(dev, M):
     wl = _rand((H, nq), dev, 0.02, 12).to(BF)
     res = _rand((M, H), dev, 1.0, 13).to(BF)
     rows_w = torch.empty((M, H), device=dev, dtype=BF)
-    _lib.call("afk_decode_chain_linear_residual_batched", a_in.data_ptr(), nq, M, wl.data_ptr(), wl.stride(0), H, nq, res.data_ptr(), H, rows_w.data_ptr(), H, st)
+    for m0 in range(0, M, 8):
+        mm = min(8, M - m0)
+        _lib.call("afk_decode_chain_linear_residual_batched", a_in[m0:].data_ptr(), nq, mm, wl.data_ptr(), wl.stride(0), H, nq, res[m0:].data_ptr(), H, rows_w[m0:].data_ptr(), H, st)
     rows_s = torch.empty((M, H), device=dev, dtype=BF)
-    ssp = torch.full((H // 16, 8), float("nan"), device=dev, dtype=torch.float32)
+    NGt = (M + 7) // 8
+    ssp = torch.full((NGt, H // 16, 8), float("nan"), device=dev, dtype=torch.float32)
     _lib.call("afk_decode_chain_linear_residual_ss_batched", a_in.data_ptr(), nq, M, wl.data_ptr(), wl.stride(0), H, nq, res.data_ptr(), H, rows_s.data_ptr(), H, ssp.data_ptr(), st)
     _cmp("linear+residual (ss form)", rows_s, rows_w.float(), atol=3e-2, rtol=2e-2)
     want_ss = (rows_s.float() ** 2).sum(1)
-    got_ss = ssp.sum(0)[:M]
-    assert bool(((got_ss - want_ss).abs() <= 1e-4 * want_ss).all()) and float(ssp[:, M:].abs().sum()) == 0.0
+    got_all = ssp.sum(1).reshape(-1)               # [groups * 8]: sequence 8 g + m
+    got_ss = got_all[:M]
+    assert bool(((got_ss - want_ss).abs() <= 1e-4 * want_ss).all()) and float(got_all[M:].abs().sum()) == 0.0
     act_b = torch.empty((M, I), device=dev, dtype=BF)
     act_p = torch.empty((M, I), device=dev, dtype=BF)
     _lib.call("afk_decode_chain_gate_up_norm_batched", rows_s.data_ptr(), H, M, nw.data_ptr(), 1e-6, wgu.data_ptr(), wgu.stride(0), I, H, act_b.data_ptr(), I, None, 0, st)
