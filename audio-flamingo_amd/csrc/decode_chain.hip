@@ -882,12 +882,12 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
     }
 }
 
-// 9 .. 16 sequences per step (round 6): the norm-in-prologue / LDS-strip launches above for NG = 2 GROUPS of eight sequences in one pass over the weights (NG = 4
-// compiles and is correct but loses to the tile path: see AFK_CHAIN_SEQ_MAX).
+// 9 .. 32 sequences per step (round 6): the norm-in-prologue / LDS-strip launches above for NG = 2 or 4 GROUPS of eight sequences in one pass over the weights.
 // Rounds 3-5 sent batches above eight down the split-K tile path (B = 9: 5.7 ms per step against 3.6 at B = 8 - fewer tokens per second than the smaller batch).  A
-// group is an independent instance of the eight-sequence arithmetic (its own rows, statistic, accumulator block, epilogue) - index for index the code of
-// gemv_chain_mfma_kernel - sharing the weight stages: a stage's weights are written to the wave's LDS area once and every group multiplies them with its own strip of
-// (normalised) rows, which reuses ONE strip (LDS operations of a wave execute in order).  Every block barrier is executed by every thread (no early exits: the
+// group is an independent instance of the eight-sequence arithmetic (its own rows, statistic and epilogue - index for index the code of gemv_chain_mfma_kernel) and
+// its sequences are eight more COLUMNS of the same MFMA: the strip holds 8 NG rows, one fragment read and one v_mfma_f32_32x32x16_bf16 per 16 reduction elements
+// serve all groups - the matrix pipe and the LDS do the work of an eight-sequence step (a first form ran the MFMAs group by group: B = 17 6.75 ms, slower than
+// the tile path).  The sums of a column are those of the eight-sequence launch bit for bit.  Every block barrier is executed by every thread (no early exits: the
 // epilogue runs once per group).  ss_in / ss_out are [NG][parts][8].
 template <int EPI, int S, int RG, int PRO, int NG>
 __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p) {
@@ -941,17 +941,17 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
             for (int j = 0; j < JR; ++j) dst[b * JR + j] = __builtin_nontemporal_load((const bf16x8*)(wp[j] + kk));
         }
     };
-    f32x16 acc[NG];
+    f32x16 acc;   // ONE accumulator block: the 8 NG sequences are the columns of the same MFMA (column 8 sg + m)
 #pragma unroll
-    for (int sg = 0; sg < NG; ++sg)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[sg][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     bf16x8 ga[8], gb[8];
-    constexpr int HXB = NB * 1024;
+    constexpr int MC = MBX * NG;                   // sequences = MFMA columns in use
+    constexpr int HB = 2;                          // blocks per strip fill (a four-block stage of the 16-row groups goes through the strip in two halves)
+    constexpr int HXB = HB * MC * 128;             // strip: [HB blocks][MC rows][128 B]
     char* hx = stage_dyn + S * 8192 + w * HXB;
     const int xm = lane >> 3, xpc = lane & 7;
-    const uint32_t hx_wr = xm * 128 + ((xpc ^ xm) << 4);
-    const uint32_t hx_rd_row = (l31 & 7) * 128, hx_rd_swz = l31 & 7;
+    const uint32_t hx_wr = xm * 128 + ((xpc ^ xm) << 4);   // + sg * 1024: row 8 sg + xm (the swizzle uses row & 7 = xm)
+    const uint32_t hx_rd_row = (l31 & (MC - 1)) * 128, hx_rd_swz = l31 & 7;
     auto Mg = [&](int sg) { return max(0, min(MBX, p.M - MBX * sg)); };   // sequences of group sg (0: an empty group computes on row 0 and stores nothing)
     const bf16* xrow[NG];
 #pragma unroll
@@ -1033,24 +1033,28 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
 #pragma unroll
             for (int j = 0; j < JR; ++j) *(bf16x8*)(my + b * BLK + wr_off[j]) = cur[b * JR + j];
 #pragma unroll
-        for (int sg = 0; sg < NG; ++sg) {
+        for (int bh = 0; bh < NB; bh += HB) {   // HB blocks at a time through the strip (LDS operations of a wave execute in order)
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                bf16x8 h = xr[sg][b];
-                if constexpr (PRO == PRO_RMS) {
+            for (int sg = 0; sg < NG; ++sg)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = (bf16)((float)gw[b][e] * rbf((float)xr[sg][b][e] * my_rstd[sg]));   // cast BEFORE the weight multiply (:250-252)
+                for (int bb = 0; bb < HB; ++bb) {
+                    const int b = bh + bb;
+                    bf16x8 h = xr[sg][b];
+                    if constexpr (PRO == PRO_RMS) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = (bf16)((float)gw[b][e] * rbf((float)xr[sg][b][e] * my_rstd[sg]));   // cast BEFORE the weight multiply (:250-252)
+                    }
+                    *(bf16x8*)(hx + bb * (MC * 128) + sg * 1024 + hx_wr) = h;
                 }
-                *(bf16x8*)(hx + b * 1024 + hx_wr) = h;
-            }
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
+            for (int bb = 0; bb < HB; ++bb) {
+                const int b = bh + bb;
                 if (kb + b < b1) {   // wave-uniform
 #pragma unroll
                     for (int st = 0; st < 4; ++st) {
                         const bf16x8 wf = *(const bf16x8*)(my + b * BLK + rd_row + ((((2 * st + hi)) ^ rd_swz) << 4));
-                        const bf16x8 xf = *(const bf16x8*)(hx + b * 1024 + hx_rd_row + ((((2 * st + hi)) ^ hx_rd_swz) << 4));
-                        acc[sg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[sg], 0, 0, 0);
+                        const bf16x8 xf = *(const bf16x8*)(hx + bb * (MC * 128) + hx_rd_row + ((((2 * st + hi)) ^ hx_rd_swz) << 4));   // lanes beyond MC repeat rows: columns nobody reads
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc, 0, 0, 0);
                     }
                 }
             }
@@ -1063,30 +1067,26 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
         }
     }
     // ---- epilogue, once per group: the eight-sequence epilogue of gemv_chain_mfma_kernel with every barrier executed by every thread
-    float* red = (float*)my;                      // [R][MBX], head of this wave's own staging area
+    float* red = (float*)my;                      // [R][MC], head of this wave's own staging area (R x MC x 4 B <= 4 KiB)
     float* fin = (float*)&stage[0][4096];         // [R][MBX]
     const bool fin_t = t < R * MBX;
     const int r = fin_t ? t / MBX : 0, m = t % MBX;
     const int row = r < HR ? rA + r : rB + r - HR;
+    if (l31 < MC) {
+#pragma unroll
+        for (int q = 0; q < RG / 8; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(8 * q + 4 * hi + e) * MC + l31] = acc[4 * q + e];
+    }
+    __syncthreads();
 #pragma unroll 1
     for (int sg = 0; sg < NG; ++sg) {
-        if (l31 < MBX) {
-            f32x16 a16 = acc[0];
-#pragma unroll
-            for (int s2 = 1; s2 < NG; ++s2)
-                if (s2 == sg) a16 = acc[s2];
-#pragma unroll
-            for (int q = 0; q < RG / 8; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) red[(8 * q + 4 * hi + e) * MBX + l31] = a16[4 * q + e];
-        }
-        __syncthreads();
         const int mg = MBX * sg + m;               // the sequence of this thread
         const bool valid = fin_t && m < Mg(sg);
         float tot = 0.f;
         if (fin_t) {
 #pragma unroll
-            for (int q = 0; q < S; ++q) tot += ((const float*)&stage[q][0])[r * MBX + m];   // K slices summed in slice order
+            for (int q = 0; q < S; ++q) tot += ((const float*)&stage[q][0])[r * MC + MBX * sg + m];   // K slices summed in slice order
         }
         float mine = 0.f;
         if (EPI == EPI_QKV) {
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
                 p.ss_out[((int64_t)sg * gridDim.x + g) * MBX + t] = a;
             }
         }
-        __syncthreads();   // red / fin are rewritten by the next group
+        __syncthreads();   // fin is rewritten by the next group
     }
 }
 
@@ -1339,12 +1339,10 @@ extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t l
 
 // ---------------------------------------------------------------- 1 .. 8 sequences, RMSNorm in the Linear's own prologue (matrix-pipe form only, round 6)
 namespace {
-#define AFK_CHAIN_SEQ_MAX (2 * AFK_CHAIN_BATCH_MAX)   // the norm-in-prologue / LDS-strip launches: up to two groups of eight sequences (four groups were built and measured
-                                                     // SLOWER than the split-K tile path - B = 17: 6.75 ms, B = 32: 7.28 against 7.03: every group re-reads the stage's weight
-                                                     // fragments from LDS, 64 KiB of LDS reads per 8 KiB of weights and wave at four groups)
+#define AFK_CHAIN_SEQ_MAX (4 * AFK_CHAIN_BATCH_MAX)   // the norm-in-prologue / LDS-strip launches: up to four groups of eight sequences = the 32 columns of the MFMA
 template <int EPI, int S, int RG, int PRO, int NG>
 int launch_chain_ng(const ChainArgs& p, int rows, hipStream_t st) {
-    constexpr int LDS = S * 8192 + S * (64 / RG) * 1024;
+    constexpr int LDS = S * 8192 + S * 2 * NG * 1024;   // weight stages + one [2 blocks][8 NG rows][128 B] strip per wave
     static bool attr_set = false;
     if (LDS > 65536 && !attr_set) {
         hipFuncSetAttribute((const void*)gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1358,6 +1356,7 @@ int launch_chain_norm(ChainArgs p, int rows, hipStream_t st) {
     constexpr int NBX = 2;   // 32-row groups: two 64-element blocks per stage
     constexpr int LDS = S * 8192 + S * NBX * 1024;
     p.kil = 1;
+    if (p.M > 2 * AFK_CHAIN_BATCH_MAX) return launch_chain_ng<EPI, S, 32, PRO_RMS, 4>(p, rows, st);   // 17 .. 32 sequences: four groups of eight
     if (p.M > AFK_CHAIN_BATCH_MAX) return launch_chain_ng<EPI, S, 32, PRO_RMS, 2>(p, rows, st);       // 9 .. 16: two
     static bool attr_set = false;
     if (LDS > 65536 && !attr_set) {
@@ -1380,7 +1379,7 @@ extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_qkv_norm_batched: 1 .. 256 partial sums");
     AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_SEQ_MAX && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && Hq > 0 && Hkv > 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 &&
                     ((Hq + 2 * Hkv) * D) % 32 == 0 && spad > 0,
-                "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 16, K %% 64 == 0, head_dim %% 32 == 0)");
+                "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 32, K %% 64 == 0, head_dim %% 32 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = (Hq + 2 * Hkv) * D; p.K = K;
     p.bias = (const bf16*)bias; p.cos_t = (const bf16*)cos_t; p.sin_t = (const bf16*)sin_t; p.pos = pos; p.pos_stride = 1; p.start = start_dev;
@@ -1395,7 +1394,7 @@ extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx,
                                                      void* act_out, int64_t ld_act, const float* ss_part, int ss_nparts, void* stream) {
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_gate_up_norm_batched: 1 .. 256 partial sums");
     AFK_REQUIRE(x && norm_w && W && act_out && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 16, I %% 16 == 0, K %% 64 == 0)");
+                "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 32, I %% 16 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = 2 * I; p.K = K;
     p.out = (bf16*)act_out; p.ld_out = ld_act; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
@@ -1408,7 +1407,7 @@ extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx,
                                                      float* logits, int64_t ld_logits, const float* ss_part, int ss_nparts, void* stream) {
     AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_lm_head_norm_batched: 1 .. 256 partial sums");
     AFK_REQUIRE(x && norm_w && W && logits && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 16, N %% 32 == 0, K %% 64 == 0)");
+                "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 32, N %% 32 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.normw = (const bf16*)norm_w; p.eps = eps; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K;
     p.out_f32 = logits; p.ld_out = ld_logits; p.D = 2; p.ss_in = ss_part; p.ss_nparts = ss_part ? ss_nparts : 0;
@@ -1422,12 +1421,13 @@ extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx,
 extern "C" int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
                                                            void* out, int64_t ld_out, float* ss_part, void* stream) {
     AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 16, N %% 32 == 0, K %% 64 == 0)");
+                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 32, N %% 32 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.ss_out = ss_part; p.kil = 1;
-    if (M > AFK_CHAIN_BATCH_MAX) {   // 9 .. 16 sequences: two groups of eight in one pass over the weights; ss_part is [groups][N / 16][8]
-        launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 2>(p, N, ST);
+    if (M > AFK_CHAIN_BATCH_MAX) {   // 9 .. 32 sequences: groups of eight in one pass over the weights; ss_part is [groups][N / 16][8]
+        if (M > 2 * AFK_CHAIN_BATCH_MAX) launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 4>(p, N, ST);
+        else launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 2>(p, N, ST);
         AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_ss_batched");
         return AFK_OK;
     }

@@ -1015,7 +1015,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return y
 
     decode_mfma_from = int(os.environ.get("AFK_DECODE_MFMA_FROM", "2"))   # batched decode: sequences per step from which the norm-in-prologue matrix-pipe launches run
-    decode_chain_batch_max = int(os.environ.get("AFK_DECODE_CHAIN_BATCH_MAX", "16"))   # 9 .. 16 sequences: two groups of eight through the same launches (8 = the split-K tile path of rounds 3-5 above eight)
+    decode_chain_batch_max = int(os.environ.get("AFK_DECODE_CHAIN_BATCH_MAX", "32"))   # 9 .. 32 sequences: two / four groups of eight through the same launches (8 = the split-K tile path of rounds 3-5 above eight)
     decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)
     decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
 
@@ -1047,6 +1047,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             if cnt is None or cnt.device != dev:
                 cnt = self._chain_norm_counter = torch.zeros(1, device=dev, dtype=torch.int32)
         h = ssx = None
+        ngrp = 1 if B <= 8 else 2 if B <= 16 else 4   # groups of eight sequences the norm-in-prologue launches run (include/afk.h)
         _p = lambda t: None if t is None else t.data_ptr()
         for i in range(self.dec_layers):
             A = lambda k: a[f"{lm}layers.{i}.{k}"]
@@ -1071,7 +1072,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           A("post_attention_layernorm.weight").data.data_ptr(), eps, h2.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ss2 = torch.empty(((B + 7) // 8, H // 16, 8), device=dev, dtype=torch.float32)   # [groups of eight sequences][blocks of the launch][8]
+                ss2 = torch.empty((ngrp, H // 16, 8), device=dev, dtype=torch.float32)   # [groups of eight sequences the launch runs: 1, 2 or 4][blocks of the launch][8]
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           ss2.data_ptr(), st)
             else:
@@ -1093,7 +1094,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H,
                           nxt.data_ptr(), eps, h.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ssx = torch.empty(((B + 7) // 8, H // 16, 8), device=dev, dtype=torch.float32)
+                ssx = torch.empty((ngrp, H // 16, 8), device=dev, dtype=torch.float32)
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, ssx.data_ptr(), st)
             else:
                 _lib.call("afk_decode_chain_linear_residual_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, st)
@@ -1113,10 +1114,10 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return (H % 64 == 0 and H <= 4096 and nq % 64 == 0 and self.I % 64 == 0 and (self.D // 2) % 16 == 0 and nk % 32 == 0 and head.shape[0] % 32 == 0)
 
     def _chain_batch_cap(self, head):
-        """largest batch of the one-launch-per-Linear decode step: 8 sequences, or (round 6) 16 = two groups of eight where the norm-in-prologue launches apply"""
+        """largest batch of the one-launch-per-Linear decode step: 8 sequences, or (round 6) 32 = four groups of eight where the norm-in-prologue launches apply"""
         cap = min(self.decode_chain_batch, 8)
         if cap == 8 and self.decode_norm_mode == "prologue" and self.decode_chain_batch_max > 8 and self._prologue_shapes_ok(head):
-            cap = min(self.decode_chain_batch_max, 16)
+            cap = min(self.decode_chain_batch_max, 32)
         return cap
 
     def _chain_ok(self, B):
