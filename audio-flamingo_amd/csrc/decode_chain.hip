@@ -1134,6 +1134,19 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
     }
 }
 
+#define AFK_CHAIN_SEQ_MAX (4 * AFK_CHAIN_BATCH_MAX)   // the norm-in-prologue / LDS-strip launches: up to four groups of eight sequences = the 32 columns of the MFMA
+template <int EPI, int S, int RG, int PRO, int NG>
+int launch_chain_ng(const ChainArgs& p, int rows, hipStream_t st) {
+    constexpr int LDS = S * 8192 + S * 2 * NG * 1024;   // weight stages + one [2 blocks][8 NG rows][128 B] strip per wave
+    static bool attr_set = false;
+    if (LDS > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>), dim3((unsigned)(rows / RG)), dim3(64 * S), LDS, st, p);
+    return AFK_OK;
+}
+
 // AFK_CHAIN_S / AFK_CHAIN_R = "qkv,linear(K<=4096),linear(K>4096),gate_up,lm_head" (measurement knobs; 0 = default)
 int chain_knob(int which, int dflt, bool is_r) {   // read per launch (a getenv; nothing inside a replayed graph): the tests switch forms in-process
     int v[5] = {0, 0, 0, 0, 0};
@@ -1314,12 +1327,21 @@ extern "C" int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, c
                                             const void* sin_t, const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs, void* vtcache, int64_t vt_bs,
                                             int spad, const int* start_dev, int Hq, int Hkv, int D, void* stream) {
     AFK_REQUIRE(h && W && bias && cos_t && sin_t && pos && q_out && kcache && vtcache && start_dev, "afk_decode_chain_qkv_batched: null pointer");
-    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_BATCH_MAX && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 && Hq > 0 && Hkv > 0 && D % 16 == 0 && spad > 0,
-                "afk_decode_chain_qkv_batched: unsupported shape (1 <= M <= 8, K %% 8 == 0, head_dim %% 16 == 0)");
+    AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_SEQ_MAX && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0 && Hq > 0 && Hkv > 0 && D % 16 == 0 && spad > 0,
+                "afk_decode_chain_qkv_batched: unsupported shape (1 <= M <= 32, K %% 8 == 0, head_dim %% 16 == 0)");
+    AFK_REQUIRE(M <= AFK_CHAIN_BATCH_MAX || (K % 64 == 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 && ((Hq + 2 * Hkv) * D) % 32 == 0),
+                "afk_decode_chain_qkv_batched: more than 8 sequences need K %% 64 == 0 and head_dim %% 32 == 0 (groups of eight on the matrix pipe)");
     ChainArgs p = {};
     p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = (Hq + 2 * Hkv) * D; p.K = K;
     p.bias = (const bf16*)bias; p.cos_t = (const bf16*)cos_t; p.sin_t = (const bf16*)sin_t; p.pos = pos; p.pos_stride = 1; p.start = start_dev;
     p.q_out = (bf16*)q_out; p.ldq = ldq; p.Kc = (bf16*)kcache; p.k_bs = k_bs; p.Vt = (bf16*)vtcache; p.vt_bs = vt_bs; p.spad = spad; p.Hq = Hq; p.Hkv = Hkv; p.D = D;
+    if (M > AFK_CHAIN_BATCH_MAX) {   // 9 .. 32 sequences: groups of eight as columns of one MFMA, input rows through the LDS strip (gemv_chain_mfma_ng_kernel)
+        p.kil = 1;
+        if (M > 2 * AFK_CHAIN_BATCH_MAX) launch_chain_ng<EPI_QKV, 8, 32, PRO_PLAIN_LDS, 4>(p, p.N, ST);
+        else launch_chain_ng<EPI_QKV, 8, 32, PRO_PLAIN_LDS, 2>(p, p.N, ST);
+        AFK_LAUNCH_CHECK("afk_decode_chain_qkv_batched");
+        return AFK_OK;
+    }
     launch_chain_batched<EPI_QKV>(p, p.N, 0, 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_qkv_batched");
     return AFK_OK;
@@ -1327,11 +1349,19 @@ extern "C" int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, c
 
 extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual,
                                                         int64_t ld_res, void* out, int64_t ld_out, void* stream) {
-    AFK_REQUIRE(x && W && residual && out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_linear_residual_batched: bad arguments (1 <= M <= 8, N %% 8 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(x && W && residual && out && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_batched: bad arguments (1 <= M <= 32, N %% 8 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(M <= AFK_CHAIN_BATCH_MAX || (N % 32 == 0 && K % 64 == 0), "afk_decode_chain_linear_residual_batched: more than 8 sequences need N %% 32 == 0 and K %% 64 == 0");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2;
+    if (M > AFK_CHAIN_BATCH_MAX) {
+        p.kil = 1;
+        if (M > 2 * AFK_CHAIN_BATCH_MAX) launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 4>(p, N, ST);
+        else launch_chain_ng<EPI_RESID, 8, 16, PRO_PLAIN_LDS, 2>(p, N, ST);
+        AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_batched");
+        return AFK_OK;
+    }
     launch_chain_batched<EPI_RESID>(p, N, K > 4096 ? 2 : 1, K > 4096 ? 8 : 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_linear_residual_batched");
     return AFK_OK;
@@ -1339,18 +1369,6 @@ extern "C" int afk_decode_chain_linear_residual_batched(const void* x, int64_t l
 
 // ---------------------------------------------------------------- 1 .. 8 sequences, RMSNorm in the Linear's own prologue (matrix-pipe form only, round 6)
 namespace {
-#define AFK_CHAIN_SEQ_MAX (4 * AFK_CHAIN_BATCH_MAX)   // the norm-in-prologue / LDS-strip launches: up to four groups of eight sequences = the 32 columns of the MFMA
-template <int EPI, int S, int RG, int PRO, int NG>
-int launch_chain_ng(const ChainArgs& p, int rows, hipStream_t st) {
-    constexpr int LDS = S * 8192 + S * 2 * NG * 1024;   // weight stages + one [2 blocks][8 NG rows][128 B] strip per wave
-    static bool attr_set = false;
-    if (LDS > 65536 && !attr_set) {
-        hipFuncSetAttribute((const void*)gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemv_chain_mfma_ng_kernel<EPI, S, RG, PRO, NG>), dim3((unsigned)(rows / RG)), dim3(64 * S), LDS, st, p);
-    return AFK_OK;
-}
 template <int EPI, int S>
 int launch_chain_norm(ChainArgs p, int rows, hipStream_t st) {
     constexpr int NBX = 2;   // 32-row groups: two 64-element blocks per stage
@@ -1469,10 +1487,18 @@ extern "C" int afk_decode_chain_linear_residual_norm_batched(const void* x, int6
 
 extern "C" int afk_decode_chain_gate_up_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int I, int K, void* act_out, int64_t ld_act,
                                                 void* stream) {
-    AFK_REQUIRE(h && W && act_out && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && I > 0 && I % 4 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
-                "afk_decode_chain_gate_up_batched: unsupported shape (1 <= M <= 8, I %% 4 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(h && W && act_out && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && I > 0 && I % 4 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
+                "afk_decode_chain_gate_up_batched: unsupported shape (1 <= M <= 32, I %% 4 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(M <= AFK_CHAIN_BATCH_MAX || (I % 16 == 0 && K % 64 == 0), "afk_decode_chain_gate_up_batched: more than 8 sequences need I %% 16 == 0 and K %% 64 == 0");
     ChainArgs p = {};
     p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = 2 * I; p.K = K; p.out = (bf16*)act_out; p.ld_out = ld_act; p.D = 2;
+    if (M > AFK_CHAIN_BATCH_MAX) {
+        p.kil = 1;
+        if (M > 2 * AFK_CHAIN_BATCH_MAX) launch_chain_ng<EPI_SWIGLU, 4, 32, PRO_PLAIN_LDS, 4>(p, 2 * I, ST);
+        else launch_chain_ng<EPI_SWIGLU, 4, 32, PRO_PLAIN_LDS, 2>(p, 2 * I, ST);
+        AFK_LAUNCH_CHECK("afk_decode_chain_gate_up_batched");
+        return AFK_OK;
+    }
     launch_chain_batched<EPI_SWIGLU>(p, 2 * I, 3, I / 4 >= 2048 ? 1 : 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_gate_up_batched");
     return AFK_OK;
@@ -1480,10 +1506,18 @@ extern "C" int afk_decode_chain_gate_up_batched(const void* h, int64_t ldh, int 
 
 extern "C" int afk_decode_chain_lm_head_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int N, int K, float* logits, int64_t ld_logits,
                                                 void* stream) {
-    AFK_REQUIRE(h && W && logits && M >= 1 && M <= AFK_CHAIN_BATCH_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
-                "afk_decode_chain_lm_head_batched: unsupported shape (1 <= M <= 8, N %% 8 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(h && W && logits && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 8 == 0 && K > 0 && K % 8 == 0 && ldw % 8 == 0 && ldh % 8 == 0,
+                "afk_decode_chain_lm_head_batched: unsupported shape (1 <= M <= 32, N %% 8 == 0, K %% 8 == 0)");
+    AFK_REQUIRE(M <= AFK_CHAIN_BATCH_MAX || (N % 32 == 0 && K % 64 == 0), "afk_decode_chain_lm_head_batched: more than 8 sequences need N %% 32 == 0 and K %% 64 == 0");
     ChainArgs p = {};
     p.x = (const bf16*)h; p.ldx = ldh; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.out_f32 = logits; p.ld_out = ld_logits; p.D = 2;
+    if (M > AFK_CHAIN_BATCH_MAX) {
+        p.kil = 1;
+        if (M > 2 * AFK_CHAIN_BATCH_MAX) launch_chain_ng<EPI_LOGITS, 4, 32, PRO_PLAIN_LDS, 4>(p, N, ST);
+        else launch_chain_ng<EPI_LOGITS, 4, 32, PRO_PLAIN_LDS, 2>(p, N, ST);
+        AFK_LAUNCH_CHECK("afk_decode_chain_lm_head_batched");
+        return AFK_OK;
+    }
     launch_chain_batched<EPI_LOGITS>(p, N, 4, N / 8 >= 2048 ? 1 : 4, ST);
     AFK_LAUNCH_CHECK("afk_decode_chain_lm_head_batched");
     return AFK_OK;

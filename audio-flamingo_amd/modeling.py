@@ -1016,6 +1016,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     decode_mfma_from = int(os.environ.get("AFK_DECODE_MFMA_FROM", "2"))   # batched decode: sequences per step from which the norm-in-prologue matrix-pipe launches run
     decode_chain_batch_max = int(os.environ.get("AFK_DECODE_CHAIN_BATCH_MAX", "32"))   # 9 .. 32 sequences: two / four groups of eight through the same launches (8 = the split-K tile path of rounds 3-5 above eight)
+    decode_prologue_max = int(os.environ.get("AFK_DECODE_PROLOGUE_MAX", "8"))   # largest batch that takes the RMSNorm in the consumer's prologue (above: a norm launch + plain launches)
     decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)
     decode_chain_batch = int(os.environ.get("AFK_DECODE_CHAIN_BATCH", "8"))   # largest batch the one-launch-per-Linear kernels take (0: single sequence only)
 
@@ -1042,6 +1043,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         I0 = a[f"{lm}layers.0.mlp.gate_up.weight"].data.shape[0] // 2
         shapes_ok = B >= self.decode_mfma_from and self._prologue_shapes_ok(head)
         mode = self.decode_norm_mode if shapes_ok else "launch"
+        if mode == "prologue" and B > self.decode_prologue_max:
+            mode = "launch"   # 9 .. 32 sequences: normalising 16 - 32 rows in EVERY block costs more VALU time than one norm launch (B = 12: 4.20 ms in the prologue, 3.99 with the launch; gate|up at 17 rows: 82 us)
         if mode == "producer":
             cnt = getattr(self, "_chain_norm_counter", None)
             if cnt is None or cnt.device != dev:

@@ -367,6 +367,8 @@ int afk_decode_select_greedy(const float* part_val, const int* part_idx, int npa
 /* The same launches for 2 .. 8 sequences decoded together (one new position each; the weights are still read once per step): M input rows h [M][K] (row stride
  * ldh) that are ALREADY normalised where the Linear follows a norm (Qwen2DecoderLayer :270 / :294, Qwen2Model.norm); pos[M] = position of each sequence's new token,
  * *start_dev = the cache slot all of them write; q_out [M][Hq*D] (row stride ldq); k_bs / vt_bs = batch strides of the K / V^T caches (elements).  Rounding points as above. */
+/* (round 6) the four _batched entry points below also take 9 .. 32 sequences - groups of eight as further columns of the same MFMA, input rows through the wave-private
+ * LDS strip (K % 64 == 0; 32-row / 16-row output groups: N % 32 == 0) - where rounds 3-5 fell back to split-K tiles + glue kernels. */
 int afk_decode_chain_qkv_batched(const void* h, int64_t ldh, int M, const void* W, int64_t ldw, int K, const void* bias, const void* cos_t, const void* sin_t,
                                  const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs, void* vtcache, int64_t vt_bs, int spad, const int* start_dev,
                                  int Hq, int Hkv, int D, void* stream);

@@ -1448,6 +1448,64 @@ def test_decode_chain_norm_in_prologue_batched(dev, M):
     _cmp("norm-prologue lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("M", [9, 16, 21, 32])
+def test_decode_chain_batched_plain_entries_more_than_eight_sequences(dev, M):
+    """the plain _batched entry points (inputs already normalised) for 9 .. 32 sequences: groups of eight as columns of one MFMA (gemv_chain_mfma_ng_kernel) - every
+    group of eight rows bit-identical to... the stand-alone kernel sequence within tolerance, and to the eight-sequence launches of the same rows where those take the
+    same arithmetic (the sums of a column do not depend on the other columns)"""
+    from audio_flamingo_amd import _lib
+    ops = _ops()
+    H, Hq, Hkv, D, I = 3584, 28, 4, 128, 18944
+    nq, nk = Hq * D, Hkv * D
+    N = nq + 2 * nk
+    st = ops._stream()
+    h = _rand((M, H), dev, 1.0, 1).to(BF)
+    res = _rand((M, H), dev, 1.0, 2).to(BF)
+    w = _rand((N, H), dev, 0.02, 3).to(BF)
+    bias = _rand((N,), dev, 0.1, 4).to(BF)
+    Smax, start = 256, 41
+    spad = ops.pad64(Smax)
+    inv = 1.0 / (1e6 ** (torch.arange(0, D, 2, device=dev, dtype=torch.float32) / D))
+    fr = torch.arange(64, device=dev, dtype=torch.float32)[:, None] * inv[None]
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    pos_t = torch.tensor([37 - 3 * (m % 12) for m in range(M)], device=dev, dtype=torch.int32)
+    start_t = torch.tensor([start], device=dev, dtype=torch.int32)
+    qkv = ops.gemm_nt(h, w, bias=bias)
+    ops.rope_(qkv, cos, sin, S=1, nheads=Hq + Hkv, D=D, pos=pos_t)
+    Kc = torch.zeros((M, Smax, nk), device=dev, dtype=BF)
+    Vt = torch.zeros((M, Hkv, D, spad), device=dev, dtype=BF)
+    q = torch.zeros((M, nq), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_qkv_batched", h.data_ptr(), H, M, w.data_ptr(), w.stride(0), H, bias.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos_t.data_ptr(),
+              q.data_ptr(), nq, Kc.data_ptr(), Smax * nk, Vt.data_ptr(), Hkv * D * spad, spad, start_t.data_ptr(), Hq, Hkv, D, st)
+    torch.cuda.synchronize()
+    _cmp("grouped q", q, qkv[:, :nq].float(), atol=3e-2, rtol=2e-2)
+    _cmp("grouped k", Kc[:, start], qkv[:, nq:nq + nk].float(), atol=3e-2, rtol=2e-2)
+    _cmp("grouped v", Vt[:, :, :, start].reshape(M, -1), qkv[:, nq + nk:].float(), atol=3e-2, rtol=2e-2)
+    Kc[:, start] = 0
+    Vt[:, :, :, start] = 0
+    assert float(Kc.float().abs().sum()) == 0.0 and float(Vt.float().abs().sum()) == 0.0, "only the new cache slot may be written"
+    for K_ in (nq, I):
+        a = _rand((M, K_), dev, 1.0, 5).to(BF)
+        wl = _rand((H, K_), dev, 0.02, 6).to(BF)
+        out = torch.empty((M, H), device=dev, dtype=BF)
+        _lib.call("afk_decode_chain_linear_residual_batched", a.data_ptr(), K_, M, wl.data_ptr(), wl.stride(0), H, K_, res.data_ptr(), H, out.data_ptr(), H, st)
+        _cmp(f"grouped linear+residual K={K_}", out, ops.gemm_nt(a, wl, residual=res).float(), atol=3e-2, rtol=2e-2)
+        tail = torch.empty((M - 8, H), device=dev, dtype=BF)   # the sequences behind the first group on their own: the same sums
+        _lib.call("afk_decode_chain_linear_residual_batched", a[8:].data_ptr(), K_, min(M - 8, 8), wl.data_ptr(), wl.stride(0), H, K_, res[8:].data_ptr(), H, tail.data_ptr(), H, st)
+        _cmp("grouped vs eight-sequence launch", out[8:8 + min(M - 8, 8)], tail[:min(M - 8, 8)].float(), atol=2e-2, rtol=1e-2)
+    wgu = _rand((2 * I, H), dev, 0.02, 7).to(BF)
+    act = torch.empty((M, I), device=dev, dtype=BF)
+    _lib.call("afk_decode_chain_gate_up_batched", h.data_ptr(), H, M, wgu.data_ptr(), wgu.stride(0), I, H, act.data_ptr(), I, st)
+    _cmp("grouped gate|up", act, ops.silu_mul_fwd(ops.gemm_nt(h, wgu)).float(), atol=3e-2, rtol=3e-2)
+    V = 4096
+    wh = _rand((V, H), dev, 0.02, 8).to(BF)
+    logits = torch.empty((M, V), device=dev, dtype=torch.float32)
+    _lib.call("afk_decode_chain_lm_head_batched", h.data_ptr(), H, M, wh.data_ptr(), wh.stride(0), V, H, logits.data_ptr(), V, st)
+    assert torch.equal(logits, logits.to(BF).float())
+    _cmp("grouped lm_head", logits, ops.gemm_nt(h, wh).float(), atol=3e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("M", [1, 4, 8])
 def test_decode_chain_linear_residual_norm_fused(dev, M):
     """afk_decode_chain_linear_residual_norm_batched (Linear + residual + the RMSNorm that follows in one launch; the last block to arrive normalises) against
