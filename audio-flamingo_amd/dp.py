@@ -538,7 +538,8 @@ class BackwardOverlap:
         self.side = make_stream(arena.device, "side")
         self._done: List[bool] = []
         self.grad_scale = engine.grad_scale if engine is not None else 1.0
-        self.thin_blocks = 256  # optimizer launches of one block per CU so that they co-reside with the GEMM workgroups
+        self.thin_blocks = 768  # optimizer launches of three blocks per CU: thin enough to co-reside with the GEMM workgroups (a full grid locks them out), and 1.5 ms per step faster
+                                # than one block per CU under the low-priority side stream (round 6, call 24: 256 / 512 / 768 / 1024 / 2048 blocks = 390.9 / 389.3 / 388.7 / 389.3 / 389.7 ms)
         # measure_tail (eager steps only - captured events carry no timestamps): HIP-event pairs around the wait for the side stream at the end of every
         # step = how long the compute stream sat idle behind the last backward kernel waiting for [exchange ->] AdamW -> shadow refresh of the last buckets
         self.measure_tail = False

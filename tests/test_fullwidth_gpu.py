@@ -145,11 +145,11 @@ def test_fulldepth_parity_vs_live_reference_on_the_benchmark_configuration(dev):
 
 
 # ------------------------------------------------------------------------------------------------ attention values at the AF3 shapes
-@pytest.mark.parametrize("B", [1, 2, 8])
+@pytest.mark.parametrize("B", [1, 2, 8, 12, 20])
 def test_fullwidth_decode_step_vs_recompute(dev, B, monkeypatch):
     """The decode step at the widths of the 7B model (hidden 3584, 28:4 x 128 heads, ffn 18 944, vocabulary 152 064; one decoder layer): logits of the new
     position from the KV-cache paths - B = 1: one launch per Linear (csrc/decode_chain.hip); B = 2 / 8: the same launches with M input rows on the matrix pipe through wave-private LDS, the
-    RMSNorm in their prologue (B = 8: the attention in its matrix-pipe group form); and the round-3 split-K + glue / generic paths - against the NO-cache forward of the extended sequence through the
+    RMSNorm in their prologue (B = 8: the attention in its matrix-pipe group form); B = 12 / 20: two / four groups of eight sequences in one pass over the weights; and the round-3 split-K + glue / generic paths - against the NO-cache forward of the extended sequence through the
     training-path kernels (which test_fullwidth_depth_reduced_model_vs_oracle pins to the oracle).  Tolerance: LOGIT_TOL of test_model_gpu (4e-2 at logit scale ~1)."""
     import bench
     from audio_flamingo_amd import _lib
@@ -187,7 +187,8 @@ def test_fullwidth_decode_step_vs_recompute(dev, B, monkeypatch):
             torch.cuda.synchronize()
             names = set(called)
             if chain:
-                want = "afk_decode_chain_qkv" if B == 1 else "afk_decode_chain_qkv_norm_batched"   # round 6: from two sequences on, the norm-in-prologue matrix-pipe launches
+                # round 6: 2 .. 8 sequences the norm-in-prologue matrix-pipe launches, 9 .. 32 groups of eight through the plain entry points behind a norm launch
+                want = "afk_decode_chain_qkv" if B == 1 else "afk_decode_chain_qkv_norm_batched" if B <= 8 else "afk_decode_chain_qkv_batched"
                 assert want in names and "afk_attn_decode_fused" in names and "afk_gemv_partials" not in names, names
             else:
                 assert not any(n.startswith("afk_decode_chain") for n in names), names
