@@ -60,8 +60,8 @@ struct ChainArgs {
     int64_t ld_n2;
     float n2_eps;
     int* n2_counter;      // one zero-initialised int32 (self-resetting)
-    float* ss_out;        // EPI_RESID (matrix-pipe form), or null: ss_out[block][8] = this block's share of sum(out[m][:]^2) per sequence - the consumer's RMSNorm statistic
-    const float* ss_in;   // PRO_RMS, or null: the producer's partial sums [ss_nparts][8] of the rows in x (null: every block takes the statistic from x itself)
+    float* ss_out;        // EPI_RESID (matrix-pipe form), or null: ss_out[8][blocks] = this block's share of sum(out[m][:]^2) per sequence - the consumer's RMSNorm statistic
+    const float* ss_in;   // PRO_RMS, or null: the producer's partial sums [8][ss_nparts] of the rows in x (null: every block takes the statistic from x itself)
     int ss_nparts, ss_first;
     int kil;              // gemv_chain_mfma_kernel: stages of the K loop dealt round-robin to the waves of a block (1) or one contiguous slice per wave (0)
     float* part_val;      // EPI_LOGITS: per row group, the largest logit ...
@@ -574,17 +574,20 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
         if (p.ss_in != nullptr) {
             // the Linear that wrote these rows left its per-block sums of squares (EPI_RESID, ss_out): every WAVE folds the ss_nparts x 8 floats itself - lane -> row
             // lane >> 3, parts (lane & 7) + 8 i - and the eight lanes of a row meet through three shuffles: no block barrier, one L2 round trip beside the first weights
-            constexpr int NP8 = 32;   // up to 256 parts (N <= 4096 at 16-row groups); every load is issued before the first sum - a loop of load -> add is a round trip per part
-            float v[NP8];
+            constexpr int NP4 = 8;   // up to 256 parts (N <= 4096 at 16-row groups), laid out [row][part]: a lane takes parts 4 (lane & 7) + 32 i .. + 3 of its row as
+                                     // ONE 16-byte load (a quarter of the load instructions of a [part][row] layout); every load is issued before the first sum -
+                                     // a loop of load -> add is a round trip per part
+            const float* ssr = p.ss_in + (int64_t)xm * p.ss_nparts;
+            f32x4 v[NP4];
 #pragma unroll
-            for (int i = 0; i < NP8; ++i) {
-                const int gp = 8 * i + xpc;
-                v[i] = gp < p.ss_nparts ? p.ss_in[gp * MBX + xm] : 0.f;
+            for (int i = 0; i < NP4; ++i) {
+                const int gp = 4 * (xpc + 8 * i);
+                v[i] = gp < p.ss_nparts ? *(const f32x4*)(ssr + gp) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             if (b0 < b1 && ss_first) gload(ga, b0);
             float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < NP8; ++i) a += v[i];
+            for (int i = 0; i < NP4; ++i) a += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             a += __shfl_xor(a, 1, 64);
             a += __shfl_xor(a, 2, 64);
             a += __shfl_xor(a, 4, 64);
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
                 float a = 0.f;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) a += fin[rr * MBX + threadIdx.x];
-                p.ss_out[(int64_t)g * MBX + threadIdx.x] = a;
+                p.ss_out[(int64_t)threadIdx.x * gridDim.x + g] = a;   // [row][part]
             }
         }
     } else if (EPI == EPI_SWIGLU) {
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_kernel(ChainArgs p) {
 // its sequences are eight more COLUMNS of the same MFMA: the strip holds 8 NG rows, one fragment read and one v_mfma_f32_32x32x16_bf16 per 16 reduction elements
 // serve all groups - the matrix pipe and the LDS do the work of an eight-sequence step (a first form ran the MFMAs group by group: B = 17 6.75 ms, slower than
 // the tile path).  The sums of a column are those of the eight-sequence launch bit for bit.  Every block barrier is executed by every thread (no early exits: the
-// epilogue runs once per group).  ss_in / ss_out are [NG][parts][8].
+// epilogue runs once per group).  ss_in / ss_out are [NG][8][parts].
 template <int EPI, int S, int RG, int PRO, int NG>
 __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p) {
     constexpr int R = RG, HR = RG / 2, MBX = AFK_CHAIN_BATCH_MAX;
@@ -963,18 +966,18 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
         if (p.ss_in != nullptr) {   // per group: the producer's partial sums, all loads of a group in flight together, before the first weights
 #pragma unroll
             for (int sg = 0; sg < NG; ++sg) {
-                constexpr int NP8 = 32;
-                const float* ssg = p.ss_in + (int64_t)sg * p.ss_nparts * MBX;
-                float v[NP8];
+                constexpr int NP4 = 8;
+                const float* ssr = p.ss_in + ((int64_t)sg * MBX + xm) * p.ss_nparts;   // [group][row][part]
+                f32x4 v[NP4];
 #pragma unroll
-                for (int i = 0; i < NP8; ++i) {
-                    const int gp = 8 * i + xpc;
-                    v[i] = gp < p.ss_nparts ? ssg[gp * MBX + xm] : 0.f;
+                for (int i = 0; i < NP4; ++i) {
+                    const int gp = 4 * (xpc + 8 * i);
+                    v[i] = gp < p.ss_nparts ? *(const f32x4*)(ssr + gp) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 if (sg == 0 && b0 < b1) gload(ga, b0);   // the first weights right behind the first group's partial sums
                 float a = 0.f;
 #pragma unroll
-                for (int i = 0; i < NP8; ++i) a += v[i];
+                for (int i = 0; i < NP4; ++i) a += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
                 a += __shfl_xor(a, 1, 64);
                 a += __shfl_xor(a, 2, 64);
                 a += __shfl_xor(a, 4, 64);
@@ -1127,7 +1130,7 @@ __global__ __launch_bounds__(64 * S) void gemv_chain_mfma_ng_kernel(ChainArgs p)
                 float a = 0.f;
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) a += fin[rr * MBX + t];
-                p.ss_out[((int64_t)sg * gridDim.x + g) * MBX + t] = a;
+                p.ss_out[((int64_t)sg * MBX + t) * gridDim.x + g] = a;   // [group][row][part]
             }
         }
         __syncthreads();   // fin is rewritten by the next group
@@ -1394,7 +1397,8 @@ extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int
                                                  void* vtcache, int64_t vt_bs, int spad, const int* start_dev, int Hq, int Hkv, int D, const float* ss_part,
                                                  int ss_nparts, void* stream) {
     AFK_REQUIRE(x && norm_w && W && bias && cos_t && sin_t && pos && q_out && kcache && vtcache && start_dev, "afk_decode_chain_qkv_norm_batched: null pointer");
-    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_qkv_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256 && ss_nparts % 4 == 0 && (uintptr_t)ss_part % 16 == 0),
+                "afk_decode_chain_qkv_norm_batched: 4 .. 256 partial sums per row, a multiple of 4, 16-byte aligned");
     AFK_REQUIRE(M >= 1 && M <= AFK_CHAIN_SEQ_MAX && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0 && Hq > 0 && Hkv > 0 && (D / 2) % 16 == 0 && (Hkv * D) % 32 == 0 &&
                     ((Hq + 2 * Hkv) * D) % 32 == 0 && spad > 0,
                 "afk_decode_chain_qkv_norm_batched: unsupported shape (1 <= M <= 32, K %% 64 == 0, head_dim %% 32 == 0)");
@@ -1410,7 +1414,8 @@ extern "C" int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int
 
 extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int I, int K,
                                                      void* act_out, int64_t ld_act, const float* ss_part, int ss_nparts, void* stream) {
-    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_gate_up_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256 && ss_nparts % 4 == 0 && (uintptr_t)ss_part % 16 == 0),
+                "afk_decode_chain_gate_up_norm_batched: 4 .. 256 partial sums per row, a multiple of 4, 16-byte aligned");
     AFK_REQUIRE(x && norm_w && W && act_out && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && I > 0 && I % 16 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
                 "afk_decode_chain_gate_up_norm_batched: unsupported shape (1 <= M <= 32, I %% 16 == 0, K %% 64 == 0)");
     ChainArgs p = {};
@@ -1423,7 +1428,8 @@ extern "C" int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx,
 
 extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K,
                                                      float* logits, int64_t ld_logits, const float* ss_part, int ss_nparts, void* stream) {
-    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256), "afk_decode_chain_lm_head_norm_batched: 1 .. 256 partial sums");
+    AFK_REQUIRE(!ss_part || (ss_nparts > 0 && ss_nparts <= 256 && ss_nparts % 4 == 0 && (uintptr_t)ss_part % 16 == 0),
+                "afk_decode_chain_lm_head_norm_batched: 4 .. 256 partial sums per row, a multiple of 4, 16-byte aligned");
     AFK_REQUIRE(x && norm_w && W && logits && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
                 "afk_decode_chain_lm_head_norm_batched: unsupported shape (1 <= M <= 32, N %% 32 == 0, K %% 64 == 0)");
     ChainArgs p = {};
@@ -1438,8 +1444,8 @@ extern "C" int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx,
 // the statistic of the RMSNorm that FOLLOWS, folded by the next Linear's prologue (afk_decode_chain_*_norm_batched with ss_part): no pass over the rows, no hand-over.
 extern "C" int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
                                                            void* out, int64_t ld_out, float* ss_part, void* stream) {
-    AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 32 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
-                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 32, N %% 32 == 0, K %% 64 == 0)");
+    AFK_REQUIRE(x && W && residual && out && ss_part && M >= 1 && M <= AFK_CHAIN_SEQ_MAX && N > 0 && N % 64 == 0 && K > 0 && K % 64 == 0 && ldw % 8 == 0 && ldx % 8 == 0,
+                "afk_decode_chain_linear_residual_ss_batched: bad arguments (1 <= M <= 32, N %% 64 == 0, K %% 64 == 0)");
     ChainArgs p = {};
     p.x = (const bf16*)x; p.ldx = ldx; p.M = M; p.W = (const bf16*)W; p.ldw = ldw; p.N = N; p.K = K; p.residual = (const bf16*)residual; p.ld_res = ld_res;
     p.out = (bf16*)out; p.ld_out = ld_out; p.D = 2; p.ss_out = ss_part; p.kil = 1;

@@ -1076,7 +1076,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           A("post_attention_layernorm.weight").data.data_ptr(), eps, h2.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ss2 = torch.empty((ngrp, H // 16, 8), device=dev, dtype=torch.float32)   # [groups of eight sequences the launch runs: 1, 2 or 4][blocks of the launch][8]
+                ss2 = torch.empty((ngrp, 8, H // 16), device=dev, dtype=torch.float32)   # [groups of eight sequences the launch runs: 1, 2 or 4][8][blocks of the launch]
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", o.data_ptr(), nq, B, wo.data_ptr(), wo.stride(0), H, nq, x.data_ptr(), x.stride(0), x2.data_ptr(), H,
                           ss2.data_ptr(), st)
             else:
@@ -1098,7 +1098,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
                 _lib.call("afk_decode_chain_linear_residual_norm_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H,
                           nxt.data_ptr(), eps, h.data_ptr(), H, cnt.data_ptr(), st)
             elif mode == "prologue":
-                ssx = torch.empty((ngrp, H // 16, 8), device=dev, dtype=torch.float32)
+                ssx = torch.empty((ngrp, 8, H // 16), device=dev, dtype=torch.float32)
                 _lib.call("afk_decode_chain_linear_residual_ss_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, ssx.data_ptr(), st)
             else:
                 _lib.call("afk_decode_chain_linear_residual_batched", act.data_ptr(), I, B, wd.data_ptr(), wd.stride(0), H, I, x2.data_ptr(), H, x.data_ptr(), H, st)

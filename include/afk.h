@@ -379,7 +379,7 @@ int afk_decode_chain_linear_residual_batched(const void* x, int64_t ldx, int M, 
  * block derives the row statistic itself (its K split covers all columns) and normalises the rows it consumes through a wave-private LDS strip (Qwen2RMSNorm
  * :247-252, cast before the weight multiply): no norm launch, no hand-over between blocks.  ss_part / ss_nparts: the producer's partial sums (below), or null / 0.
  * Otherwise as the _batched entry points above.  K % 64 == 0.  1 <= M <= 32: nine and more sequences run as two / four GROUPS of eight (more columns of the same MFMA) in one pass over the
- * weights (every group an independent instance of the eight-sequence arithmetic); ss_part is then [G][ss_nparts][8], G = 2 (M <= 16) or 4. */
+ * weights (every group an independent instance of the eight-sequence arithmetic); ss_part is then [G][8][ss_nparts], G = 2 (M <= 16) or 4.  ss_nparts % 4 == 0, ss_part 16-byte aligned. */
 int afk_decode_chain_qkv_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int K, const void* bias,
                                       const void* cos_t, const void* sin_t, const int* pos, void* q_out, int64_t ldq, void* kcache, int64_t k_bs, void* vtcache,
                                       int64_t vt_bs, int spad, const int* start_dev, int Hq, int Hkv, int D, const float* ss_part, int ss_nparts, void* stream);
@@ -387,10 +387,10 @@ int afk_decode_chain_gate_up_norm_batched(const void* x, int64_t ldx, int M, con
                                           int64_t ld_act, const float* ss_part, int ss_nparts, void* stream);
 int afk_decode_chain_lm_head_norm_batched(const void* x, int64_t ldx, int M, const void* norm_w, float eps, const void* W, int64_t ldw, int N, int K, float* logits,
                                           int64_t ld_logits, const float* ss_part, int ss_nparts, void* stream);
-/* afk_decode_chain_linear_residual_batched on the matrix-pipe form that also leaves ss_part[N / 16][8]: every block's share of sum_n out[m][n]^2 per sequence m.  Passed
+/* afk_decode_chain_linear_residual_batched on the matrix-pipe form that also leaves ss_part[8][N / 16]: every block's share of sum_n out[m][n]^2 per sequence m (N % 64 == 0).  Passed
  * to the NEXT Linear's afk_decode_chain_*_norm_batched (ss_part, ss_nparts = N / 16) it replaces that launch's own pass over the rows: every wave folds the
  * partial sums in part order (bit-reproducible).  ss_part = null there: the block takes the statistic from x itself (the first layer, whose rows no Linear wrote).
- * 1 <= M <= 32; ss_part holds G x (N / 16) x 8 floats, G = the groups of eight sequences the launch RUNS: 1 (M <= 8), 2 (M <= 16) or 4 (an empty group writes zeros). */
+ * 1 <= M <= 32; ss_part holds G x 8 x (N / 16) floats, G = the groups of eight sequences the launch RUNS: 1 (M <= 8), 2 (M <= 16) or 4 (an empty group writes zeros). */
 int afk_decode_chain_linear_residual_ss_batched(const void* x, int64_t ldx, int M, const void* W, int64_t ldw, int N, int K, const void* residual, int64_t ld_res,
                                                 void* out, int64_t ld_out, float* ss_part, void* stream);
 /* Linear + residual + the RMSNorm that follows it in ONE launch, 1 .. 8 sequences (round 6): out = bf16(W x) + residual (Qwen2DecoderLayer :284 / :297), h_out =

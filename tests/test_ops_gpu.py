@@ -1427,11 +1427,11 @@ def test_decode_chain_norm_in_prologue_batched(dev, M):
         _lib.call("afk_decode_chain_linear_residual_batched", a_in[m0:].data_ptr(), nq, mm, wl.data_ptr(), wl.stride(0), H, nq, res[m0:].data_ptr(), H, rows_w[m0:].data_ptr(), H, st)
     rows_s = torch.empty((M, H), device=dev, dtype=BF)
     NGt = 1 if M <= 8 else 2 if M <= 16 else 4   # groups the launch runs
-    ssp = torch.full((NGt, H // 16, 8), float("nan"), device=dev, dtype=torch.float32)
+    ssp = torch.full((NGt, 8, H // 16), float("nan"), device=dev, dtype=torch.float32)   # [groups][row][blocks of the launch]
     _lib.call("afk_decode_chain_linear_residual_ss_batched", a_in.data_ptr(), nq, M, wl.data_ptr(), wl.stride(0), H, nq, res.data_ptr(), H, rows_s.data_ptr(), H, ssp.data_ptr(), st)
     _cmp("linear+residual (ss form)", rows_s, rows_w.float(), atol=3e-2, rtol=2e-2)
     want_ss = (rows_s.float() ** 2).sum(1)
-    got_all = ssp.sum(1).reshape(-1)               # [groups * 8]: sequence 8 g + m
+    got_all = ssp.sum(2).reshape(-1)               # [groups * 8]: sequence 8 g + m
     got_ss = got_all[:M]
     assert bool(((got_ss - want_ss).abs() <= 1e-4 * want_ss).all()) and float(got_all[M:].abs().sum()) == 0.0
     act_b = torch.empty((M, I), device=dev, dtype=BF)

@@ -46,7 +46,7 @@ cnt = torch.zeros(1, device=dev, dtype=torch.int32)
 hn = torch.empty(M, H, device=dev, dtype=BF)
 def k_on(i): _lib.call("afk_decode_chain_linear_residual_norm_batched", o.data_ptr(), nq, M, W[i]["o"].data_ptr(), nq, H, nq, x.data_ptr(), H, x2.data_ptr(), H, nw.data_ptr(), 1e-6, hn.data_ptr(), H, cnt.data_ptr(), st)
 def k_dn(i): _lib.call("afk_decode_chain_linear_residual_norm_batched", actr.data_ptr(), I, M, W[i]["d"].data_ptr(), I, H, I, x.data_ptr(), H, x2.data_ptr(), H, nw.data_ptr(), 1e-6, hn.data_ptr(), H, cnt.data_ptr(), st)
-ssp = torch.rand(H // 16, 8, device=dev, dtype=torch.float32)
+ssp = torch.rand(4, 8, H // 16, device=dev, dtype=torch.float32)
 SS = lambda: ssp.data_ptr() if os.environ.get("SSPART", "1") == "1" else None
 def k_qkvn(i): _lib.call("afk_decode_chain_qkv_norm_batched", x.data_ptr(), H, M, nw.data_ptr(), 1e-6, W[i]["qkv"].data_ptr(), H, H, bias.data_ptr(), cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), q.data_ptr(), nq, Kc[i].data_ptr(), Smax * nk, Vt[i].data_ptr(), Hkv * D * spad, spad, start.data_ptr(), Hq, Hkv, D, SS(), H // 16, st)
 def k_gun(i): _lib.call("afk_decode_chain_gate_up_norm_batched", x.data_ptr(), H, M, nw.data_ptr(), float(os.environ.get("EPS", "1e-6")), W[i]["gu"].data_ptr(), H, I, H, act.data_ptr(), I, SS(), H // 16, st)
