@@ -23,6 +23,31 @@ def _cfg():
     return AudioFlamingo3Config(**TINY)
 
 
+def test_decode_batch_routing_host_logic():
+    """which batches take the one-launch-per-Linear decode step (host logic of modeling._chain_batch_cap / _prologue_shapes_ok, round 6): the tiny test geometry
+    (hidden 256, 4:2 x 64 heads) and the AF3-7B geometry take the norm-in-prologue launches up to 8 sequences and groups of eight up to 32; AFK_DECODE_CHAIN_BATCH_MAX
+    caps it; a geometry the 64-element blocks do not divide, or another norm mode, stays at eight sequences on rounds 4-5's launches"""
+    import types
+
+    import torch
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    m = Mine(_cfg(), device="cpu")
+    head = m.arena["lm_head.weight"].data
+    assert m._prologue_shapes_ok(head) and m._chain_batch_cap(head) == 32
+    big = types.SimpleNamespace(H=3584, Hq=28, Hkv=4, D=128, I=18944, decode_chain_batch=8, decode_chain_batch_max=32, decode_norm_mode="prologue")
+    big._prologue_shapes_ok = types.MethodType(Mine._prologue_shapes_ok, big)
+    big._chain_batch_cap = types.MethodType(Mine._chain_batch_cap, big)
+    wide = torch.empty((152064, 1), dtype=torch.bfloat16)
+    assert big._prologue_shapes_ok(wide) and big._chain_batch_cap(wide) == 32
+    big.decode_chain_batch_max = 16
+    assert big._chain_batch_cap(wide) == 16
+    big.decode_chain_batch_max, big.decode_norm_mode = 32, "launch"
+    assert big._chain_batch_cap(wide) == 8
+    big.decode_norm_mode, big.I = "prologue", 18944 + 8    # an intermediate size the 64-element blocks do not divide
+    assert not big._prologue_shapes_ok(wide) and big._chain_batch_cap(wide) == 8
+
+
 def test_library_exports_every_declared_symbol():
     from audio_flamingo_amd import _lib
 
