@@ -890,6 +890,26 @@ def test_generate_left_padded_batch_matches_single(dev):
     assert both[1, 40:].tolist() == alone[1][0, 23:].tolist()
 
 
+@pytest.mark.parametrize("B", [5, 12, 20])
+def test_generate_batches_of_more_than_eight_match_single(dev, B):
+    """round 6: batches of 9 .. 32 sequences run the decode step as groups of eight in one pass over the weights (5: one group, the norm-in-prologue launches;
+    12 / 20: two / four groups behind norm launches, 20 with a partly filled and an empty group) - every row, left padded to the common length, must decode
+    as it does alone"""
+    torch.manual_seed(5)
+    m = _model(dev)
+    lens = [40 - (3 * i) % 17 for i in range(B)]
+    prompts = [torch.randint(0, 256, (1, n)) for n in lens]
+    ids = torch.zeros((B, 40), dtype=torch.long)
+    att = torch.zeros((B, 40), dtype=torch.long)
+    for i, pr in enumerate(prompts):
+        ids[i, 40 - lens[i]:] = pr[0]
+        att[i, 40 - lens[i]:] = 1
+    both = m.generate(ids.to(dev), attention_mask=att.to(dev), max_new_tokens=8).cpu()
+    for i in sorted({0, 1, min(7, B - 1), min(8, B - 1), B - 2, B - 1}):
+        alone = m.generate(prompts[i].to(dev), max_new_tokens=8).cpu()
+        assert both[i, 40:].tolist() == alone[0, lens[i]:].tolist(), f"row {i} of a batch of {B}"
+
+
 def test_gradient_checkpointing_matches(dev):
     """recompute (oracle row a19) must not change loss or gradients, whatever the plan: the reference's every-layer recompute ("full"), the
     memory-budgeted default (which recomputes nothing when the batch fits the budget) and a budget so tight that only part of each tower is
