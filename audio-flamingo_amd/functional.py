@@ -74,6 +74,26 @@ NN_DGRAD_DEFAULT = "mlp.gate_up.weight"
 NN_DGRAD_SUFFIXES = tuple(x for x in os.environ.get("AFK_NN_DGRAD", NN_DGRAD_DEFAULT).split(",") if x)
 
 
+# Recomputation of a checkpointed layer (torch.utils.checkpoint re-runs the stage's forward inside backward; modeling._layer sets the flag around exactly that
+# re-run): what the re-run produces is only read through the tensors the stage KEEPS for its backward - its output is thrown away - so the GEMM that produces
+# nothing but the output (encoder fc2, decoder down_proj: 36 % / 29 % of a layer's forward GEMM work) is dead there and is skipped.  The reference's
+# GradientCheckpointingLayer recomputes it (autograd cannot know); gradients are bit-identical either way (AFK_RECOMPUTE_SKIP_TAIL=0 restores it).
+RECOMPUTING = False
+RECOMPUTE_SKIP_TAIL = os.environ.get("AFK_RECOMPUTE_SKIP_TAIL", "1") == "1"
+
+
+class recomputing:
+    """context manager of the re-run (the second manager of torch.utils.checkpoint's context_fn)"""
+
+    def __enter__(self):
+        global RECOMPUTING
+        self.prev, RECOMPUTING = RECOMPUTING, True
+
+    def __exit__(self, *a):
+        global RECOMPUTING
+        RECOMPUTING = self.prev
+
+
 # Bias gradients where their operand is produced (round 6, AFK_FUSE_BIAS_SUMS=0 restores the separate column-sum passes): the column-owned LayerNorm backward
 # also sums the residual-stream gradient it writes (= grad_output of the Linear below the norm: out_proj in the same layer, fc2 of the LOWER layer), and the GELU
 # backward sums the d(pre-activation) it writes (= grad_output of fc1).
@@ -244,7 +264,10 @@ class EncoderLayerFn:
         h2, mean2, rstd2 = ops.layernorm_fwd(x2, A("final_layer_norm.weight").data, A("final_layer_norm.bias").data)
         pre = torch.empty((x.shape[0], A("fc1.weight").shape[0]), device=x.device, dtype=torch.bfloat16)
         f = ops.gemm_nt(h2, A("fc1.weight").data, bias=A("fc1.bias").data, gelu=True, preact_out=pre)
-        x3 = ops.gemm_nt(f, A("fc2.weight").data, bias=A("fc2.bias").data, residual=x2)
+        if RECOMPUTING and RECOMPUTE_SKIP_TAIL:
+            x3 = torch.empty_like(x2)   # the re-run's output is discarded: fc2 is dead work there
+        else:
+            x3 = ops.gemm_nt(f, A("fc2.weight").data, bias=A("fc2.bias").data, residual=x2)
         ctx.save_for_backward(x, mean1, rstd1, h, qkv, o, lse, x2, mean2, rstd2, h2, pre, kv_len, f if SAVE_GELU else None)
         ctx.meta = (arena, pfx, W, S, H, D)
         return x3
@@ -415,7 +438,10 @@ class DecoderLayerFn:
         else:
             gu = ops.gemm_nt(h2, wgu)
             a = ops.silu_mul_fwd(gu)
-        x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
+        if RECOMPUTING and RECOMPUTE_SKIP_TAIL:
+            x3 = torch.empty_like(x2)   # the re-run's output is discarded: down_proj is dead work there
+        else:
+            x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
         # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
         ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo)
         ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)

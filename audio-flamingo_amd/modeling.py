@@ -530,9 +530,12 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
 
     def _layer(self, fn, *args, ckpt=True):
         if ckpt and self.gradient_checkpointing and torch.is_grad_enabled():
+            import contextlib
+
             from torch.utils.checkpoint import checkpoint
 
-            return checkpoint(fn, *args, use_reentrant=False)
+            # the second context manager wraps the RE-RUN of the layer inside backward: functional.py skips what only produces the (discarded) output there
+            return checkpoint(fn, *args, use_reentrant=False, context_fn=lambda: (contextlib.nullcontext(), F_.recomputing()))
         return fn(*args)
 
     def _require_hip(self):
