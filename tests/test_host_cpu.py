@@ -66,6 +66,32 @@ def test_library_exports_every_declared_symbol():
         _lib.call("afk_gemm_nt_bf16", 0, 0, 0, 0, 0, 0, 1, 1, 64, 0, 0, 0, 0, 0, 1.0, 0, 0)
 
 
+def test_round6_entry_points_validate_their_arguments_without_a_device():
+    """the decode / backward entry points of round 6 refuse what they cannot run BEFORE any GPU work (the error text names the limit): more than 32 sequences,
+    a reduction length the 64-element blocks do not divide, a partial-sum count that is not a multiple of four, null pointers"""
+    from audio_flamingo_amd import _lib
+    buf = torch.zeros(1 << 16, dtype=torch.float32)   # host memory: never touched - validation fails first
+    p = buf.data_ptr()
+    H, I = 3584, 18944
+    with pytest.raises(_lib.AfkError, match="1 <= M <= 32"):
+        _lib.call("afk_decode_chain_gate_up_norm_batched", p, H, 33, p, 1e-6, p, H, I, H, p, I, None, 0, 0)
+    with pytest.raises(_lib.AfkError, match="K %% 64|K % 64"):
+        _lib.call("afk_decode_chain_gate_up_norm_batched", p, H, 8, p, 1e-6, p, H, I, H + 8, p, I, None, 0, 0)
+    with pytest.raises(_lib.AfkError, match="multiple of 4"):
+        _lib.call("afk_decode_chain_gate_up_norm_batched", p, H, 8, p, 1e-6, p, H, I, H, p, I, p, 222, 0)
+    with pytest.raises(_lib.AfkError, match="more than 8 sequences need"):
+        _lib.call("afk_decode_chain_linear_residual_batched", p, H + 8, 12, p, H + 8, H, H + 8, p, H, p, H, 0)
+    with pytest.raises(_lib.AfkError, match="1 <= M <= 32"):
+        _lib.call("afk_decode_chain_linear_residual_ss_batched", p, H, 40, p, H, H, H, p, H, p, H, p, 0)
+    with pytest.raises(_lib.AfkError, match="null"):
+        _lib.call("afk_layernorm_bwd_colsum", p, p, p, p, p, p, p, p, p, 0, None, 0, p, 8, 64, 0)
+    with pytest.raises(_lib.AfkError, match="C %% 8|C % 8"):
+        _lib.call("afk_gelu_bwd_colsum", p, p, p, 8, 60, p, 0, p, 0)
+    with pytest.raises(_lib.AfkError, match="mode"):
+        _lib.call("afk_attn_decode_set_group", 7)
+    assert _lib.load().afk_gelu_bwd_colsum_parts(12000) >= 256 and _lib.load().afk_gelu_bwd_colsum_parts(5) == 5
+
+
 def test_state_dict_is_oracle_compatible_and_fused_views_alias():
     from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
 
