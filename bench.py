@@ -85,7 +85,13 @@ def train_flops_per_sample(S=S_TOK, windows=1, recompute=False):
     dec_1 = 2 * S * (2 * 3584 ** 2 + 2 * 3584 * 512 + 3 * 3584 * 18944) + 2 * S ** 2 * 3584
     lm = 2 * S * 3584 * 152064
     n_enc, n_dec = (32, 28) if recompute is True else (0, 0) if not recompute else recompute
-    return 3.0 * (enc + proj + lm) + windows * enc_1 * (3.0 * 32 + n_enc) + dec_1 * (3.0 * 28 + n_dec)
+    # the re-run of a checkpointed layer does not compute the GEMM whose only product is its (discarded) output - encoder fc2, decoder down_proj
+    # (functional.RECOMPUTE_SKIP_TAIL, round 6): the second forward of those layers is counted without it
+    from audio_flamingo_amd import functional as _F
+    skip = bool(getattr(_F, "RECOMPUTE_SKIP_TAIL", False))
+    enc_rerun = enc_1 - (2 * 1500 * 1280 * 5120 if skip else 0)
+    dec_rerun = dec_1 - (2 * S * 3584 * 18944 if skip else 0)
+    return 3.0 * (enc + proj + lm) + windows * (enc_1 * 3.0 * 32 + enc_rerun * n_enc) + dec_1 * 3.0 * 28 + dec_rerun * n_dec
 
 
 def _layer_flops():
