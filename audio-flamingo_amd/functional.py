@@ -419,7 +419,11 @@ class DecoderLayerFn:
     """RMSNorm -> GQA causal attention (RoPE) -> +res ; RMSNorm -> SwiGLU -> +res  (Qwen2DecoderLayer.forward, :269-298)"""
 
     @staticmethod
-    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None, kv_lo=None):
+    def forward(ctx, x, anchor, arena, pfx, B, S, Hq, Hkv, D, eps, cos, sin, pos, kv_len, krange=None, kv_lo=None, rows=None):
+        # rows (int64, ascending, on the device; None = every row; round 6): the LAST decoder layer of a training step with labels needs its residual stream only
+        # at the positions the loss reads (their keys / values still come from every row): behind the attention, o_proj, the post-attention norm and the MLP run
+        # on the gathered rows alone and the layer returns [len(rows), H].  Same loss and - up to the summation order inside the GEMMs - the same gradients (a
+        # row the loss does not read has an exactly zero grad_output); the reference computes every row (modeling_qwen2.py:269-298) and drops them at the loss.
         A = lambda k: arena[pfx + k]
         h, rstd1 = ops.rmsnorm_fwd(x, A("input_layernorm.weight").data, eps)
         # qkv projection with the rotary embedding in the GEMM's epilogue where the shape allows (ops.gemm_nt_rope, round 6)
@@ -429,7 +433,10 @@ class DecoderLayerFn:
         else:
             # right padding: kv_len; left padding on the LDS kernels (head_dim 64 / 128): kv_lo beside it
             o, lse = ops.attn_fwd(qkv, B, S, Hq, Hkv, D, scale=D ** -0.5, causal=True, kv_len=kv_len, kv_lo=kv_lo)
-        x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
+        if rows is not None:
+            x2 = ops.gemm_nt(ops.gather_rows(o, rows), A("self_attn.o_proj.weight").data, residual=ops.gather_rows(x, rows))
+        else:
+            x2 = ops.gemm_nt(o, A("self_attn.o_proj.weight").data, residual=x)
         h2, rstd2 = ops.rmsnorm_fwd(x2, A("post_attention_layernorm.weight").data, eps)
         wgu = A("mlp.gate_up.weight").data
         if FUSE_SWIGLU_FWD and wgu.shape[0] % 256 == 0:
@@ -443,13 +450,13 @@ class DecoderLayerFn:
         else:
             x3 = ops.gemm_nt(a, A("mlp.down_proj.weight").data, residual=x2)
         # `a` (310 MB / layer at B=8) is kept: 288 GB of HBM makes the recompute pass the worse trade
-        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo)
+        ctx.save_for_backward(x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo, rows)
         ctx.meta = (arena, pfx, B, S, Hq, Hkv, D)
         return x3
 
     @staticmethod
     def backward(ctx, dx3):
-        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo = ctx.saved_tensors
+        x, rstd1, h, qkv, o, lse, x2, rstd2, h2, gu, cos, sin, pos, kv_len, a, krange, kv_lo, rows = ctx.saved_tensors
         arena, pfx, B, S, Hq, Hkv, D = ctx.meta
         A = lambda k: arena[pfx + k]
         dx3 = dx3.contiguous()
@@ -467,7 +474,11 @@ class DecoderLayerFn:
         dx2 = ops.rmsnorm_bwd(x2, nw.data, dh2, rstd2, nw.grad, dx_add=dx3, accumulate=not nw.fresh)
         arena.grad_written(nw)
         del dh2
-        do = linear_bwd(arena, dx2, o, pfx + "self_attn.o_proj.weight")
+        if rows is not None:   # the rows the loss reads: their gradients go back to their places, every other row of d(attention output) / d(residual) is zero
+            do = ops.scatter_rows(linear_bwd(arena, dx2, ops.gather_rows(o, rows), pfx + "self_attn.o_proj.weight"), rows, x.shape[0])
+            dx2 = ops.scatter_rows(dx2, rows, x.shape[0])
+        else:
+            do = linear_bwd(arena, dx2, o, pfx + "self_attn.o_proj.weight")
         if krange is not None:
             dqkv = ops.attn_interval_bwd(qkv, o, do, lse, krange, B, S, Hq, Hkv, D, scale=D ** -0.5)
         else:
@@ -481,7 +492,7 @@ class DecoderLayerFn:
         nw = A("input_layernorm.weight")
         dx = ops.rmsnorm_bwd(x, nw.data, dh, rstd1, nw.grad, dx_add=dx2, accumulate=not nw.fresh)
         arena.grad_written(nw)
-        return (dx,) + (None,) * 15
+        return (dx,) + (None,) * 16
 
 
 class RMSNormFn:
@@ -628,7 +639,7 @@ PoolNormFn.apply = staticmethod(register_stage("pool_norm", PoolNormFn, ("T", "T
 RotaryTimeFn.apply = staticmethod(register_stage("rotary_time_stage", RotaryTimeFn, ("T", "T", "T", "A")))
 ProjectorFn.apply = staticmethod(register_stage("projector", ProjectorFn, ("T", "T", "A", "S")))
 EmbedScatterFn.apply = staticmethod(register_stage("embed_scatter", EmbedScatterFn, ("T?", "T", "A", "S", "T", "T?")))
-DecoderLayerFn.apply = staticmethod(register_stage("decoder_layer", DecoderLayerFn, ("T", "T", "A", "S", "S", "S", "S", "S", "S", "S", "T", "T", "T?", "T?", "T?", "T?")))
+DecoderLayerFn.apply = staticmethod(register_stage("decoder_layer", DecoderLayerFn, ("T", "T", "A", "S", "S", "S", "S", "S", "S", "S", "T", "T", "T?", "T?", "T?", "T?", "T?")))
 RMSNormFn.apply = staticmethod(register_stage("final_rms_norm", RMSNormFn, ("T", "T", "A", "S", "S")))
 LMHeadFn.apply = staticmethod(register_stage("lm_head", LMHeadFn, ("T", "T", "A", "S")))
 LMHeadLossFn.apply = staticmethod(register_stage("lm_head_loss", LMHeadLossFn, ("T", "T", "A", "S", "T", "T", "T?")))

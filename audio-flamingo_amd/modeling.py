@@ -729,10 +729,24 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             raise AfkError("output_attentions=True: the attention kernels never materialise the probabilities (the reference's default sdpa path returns none either)")
         want_hidden = bool(kwargs.get("output_hidden_states", getattr(self.config, "output_hidden_states", False)))
         hidden = [x.reshape(B, S, -1)] if want_hidden else None      # the reference's tuple: merged embeddings, every layer's output, ...
+        # the positions the loss reads, known before the decoder runs: behind its attention, the LAST decoder layer (and the final norm) run on those rows alone
+        # (round 6, DecoderLayerFn rows=...: a quarter of the rows on the 256-answer-token batches of the benchmark) whenever nobody asks for the hidden states or
+        # the logits of the other positions inside this call; the lazy `output.logits` of a labelled call re-runs the last layer on every row when it is read
+        shift = rows = None
+        if labels is not None:
+            shift, rows = self._valid_rows(labels) if self.loss_on_valid_rows_only else (
+                torch.nn.functional.pad(labels.to(self.device_), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous(), None)
+        last_rows = rows if (rows is not None and self.last_layer_rows_only and torch.is_grad_enabled() and not want_hidden and not return_logits
+                             and self.dec_layers > 0) else None
+        x_before_last, last_args = None, None
         for i in range(self.dec_layers):
             p = f"{lm}layers.{i}."
-            x = self._layer(F_.DecoderLayerFn.apply, x, self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D,
-                            self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo, ckpt=self.ckpt_plan is None or i < self.ckpt_plan["dec"])
+            la = (self._anchor(p + "mlp.down_proj.weight"), a, p, B, S, self.Hq, self.Hkv, self.D, self.rms_eps, cos, sin, pos, kv_len, krange, kv_lo)
+            if i + 1 == self.dec_layers and last_rows is not None:
+                x_before_last, last_args = x, la
+                x = self._layer(F_.DecoderLayerFn.apply, x, *la, last_rows, ckpt=self.ckpt_plan is None or i < self.ckpt_plan["dec"])
+            else:
+                x = self._layer(F_.DecoderLayerFn.apply, x, *la, ckpt=self.ckpt_plan is None or i < self.ckpt_plan["dec"])
             if want_hidden and i + 1 < self.dec_layers:
                 hidden.append(x.reshape(B, S, -1))
         x = F_.RMSNormFn.apply(x, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps)
@@ -741,8 +755,8 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
             hidden = tuple(hidden)
         loss, logits = None, None
         if labels is not None:
-            shift, rows = self._valid_rows(labels) if self.loss_on_valid_rows_only else (
-                torch.nn.functional.pad(labels.to(self.device_), (0, 1), value=-100)[:, 1:].reshape(-1).contiguous(), None)
+            if last_rows is not None:   # x already holds the labelled rows only, in order
+                shift, rows = shift.index_select(0, last_rows), None
             if num_items_in_batch is not None:
                 denom = torch.as_tensor(num_items_in_batch, device=self.device_, dtype=torch.float32).reshape(1)
             else:
@@ -762,14 +776,18 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         # from the DETACHED final hidden states (no second autograd branch, the step's graph is not kept alive by the output object) and only while
         # the weights are still the ones the loss was computed with: after an optimizer step the lm_head has moved, the logits would no longer
         # belong to `loss`, and the access raises instead (forward(return_logits=True) is the in-graph, forward-time path)
-        x_keep, weights_at = x.detach(), a.version()
+        x_keep, weights_at = (x if last_rows is None else x_before_last).detach(), a.version()
 
         def _lazy_logits():
             if a.version() != weights_at:
                 raise AfkError("output.logits was first read after the parameters changed (optimizer step / load_state_dict): lazy logits would be "
                                "computed with other weights than output.loss; read them before the step or call forward(return_logits=True)")
             with torch.no_grad():
-                return _logits(x_keep)
+                if last_rows is None:
+                    return _logits(x_keep)
+                # the step ran its last layer on the labelled rows only: every position's logits need that layer (and the final norm) on every row
+                xf = F_.DecoderLayerFn.apply(x_keep, *last_args)
+                return _logits(F_.RMSNormFn.apply(xf, self._anchor(lm + "norm.weight"), a, lm + "norm.weight", self.rms_eps))
 
         return AF3Output(loss=loss, logits_fn=_lazy_logits, hidden_states=hidden, audio_hidden_states=audio_hidden)
 
@@ -1018,6 +1036,7 @@ class AudioFlamingo3ForConditionalGeneration(nn.Module):
         return y
 
     decode_mfma_from = int(os.environ.get("AFK_DECODE_MFMA_FROM", "2"))   # batched decode: sequences per step from which the norm-in-prologue matrix-pipe launches run
+    last_layer_rows_only = os.environ.get("AFK_LAST_LAYER_ROWS", "1") == "1"   # training forward with labels: the last decoder layer behind its attention on the labelled rows only
     decode_chain_batch_max = int(os.environ.get("AFK_DECODE_CHAIN_BATCH_MAX", "32"))   # 9 .. 32 sequences: two / four groups of eight through the same launches (8 = the split-K tile path of rounds 3-5 above eight)
     decode_prologue_max = int(os.environ.get("AFK_DECODE_PROLOGUE_MAX", "8"))   # largest batch that takes the RMSNorm in the consumer's prologue (above: a norm launch + plain launches)
     decode_norm_mode = os.environ.get("AFK_DECODE_NORM", "prologue")   # batched decode, four sequences and more: "prologue" | "producer" | "launch" (_decode_layers_chain_batched)

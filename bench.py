@@ -1142,6 +1142,9 @@ def main():
         # lm_head + loss (forward, dgrad, wgrad) run only on the rows that carry a label: identical loss and gradients, fewer executed FLOPs.
         # model_tflops stays ALGORITHMIC (the reference's 3 x forward over every row); executed = what the kernels really did.
         skipped = 3.0 * 2 * (s_tok - N_ANSWER) * 3584 * 152064 if model.loss_on_valid_rows_only else 0.0
+        if model.loss_on_valid_rows_only and getattr(model, "last_layer_rows_only", False):
+            # round 6: behind its attention the LAST decoder layer (o_proj, MLP) runs on the labelled rows only as well (same loss, same gradients)
+            skipped += 3.0 * 2 * (s_tok - N_ANSWER) * (3584 * 3584 + 3 * 3584 * 18944)
         exec_tf = (train_flops_per_sample(s_tok, windows, rc) - skipped) * samples_per_s / world / 1e12 if full_model else None
         res = {
             "metric": "audio-sec/s + decoder tokens/s, AF3-7B bf16 train",
@@ -1186,7 +1189,8 @@ def main():
                 "achieved": 28.0 * model.trainable_numel() / (adamw_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": 28.0 * model.trainable_numel() / (adamw_ms * 1e-3) / 1e9 / 8000.0, "ms": adamw_ms, "algorithmic_bytes": 28.0 * model.trainable_numel(),
                 "note": "HIP events around the full-width AdamW launches of the extra serial step (alone on the chip); 6.29 TB/s is the achievable streaming rate (MI355X_MICROARCH.md)"},
-            "lm_head_rows": {"executed": N_ANSWER, "of": s_tok, "note": "lm_head/CE and their backward GEMMs run on the labelled rows only (same loss, same gradients)"},
+            "lm_head_rows": {"executed": N_ANSWER, "of": s_tok, "note": "lm_head/CE and their backward GEMMs run on the labelled rows only (same loss, same gradients)",
+                             "last_decoder_layer_behind_its_attention": bool(getattr(model, "last_layer_rows_only", False))},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_k256 (+ k128 for <192-tile shapes): every dense contraction (fwd, dgrad, wgrad, conv stem, lm_head)",
                          "achieved": achieved_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved_tf / 2500.0, "traffic": traffic, "traffic_detail": traffic_detail,
                          "launches": gemm_launches, "avg_launch_ms": gemm_ms / max(gemm_launches, 1),

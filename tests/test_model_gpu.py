@@ -733,6 +733,33 @@ def test_fused_bias_sums_match_the_column_sum_passes(dev, monkeypatch):
     assert n_fam >= 3 * _cfg().audio_config.num_hidden_layers - 1
 
 
+def test_last_decoder_layer_on_labelled_rows_matches_all_rows(dev, monkeypatch):
+    """round 6: with labels, the last decoder layer runs behind its attention on the rows the loss reads (modeling.last_layer_rows_only) - same loss and, up to the
+    summation order inside the GEMMs, the same gradient of EVERY parameter as the all-rows step; the lazy output.logits of such a call (every position) equal the
+    in-graph logits of a return_logits=True call"""
+    from audio_flamingo_amd.modeling import AudioFlamingo3ForConditionalGeneration as Mine
+
+    g = torch.load(os.path.join(G, "tiny64_caseB.pt"))
+    kw = dict(input_ids=g["ids"].to(dev), input_features=g["feats"].to(dev), input_features_mask=g["fmask"].to(dev), labels=g["labels"].to(dev))
+    res = {}
+    for rows_only in (False, True):
+        monkeypatch.setattr(Mine, "last_layer_rows_only", rows_only)
+        m = _fresh_model(dev, seed=17)
+        m.zero_grad()
+        out = m(**kw)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res[rows_only] = (float(out.loss), {k: b.grad.detach().clone() for k, b in m.arena.blocks.items()}, out.logits.float().clone())
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
+    worst = max((_rel(res[True][1][k], v), k) for k, v in res[False][1].items() if float(v.float().abs().max()) > 0)
+    assert worst[0] < 2e-2, worst
+    assert _rel(res[True][2], res[False][2]) < 1e-2   # lazy logits: the last layer re-run on every row
+    monkeypatch.setattr(Mine, "last_layer_rows_only", True)
+    m = _fresh_model(dev, seed=17)
+    full = m(**kw, return_logits=True).logits.float()
+    assert _rel(res[True][2], full) < 1e-2
+
+
 def test_graphed_step_matches_eager(dev):
     """graphs.GraphedTrainStep: the whole step (three streams, optimizer inside backward) captured once and replayed must leave
     bit-identical parameters / optimizer state / loss to the eager step, step after step (lr and bias corrections come from device memory)"""
